@@ -1,0 +1,318 @@
+"""TEST INFRASTRUCTURE — ctypes binding of oracle/liboracle.so (the CPU restatement).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (libyafaray_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+MAT_SHINYDIFFUSE, MAT_GLOSSY, MAT_LIGHT = 0, 1, 2
+LIGHT_AREA, LIGHT_POINT = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
+FILTER_BOX, FILTER_MITCHELL, FILTER_GAUSS, FILTER_LANCZOS = 0, 1, 2, 3
+
+f3 = C.c_float * 3
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("visibility", C.c_int32), ("receive_shadows", C.c_int32), ("flat_material", C.c_int32),
+        ("color", f3), ("mirror_color", f3),
+        ("diffuse_reflect", C.c_float), ("specular_reflect", C.c_float), ("transparency", C.c_float),
+        ("translucency", C.c_float), ("emit", C.c_float), ("ior", C.c_float),
+        ("fresnel_effect", C.c_int32), ("transmit_filter", C.c_float), ("oren_nayar", C.c_int32), ("pad0", C.c_float),
+        ("sigma", C.c_double),
+        ("glossy_color", f3), ("diffuse_color", f3),
+        ("glossy_reflect", C.c_float), ("glossy_diffuse_reflect", C.c_float), ("exponent", C.c_float),
+        ("as_diffuse", C.c_int32),
+        ("light_color", f3), ("light_power", C.c_float), ("double_sided", C.c_int32), ("pad1", C.c_int32),
+    ]
+
+
+class LightDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("samples", C.c_int32), ("cast_shadows", C.c_int32), ("pad0", C.c_int32),
+        ("corner", f3), ("point1", f3), ("point2", f3), ("color", f3), ("power", C.c_float), ("pad1", f3),
+    ]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [
+        ("from_", f3), ("to", f3), ("up", f3), ("resx", C.c_int32), ("resy", C.c_int32),
+        ("focal", C.c_float), ("aspect_ratio", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
+        ("aperture", C.c_float), ("pad0", C.c_float),
+    ]
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [
+        ("integrator", C.c_int32), ("path_samples", C.c_int32), ("bounces", C.c_int32), ("rr_min_bounces", C.c_int32),
+        ("no_recursive", C.c_int32), ("bg_transp", C.c_int32), ("bg_transp_refract", C.c_int32),
+        ("width", C.c_int32), ("height", C.c_int32), ("xstart", C.c_int32), ("ystart", C.c_int32),
+        ("aa_passes", C.c_int32), ("aa_minsamples", C.c_int32), ("aa_pixelwidth", C.c_float),
+        ("filter_type", C.c_int32), ("tile_size", C.c_int32), ("base_sampling_offset", C.c_uint32),
+        ("shadow_bias_auto", C.c_int32), ("shadow_bias", C.c_float), ("min_raydist_auto", C.c_int32),
+        ("min_raydist", C.c_float), ("aa_light_sample_multiplier", C.c_float),
+        ("background", f3), ("has_background", C.c_int32), ("tile_seed_rand", C.c_uint32),
+        ("n_threads", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("interior_steps", C.c_uint64),
+        ("leaves", C.c_uint64), ("tri_tests", C.c_uint64), ("camera_samples", C.c_uint64),
+        ("kd_nodes", C.c_uint32), ("kd_leaf_refs", C.c_uint32), ("build_seconds", C.c_double), ("render_seconds", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so with the flags in oracle/Makefile (gcc, IEEE, no fast-math)."""
+    src = os.path.join(HERE, "yaf_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "yaf_oracle.h"))):
+        subprocess.run(["make", "-C", HERE, "liboracle.so"], check=True, timeout=300,
+                       stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.yor_scene_create.restype = C.c_void_p
+    L.yor_scene_create.argtypes = [C.c_int32, fp, C.POINTER(C.c_int32), fp, C.c_int32, C.POINTER(MaterialDesc),
+                                   C.c_int32, C.POINTER(LightDesc), C.POINTER(CameraDesc)]
+    L.yor_scene_destroy.argtypes = [C.c_void_p]
+    L.yor_render.restype = C.c_int
+    L.yor_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), fp, C.POINTER(Stats)]
+    L.yor_intersect.restype = C.c_int
+    L.yor_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_float, C.POINTER(C.c_int32), fp, fp]
+    L.yor_is_shadowed.restype = C.c_int
+    L.yor_is_shadowed.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_float]
+    for name in ("yor_fsin", "yor_fcos", "yor_fexp2", "yor_flog2", "yor_fsqrt", "yor_facos"):
+        getattr(L, name).restype = C.c_float
+        getattr(L, name).argtypes = [C.c_float]
+    L.yor_fpow.restype = C.c_float
+    L.yor_fpow.argtypes = [C.c_float, C.c_float]
+    for name in ("yor_ri_vdc", "yor_ri_s", "yor_ri_lp"):
+        getattr(L, name).restype = C.c_float
+        getattr(L, name).argtypes = [C.c_uint32, C.c_uint32]
+    L.yor_fnv32a.restype = C.c_uint32
+    L.yor_fnv32a.argtypes = [C.c_uint32]
+    L.yor_scr_halton.restype = C.c_double
+    L.yor_scr_halton.argtypes = [C.c_int, C.c_uint32]
+    L.yor_halton_seq.argtypes = [C.c_uint32, C.c_uint32, C.c_int, fp]
+    L.yor_mwc_seq.argtypes = [C.c_uint32, C.c_int, fp]
+    L.yor_faure_perm.restype = C.POINTER(C.c_int)
+    L.yor_faure_perm.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.yor_create_cs.argtypes = [fp, fp, fp]
+    L.yor_sample_cos_hemisphere.argtypes = [fp, fp, fp, C.c_float, C.c_float, fp]
+    L.yor_bound_cross.restype = C.c_int
+    L.yor_bound_cross.argtypes = [fp, fp, fp, fp, C.c_float, fp, fp]
+    L.yor_camera_shoot.argtypes = [C.POINTER(CameraDesc), C.c_float, C.c_float, fp]
+    L.yor_arealight_illum_sample.restype = C.c_int
+    L.yor_arealight_illum_sample.argtypes = [C.POINTER(LightDesc), fp, C.c_float, C.c_float, fp]
+    L.yor_arealight_intersect.restype = C.c_int
+    L.yor_arealight_intersect.argtypes = [C.POINTER(LightDesc), fp, fp, fp]
+    L.yor_pointlight_illuminate.restype = C.c_int
+    L.yor_pointlight_illuminate.argtypes = [C.POINTER(LightDesc), fp, fp]
+    L.yor_material_probe.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, fp,
+                                     C.POINTER(C.c_int32), fp]
+    L.yor_lightmat_emit.argtypes = [C.POINTER(MaterialDesc), fp, fp, C.c_int, fp]
+    _lib = L
+    return L
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ------------------------------------------------------------------ descriptors from plain dicts
+def material_desc(m):
+    """m: dict with the reference's factory parameter names (material_shiny_diffuse.cc:627-646,
+    material_glossy.cc:427-439, material_simple.cc:69-71) plus 'type'."""
+    d = MaterialDesc()
+    t = m["type"]
+    vis = {"normal": 0, "no_shadows": 1, "shadow_only": 2, "invisible": 3}[m.get("visibility", "normal")]
+    d.visibility = vis
+    d.receive_shadows = int(m.get("receive_shadows", True))
+    d.flat_material = int(m.get("flat_material", False))
+    if t == "shinydiffusemat":
+        d.type = MAT_SHINYDIFFUSE
+        d.color = f3(*m.get("color", (1, 1, 1))[:3])
+        d.mirror_color = f3(*m.get("mirror_color", (1, 1, 1))[:3])
+        d.diffuse_reflect = m.get("diffuse_reflect", 1.0)
+        d.specular_reflect = m.get("specular_reflect", 0.0)
+        d.transparency = m.get("transparency", 0.0)
+        d.translucency = m.get("translucency", 0.0)
+        d.emit = m.get("emit", 0.0)
+        d.ior = m.get("IOR", 1.33)
+        d.fresnel_effect = int(m.get("fresnel_effect", False))
+        d.transmit_filter = m.get("transmit_filter", 1.0)
+        d.oren_nayar = int(m.get("diffuse_brdf", "") == "oren_nayar")
+        d.sigma = m.get("sigma", 0.1)
+    elif t == "glossy":
+        d.type = MAT_GLOSSY
+        d.glossy_color = f3(*m.get("color", (1, 1, 1))[:3])
+        d.diffuse_color = f3(*m.get("diffuse_color", (1, 1, 1))[:3])
+        d.glossy_diffuse_reflect = m.get("diffuse_reflect", 0.0)
+        d.glossy_reflect = m.get("glossy_reflect", 1.0)
+        d.exponent = m.get("exponent", 50.0)
+        d.as_diffuse = int(m.get("as_diffuse", True))
+        d.oren_nayar = int(m.get("diffuse_brdf", "") == "Oren-Nayar")
+        d.sigma = m.get("sigma", 0.1)
+    elif t == "light_mat":
+        d.type = MAT_LIGHT
+        d.light_color = f3(*m.get("color", (1, 1, 1))[:3])
+        d.light_power = m.get("power", 1.0)
+        d.double_sided = int(m.get("double_sided", False))
+    else:
+        raise ValueError(t)
+    return d
+
+
+def light_desc(l):
+    d = LightDesc()
+    d.cast_shadows = int(l.get("cast_shadows", True))
+    d.color = f3(*l.get("color", (1, 1, 1))[:3])
+    d.power = l.get("power", 1.0)
+    if l["type"] == "arealight":
+        d.type = LIGHT_AREA
+        d.samples = l.get("samples", 4)
+        d.corner = f3(*l.get("corner", (0, 0, 0)))
+        d.point1 = f3(*l.get("point1", (0, 0, 0)))
+        d.point2 = f3(*l.get("point2", (0, 0, 0)))
+    elif l["type"] == "pointlight":
+        d.type = LIGHT_POINT
+        d.corner = f3(*l.get("from", (0, 0, 0)))
+    else:
+        raise ValueError(l["type"])
+    return d
+
+
+def camera_desc(c):
+    d = CameraDesc()
+    d.from_ = f3(*c.get("from", (0, 1, 0)))
+    d.to = f3(*c.get("to", (0, 0, 0)))
+    d.up = f3(*c.get("up", (0, 1, 1)))
+    d.resx = c.get("resx", 320)
+    d.resy = c.get("resy", 200)
+    d.focal = c.get("focal", 1.0)
+    d.aspect_ratio = c.get("aspect_ratio", 1.0)
+    d.near_clip = c.get("nearClip", 0.0)
+    d.far_clip = c.get("farClip", -1.0)
+    d.aperture = c.get("aperture", 0.0)
+    return d
+
+
+def render_desc(r):
+    d = RenderDesc()
+    d.integrator = {"pathtracing": INTEGRATOR_PATH, "directlighting": INTEGRATOR_DIRECT}[r.get("integrator", "pathtracing")]
+    d.path_samples = r.get("path_samples", 32)
+    d.bounces = r.get("bounces", 3)
+    d.rr_min_bounces = r.get("russian_roulette_min_bounces", 0)
+    d.no_recursive = int(r.get("no_recursive", False))
+    d.bg_transp = int(r.get("bg_transp", False))
+    d.bg_transp_refract = int(r.get("bg_transp_refract", False))
+    d.width = r["width"]
+    d.height = r["height"]
+    d.xstart = r.get("xstart", 0)
+    d.ystart = r.get("ystart", 0)
+    d.aa_passes = r.get("AA_passes", 1)
+    d.aa_minsamples = r.get("AA_minsamples", 1)
+    d.aa_pixelwidth = r.get("AA_pixelwidth", 1.5)
+    d.filter_type = {"box": 0, "mitchell": 1, "gauss": 2, "lanczos": 3}[r.get("filter_type", "box")]
+    d.tile_size = r.get("tile_size", 32)
+    d.base_sampling_offset = r.get("adv_base_sampling_offset", 0) + 100000 * r.get("adv_computer_node", 0)
+    d.shadow_bias_auto = int(r.get("adv_auto_shadow_bias_enabled", True))
+    d.shadow_bias = r.get("adv_shadow_bias_value", 0.0005)
+    d.min_raydist_auto = int(r.get("adv_auto_min_raydist_enabled", True))
+    d.min_raydist = r.get("adv_min_raydist_value", 0.00005)
+    d.aa_light_sample_multiplier = 1.0
+    bg = r.get("background")
+    if bg is not None:
+        d.background = f3(*bg)
+        d.has_background = 1
+    d.tile_seed_rand = r.get("tile_seed_rand", 0)
+    d.n_threads = r.get("oracle_threads", 1)
+    d.shard_index = r.get("shard_index", 0)
+    d.shard_count = r.get("shard_count", 1)
+    return d
+
+
+class OracleScene:
+    """A scene description dict -> oracle scene.  scene = {verts: (N,3,3) f32, tri_mat: (N,) i32,
+    vnormals: None | (N,3,3) f32, materials: [dict], lights: [dict], camera: dict}."""
+
+    def __init__(self, scene):
+        L = lib()
+        self.verts = np.ascontiguousarray(scene["verts"], dtype=np.float32).reshape(-1, 9)
+        self.tri_mat = np.ascontiguousarray(scene["tri_mat"], dtype=np.int32)
+        n = self.verts.shape[0]
+        vn = scene.get("vnormals")
+        self.vn = None if vn is None else np.ascontiguousarray(vn, dtype=np.float32).reshape(-1, 9)
+        mats = (MaterialDesc * len(scene["materials"]))(*[material_desc(m) for m in scene["materials"]])
+        lights = (LightDesc * max(1, len(scene["lights"])))(*[light_desc(l) for l in scene["lights"]])
+        cam = camera_desc(scene["camera"])
+        self.h = L.yor_scene_create(n, fptr(self.verts), self.tri_mat.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    None if self.vn is None else fptr(self.vn),
+                                    len(scene["materials"]), mats, len(scene["lights"]), lights, C.byref(cam))
+
+    def render(self, render):
+        L = lib()
+        rd = render_desc(render)
+        film = np.zeros((rd.height, rd.width, 5), dtype=np.float32)
+        st = Stats()
+        rc = L.yor_render(self.h, C.byref(rd), fptr(film), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"oracle: unsupported configuration (code {rc})")
+        return film, st
+
+    def intersect(self, frm, dr, tmin=0.0, tmax=-1.0, use_tree=True):
+        L = lib()
+        f = np.asarray(frm, dtype=np.float32)
+        d = np.asarray(dr, dtype=np.float32)
+        tri = C.c_int32()
+        t = C.c_float()
+        bary = np.zeros(3, dtype=np.float32)
+        hit = L.yor_intersect(self.h, int(use_tree), fptr(f), fptr(d), tmin, tmax, C.byref(tri), C.byref(t), fptr(bary))
+        return hit, tri.value, t.value, bary
+
+    def is_shadowed(self, frm, dr, tmin, tmax, use_tree=True):
+        L = lib()
+        f = np.asarray(frm, dtype=np.float32)
+        d = np.asarray(dr, dtype=np.float32)
+        return L.yor_is_shadowed(self.h, int(use_tree), fptr(f), fptr(d), tmin, tmax)
+
+    def close(self):
+        if self.h:
+            lib().yor_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def film_to_rgb(film):
+    """Pixel::normalized, util_image_buffers.h:39-43: col/weight when weight != 0."""
+    w = film[..., 4:5]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.where(w != 0, film[..., :4] / w, 0.0)
+    return out.astype(np.float32)

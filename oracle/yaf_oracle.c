@@ -1,0 +1,2163 @@
+/* TEST INFRASTRUCTURE — CPU oracle (plain C restatement of the reference's path-tracing hot
+ * path).  Never linked into or called from the product; see yaf_oracle.h for who may use it
+ * and for the pinning status of each part.
+ *
+ * All citations are file:line in /root/reference.  Arithmetic types follow the reference
+ * expression by expression: where the C++ source mixes float with double literals the
+ * double intermediate is kept, because the result differs in the last bits otherwise.
+ * Build with -ffp-contract=off and without -ffast-math (oracle/Makefile).
+ */
+#define _GNU_SOURCE
+#include "yaf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <time.h>
+#include <pthread.h>
+
+/* ------------------------------------------------------------------ constants */
+#define Y_M_PI     3.14159265358979323846
+#define Y_M_PI_2   1.57079632679489661923
+#define Y_M_1_PI   0.31830988618379067154
+#define Y_M_2PI    6.28318530717958647692  /* util_math_optimizations.h:84 */
+#define Y_M_1_2PI  0.15915494309189533577  /* :86 */
+#define Y_M_4_PI   1.27323954473516268615  /* :87 */
+#define Y_M_4_PI2  0.40528473456935108578  /* :88 */
+#define MIN_RAYDIST     0.00005            /* CMakeLists.txt:46-48 */
+#define YAF_SHADOW_BIAS 0.0005             /* CMakeLists.txt:50-52 */
+#define KD_MAX_STACK 64                    /* kdtree_triangle.cc:43 */
+
+/* BsdfFlags, material.h:49-64 */
+enum {
+	BSDF_NONE = 0, BSDF_SPECULAR = 1, BSDF_GLOSSY = 2, BSDF_DIFFUSE = 4, BSDF_DISPERSIVE = 8,
+	BSDF_REFLECT = 0x10, BSDF_TRANSMIT = 0x20, BSDF_FILTER = 0x40, BSDF_EMIT = 0x80, BSDF_VOLUMETRIC = 0x100,
+	BSDF_ALL = BSDF_SPECULAR | BSDF_GLOSSY | BSDF_DIFFUSE | BSDF_DISPERSIVE | BSDF_REFLECT | BSDF_TRANSMIT | BSDF_FILTER
+};
+enum { VIS_NORMAL = 0, VIS_NO_SHADOWS = 1, VIS_SHADOW_ONLY = 2, VIS_INVISIBLE = 3 };
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float r, g, b; } rgb;
+
+static inline v3 V(float x, float y, float z) { v3 v = {x, y, z}; return v; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* vector.h:159-167: both Vec3*float overloads compute f*b.x_ */
+static inline v3 vmul(v3 b, float f) { return V(f * b.x, f * b.y, f * b.z); }
+/* vector.h:154 */
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }
+/* vector.h:194 */
+static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float vcomp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+static inline rgb C(float r, float g, float b) { rgb c = {r, g, b}; return c; }
+static inline rgb cadd(rgb a, rgb b) { return C(a.r + b.r, a.g + b.g, a.b + b.b); }
+static inline rgb cmul(rgb a, rgb b) { return C(a.r * b.r, a.g * b.g, a.b * b.b); }
+static inline rgb cscale(rgb b, float f) { return C(f * b.r, f * b.g, f * b.b); }   /* color.h:261-269 */
+static inline rgb cdiv(rgb b, float f) { return C(b.r / f, b.g / f, b.b / f); }       /* color.h:271 */
+static inline int cblack(rgb c) { return c.r == 0 && c.g == 0 && c.b == 0; }
+static inline float fmaxf_(float a, float b) { return a < b ? b : a; } /* std::max(a,b) */
+static inline float fminf_(float a, float b) { return b < a ? b : a; } /* std::min(a,b) */
+
+/* ------------------------------------------------------------------ fast math
+ * util_math_optimizations.h:90-253 (FAST_MATH and FAST_TRIG are ON by default, CMakeLists.txt:22-23) */
+typedef union { int32_t i; float f; } bit_twiddler;
+
+float yor_fexp2(float x) /* :116-129 */
+{
+	bit_twiddler ipart, fpart, expipart;
+	x = fminf_(x, 129.00000f);
+	x = fmaxf_(x, -126.99999f);
+	ipart.i = (int32_t)(x - 0.5f);
+	fpart.f = (x - (float)(ipart.i));
+	expipart.i = (int32_t)((uint32_t)(ipart.i + 127) << 23);
+	{
+		float p = fpart.f; /* POLYEXP :93, all-float */
+		float poly = (float)(p * (p * (p * (p * (p * 1.8775767e-3f + 8.9893397e-3f) + 5.5826318e-2f) + 2.4015361e-1f) + 6.9315308e-1f) + 9.9999994e-1f);
+		return (expipart.f * poly);
+	}
+}
+
+float yor_flog2(float x) /* :131-142 */
+{
+	bit_twiddler one, i, m, e;
+	one.f = 1.0f;
+	i.f = x;
+	e.f = (float)(((i.i & 0x7F800000) >> 23) - 127);
+	m.i = ((i.i & 0x7FFFFF) | one.i);
+	{
+		/* POLYLOG :94 — the constant 2.5988452 has no f suffix, so from there on the Horner
+		 * chain runs in double and is narrowed once at the end */
+		float xx = m.f;
+		float a = xx * -3.4436006e-2f + 3.1821337e-1f;
+		float b = xx * a + -1.2315303f;
+		double c = (double)(xx * b) + 2.5988452;
+		double d = (double)xx * c + (double)-3.3241990f;
+		double ee = (double)xx * d + (double)3.1157899f;
+		float poly = (float)ee;
+		return (poly * (m.f - one.f) + e.f);
+	}
+}
+
+float yor_fpow(float a, float b) { return yor_fexp2(yor_flog2(a) * b); } /* :176-183 */
+float yor_fsqrt(float a) { return sqrtf(a); }                              /* :203-210, :168 */
+
+float yor_fsin(float x) /* :222-244 */
+{
+	if((double)x > Y_M_2PI || (double)x < -Y_M_2PI) x -= ((int)(x * (float)Y_M_1_2PI)) * (float)Y_M_2PI;
+	if((double)x < -Y_M_PI) x += (float)Y_M_2PI;
+	else if((double)x > Y_M_PI) x -= (float)Y_M_2PI;
+	x = ((float)Y_M_4_PI * x) - ((float)Y_M_4_PI2 * x * fabsf(x));
+	{
+		float result = 0.225f * (x * fabsf(x) - x) + x;
+		if((double)result <= -1.0) return -1.0f;
+		else if((double)result >= 1.0) return 1.0f;
+		else return result;
+	}
+}
+float yor_fcos(float x) { return yor_fsin(x + (float)Y_M_PI_2); } /* :246-253 */
+float yor_facos(float x) /* :255-261 */
+{
+	if((double)x <= -1.0) return (float)Y_M_PI;
+	else if((double)x >= 1.0) return 0.0f;
+	else return acosf(x);
+}
+
+/* vector.h:227-238 */
+static inline v3 vnormalize(v3 v)
+{
+	float len = v.x * v.x + v.y * v.y + v.z * v.z;
+	if(len != 0)
+	{
+		len = (float)(1.0 / (double)yor_fsqrt(len));
+		v.x *= len; v.y *= len; v.z *= len;
+	}
+	return v;
+}
+static inline float vlength(v3 v) { return yor_fsqrt(v.x * v.x + v.y * v.y + v.z * v.z); } /* vector.h:222 */
+
+/* vector.h:319-337 */
+static void create_cs(v3 n, v3 *u, v3 *v)
+{
+	if((n.x == 0) && (n.y == 0))
+	{
+		if(n.z < 0) *u = V(-1, 0, 0);
+		else *u = V(1, 0, 0);
+		*v = V(0, 1, 0);
+	}
+	else
+	{
+		const float d = (float)(1.0 / (double)yor_fsqrt(n.y * n.y + n.x * n.x));
+		*u = V(n.y * d, -n.x * d, 0);
+		*v = vcross(n, *u);
+	}
+}
+
+/* vector.h:273-278 */
+static inline v3 reflect_dir(v3 n, v3 v)
+{
+	const float vn = vdot(v, n);
+	if(vn < 0) return vneg(v);
+	/* 2 * vn * n - v : (2*vn) float, Vec3 scale, minus */
+	return vsub(vmul(n, 2 * vn), v);
+}
+
+/* ------------------------------------------------------------------ QMC
+ * util_mcqmc.h, scr_halton.h */
+#define MULT_RATIO 0.00000000023283064365386962890625 /* util_mcqmc.h:91 */
+
+static inline float clamp01f(float v) { return fmaxf_(0.f, fminf_(1.f, v)); }
+
+float yor_ri_vdc(uint32_t bits, uint32_t r) /* util_mcqmc.h:93-101 */
+{
+	bits = (bits << 16) | (bits >> 16);
+	bits = ((bits & 0x00ff00ff) << 8) | ((bits & 0xff00ff00) >> 8);
+	bits = ((bits & 0x0f0f0f0f) << 4) | ((bits & 0xf0f0f0f0) >> 4);
+	bits = ((bits & 0x33333333) << 2) | ((bits & 0xcccccccc) >> 2);
+	bits = ((bits & 0x55555555) << 1) | ((bits & 0xaaaaaaaa) >> 1);
+	return clamp01f((float)((double)(bits ^ r) * MULT_RATIO));
+}
+float yor_ri_s(uint32_t i, uint32_t r) /* :103-108 */
+{
+	for(uint32_t v = 1u << 31; i; i >>= 1, v ^= v >> 1)
+		if(i & 1) r ^= v;
+	return clamp01f((float)((double)r * MULT_RATIO));
+}
+float yor_ri_lp(uint32_t i, uint32_t r) /* :110-115 */
+{
+	for(uint32_t v = 1u << 31; i; i >>= 1, v |= v >> 1)
+		if(i & 1) r ^= v;
+	return clamp01f((float)((double)r * MULT_RATIO));
+}
+uint32_t yor_fnv32a(uint32_t value) /* :147-163 (little-endian byte order of the union) */
+{
+	uint32_t hash = 0x811c9dc5u;
+	for(int i = 0; i < 4; i++)
+	{
+		hash ^= (value >> (8 * i)) & 0xffu;
+		hash *= 0x01000193u;
+	}
+	return hash;
+}
+
+/* Halton, util_mcqmc.h:28-87 */
+typedef struct { uint32_t base; double inv_base, value; } halton_t;
+static void halton_init(halton_t *h, int base) { h->base = (uint32_t)base; h->inv_base = 1.0 / (double)base; h->value = 0; }
+static void halton_set_start(halton_t *h, uint32_t i)
+{
+	double factor = h->inv_base;
+	h->value = 0.0;
+	while(i > 0)
+	{
+		h->value += (double)(i % h->base) * factor;
+		i /= h->base;
+		factor *= h->inv_base;
+	}
+}
+static float halton_next(halton_t *h)
+{
+	double r = 0.9999999999 - h->value;
+	if(h->inv_base < r) h->value += h->inv_base;
+	else
+	{
+		double hh = 0.0, hv = h->inv_base;
+		while(hv >= r) { hh = hv; hv *= h->inv_base; }
+		h->value += hh + hv - 1.0;
+	}
+	return fmaxf_(0.f, fminf_(1.f, (float)h->value));
+}
+void yor_halton_seq(uint32_t base, uint32_t start, int count, float *out)
+{
+	halton_t h; halton_init(&h, (int)base); halton_set_start(&h, start);
+	for(int i = 0; i < count; ++i) out[i] = halton_next(&h);
+}
+
+/* MWC PRNG, util_mcqmc.h:173-192 */
+typedef struct { uint32_t x, c; } mwc_t;
+static void mwc_init(mwc_t *p, uint32_t seed) { p->x = 30903; p->c = seed; }
+static double mwc_next(mwc_t *p)
+{
+	const uint32_t ya = 1791398085u, yah = ya >> 16, yal = ya & 65535u;
+	const uint32_t xh = p->x >> 16, xl = p->x & 65535u;
+	p->x = p->x * ya + p->c;
+	p->c = xh * yah + ((xh * yal) >> 16) + ((xl * yah) >> 16);
+	if(xl * yal >= ~p->c + 1) p->c++;
+	return (double)p->x * MULT_RATIO;
+}
+void yor_mwc_seq(uint32_t seed, int count, float *out)
+{
+	mwc_t p; mwc_init(&p, seed);
+	for(int i = 0; i < count; ++i) out[i] = (float)mwc_next(&p);
+}
+
+/* scr_halton.h:29-47.  The Faure permutations (faure_tables.cc) are not copied: they are
+ * regenerated with Faure's construction and a test compares them with the reference file.
+ * Dimensions 0,1,2 all use the length-3 identity (faure_tables.cc:437). */
+static const int prims[50] = {1, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67,
+                              71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167,
+                              173, 179, 181, 191, 193, 197, 199, 211, 223, 227};
+/* the reference's 9-digit truncated inverses, scr_halton.h:37-47 (these are data: 1/p printed to 9 decimals) */
+static double inv_prims[50];
+static int *faure_tab[50];
+static int faure_ready = 0;
+static pthread_once_t faure_once = PTHREAD_ONCE_INIT;
+
+static void faure_build(int b, int *out) /* Faure 1992: sigma_b from sigma_{b/2} (even) or sigma_{b-1} (odd) */
+{
+	if(b == 2) { out[0] = 0; out[1] = 1; return; }
+	if(b % 2 == 0)
+	{
+		int h = b / 2;
+		int *half = (int *)malloc(sizeof(int) * (size_t)h);
+		faure_build(h, half);
+		for(int i = 0; i < h; ++i) { out[i] = 2 * half[i]; out[h + i] = 2 * half[i] + 1; }
+		free(half);
+	}
+	else
+	{
+		int m = (b - 1) / 2;
+		int *prev = (int *)malloc(sizeof(int) * (size_t)(b - 1));
+		faure_build(b - 1, prev);
+		for(int i = 0; i < b - 1; ++i) if(prev[i] >= m) prev[i]++;
+		for(int i = 0; i < m; ++i) out[i] = prev[i];
+		out[m] = m;
+		for(int i = m; i < b - 1; ++i) out[i + 1] = prev[i];
+		free(prev);
+	}
+}
+static void faure_init(void)
+{
+	for(int d = 0; d < 50; ++d)
+	{
+		/* 1/p rounded to 9 decimals, as printed in scr_halton.h:37-47 */
+		double q = floor(1e9 / (double)prims[d] + 0.5);
+		char buf[32];
+		snprintf(buf, sizeof buf, "%.9f", q / 1e9);
+		inv_prims[d] = strtod(buf, NULL);
+		int b = d < 3 ? 3 : prims[d];
+		faure_tab[d] = (int *)malloc(sizeof(int) * (size_t)b);
+		if(d < 3) { faure_tab[d][0] = 0; faure_tab[d][1] = 1; faure_tab[d][2] = 2; }
+		else faure_build(b, faure_tab[d]);
+	}
+	faure_ready = 1;
+}
+const int *yor_faure_perm(int dim, int *len)
+{
+	pthread_once(&faure_once, faure_init);
+	*len = dim < 3 ? 3 : prims[dim];
+	return faure_tab[dim];
+}
+
+double yor_scr_halton(int dim, uint32_t n) /* scr_halton.h:52-75 */
+{
+	double value = 0.0;
+	pthread_once(&faure_once, faure_init);
+	if(dim < 50)
+	{
+		const int *sigma = faure_tab[dim];
+		uint32_t base = (uint32_t)prims[dim];
+		double f, factor, dn = (double)n;
+		f = factor = inv_prims[dim];
+		while(n > 0)
+		{
+			value += (double)(sigma[n % base]) * factor;
+			dn *= f;
+			n = (uint32_t)dn;
+			factor *= f;
+		}
+	}
+	else
+	{
+		/* dim >= 50 falls back to a global racy LCG in the reference (scr_halton.h:70-73); the
+		 * path tracer reaches it only for bounces > 12, which yor_render rejects */
+		value = 0.5;
+	}
+	return fmax(1.0e-36, fmin(1.0, value));
+}
+
+static inline float add_mod1(float a, float b) { float s = a + b; return s > 1 ? s - 1.f : s; } /* util_sample.h:183-187 */
+
+/* util_sample.h:45-55 */
+static v3 sample_cos_hemisphere(v3 n, v3 ru, v3 rv, float s_1, float s_2)
+{
+	if(s_1 >= 1.0f) return n;
+	else
+	{
+		float z_1 = s_1;
+		float z_2 = (float)((double)s_2 * Y_M_2PI);
+		v3 a = vadd(vmul(ru, yor_fcos(z_2)), vmul(rv, yor_fsin(z_2)));
+		return vadd(vmul(a, yor_fsqrt((float)(1.0 - (double)z_1))), vmul(n, yor_fsqrt(z_1)));
+	}
+}
+
+/* ------------------------------------------------------------------ bound.h:144-212 */
+static int bound_cross(v3 a_0, v3 a_1, v3 from, v3 dir, float *enter, float *leave, float dist)
+{
+	v3 p = vsub(from, a_0);
+	float lmin = (float)-1e38, lmax = (float)1e38, ltmin, ltmax;
+	if(dir.x != 0)
+	{
+		float invrx = (float)(1. / (double)dir.x);
+		if(invrx > 0) { lmin = -p.x * invrx; lmax = ((a_1.x - a_0.x) - p.x) * invrx; }
+		else { lmin = ((a_1.x - a_0.x) - p.x) * invrx; lmax = -p.x * invrx; }
+		if((lmax < 0) || (lmin > dist)) return 0;
+	}
+	if(dir.y != 0)
+	{
+		float invry = (float)(1. / (double)dir.y);
+		if(invry > 0) { ltmin = -p.y * invry; ltmax = ((a_1.y - a_0.y) - p.y) * invry; }
+		else { ltmin = ((a_1.y - a_0.y) - p.y) * invry; ltmax = -p.y * invry; }
+		lmin = fmaxf_(ltmin, lmin);
+		lmax = fminf_(ltmax, lmax);
+		if((lmax < 0) || (lmin > dist)) return 0;
+	}
+	if(dir.z != 0)
+	{
+		float invrz = (float)(1. / (double)dir.z);
+		if(invrz > 0) { ltmin = -p.z * invrz; ltmax = ((a_1.z - a_0.z) - p.z) * invrz; }
+		else { ltmin = ((a_1.z - a_0.z) - p.z) * invrz; ltmax = -p.z * invrz; }
+		lmin = fmaxf_(ltmin, lmin);
+		lmax = fminf_(ltmax, lmax);
+		if((lmax < 0) || (lmin > dist)) return 0;
+	}
+	if((lmin <= lmax) && (lmax >= 0) && (lmin <= dist))
+	{
+		*enter = lmin;
+		*leave = lmax;
+		return 1;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------ scene data */
+typedef struct
+{
+	v3 a, e1, e2;      /* vertex a and cached edges, triangle.h:197-205 */
+	float eps;         /* intersection_bias_factor_, triangle.h:206 */
+	v3 ng;             /* recNormal, triangle.h:295-302 */
+	int mat;
+	int smooth;        /* has per-vertex normals */
+	v3 na, nb, nc;
+	v3 b, c;
+} tri_t;
+
+typedef struct
+{
+	int type, visibility, receive_shadows, flat;
+	unsigned flags;
+	/* shinydiffuse state after config(), material_shiny_diffuse.cc:46-92 */
+	rgb diffuse_color, mirror_color, emit_color;
+	float mirror_strength, transparency_strength, translucency_strength, diffuse_strength, emit_strength, transmit_filter;
+	int is_mirror, is_transparent, is_translucent, is_diffuse, has_fresnel;
+	float ior_squared;
+	int use_oren; float oren_a, oren_b;
+	int n_bsdf; unsigned c_flags[4]; int c_index[4];
+	/* glossy */
+	rgb gloss_color, diff_color;
+	float exponent, reflectivity, diffuse;
+	int as_diffuse, with_diffuse;
+	/* light mat */
+	rgb light_col; int double_sided;
+} mat_t;
+
+typedef struct
+{
+	int type, samples, cast_shadows;
+	/* area, light_area.cc:34-52 */
+	v3 corner, c2, c3, c4, to_x, to_y, normal, fnormal;
+	rgb color;
+	float area, inv_area;
+	/* point, light_point.cc:28-36 */
+	v3 position;
+} light_t;
+
+typedef struct
+{
+	v3 position, cam_x, cam_y, cam_z, vto, vup, vright;
+	v3 near_p, near_n, far_p, far_n;
+	int resx, resy;
+	float aspect_ratio, focal, aperture;
+} camera_t;
+
+typedef struct { union { float split; uint32_t first; } u; uint32_t flags; } kdnode_t; /* kdtree_triangle.h:48-86, pointers -> indices */
+
+struct yor_scene
+{
+	int n_tris; tri_t *tris;
+	int n_mats; mat_t *mats;
+	int n_lights; light_t *lights;
+	camera_t cam;
+	/* kd tree */
+	kdnode_t *nodes; uint32_t n_nodes, cap_nodes;
+	uint32_t *leaf_refs; uint32_t n_refs, cap_refs;
+	v3 tb_a, tb_g; /* tree bound */
+	double build_seconds;
+};
+
+/* per-thread counters */
+typedef struct { uint64_t rays_closest, rays_shadow, interior, leaves, tests; } counters_t;
+
+/* ------------------------------------------------------------------ triangle.h:223-259 */
+static inline int tri_intersect(const tri_t *tr, v3 from, v3 dir, float *t, float *u_out, float *v_out)
+{
+	v3 pvec = vcross(dir, tr->e2);
+	float det = vdot(tr->e1, pvec);
+	float epsilon = tr->eps;
+	if(det > -epsilon && det < epsilon) return 0;
+	{
+		float inv_det = 1.f / det;
+		v3 tvec = vsub(from, tr->a);
+		float u = vdot(tvec, pvec) * inv_det;
+		if(u < 0.f || u > 1.f) return 0;
+		{
+			v3 qvec = vcross(tvec, tr->e1);
+			float v = vdot(dir, qvec) * inv_det;
+			if((v < 0.f) || ((u + v) > 1.f)) return 0;
+			*t = vdot(tr->e2, qvec) * inv_det;
+			if(*t < epsilon) return 0;
+			*u_out = u; *v_out = v;
+			return 1;
+		}
+	}
+}
+
+static inline int mat_visible_primary(const mat_t *m) { return m->visibility == VIS_NORMAL || m->visibility == VIS_NO_SHADOWS; }  /* kdtree_triangle.cc:786 */
+static inline int mat_visible_shadow(const mat_t *m) { return m->visibility == VIS_NORMAL || m->visibility == VIS_SHADOW_ONLY; }   /* :938 */
+
+/* ------------------------------------------------------------------ kd-tree build (our own; K4 is not mirrored)
+ * Only the *results* of intersect/intersectS are contractual.  Parameters follow
+ * scene.cc:818 and kdtree_triangle.cc:89-100: max depth 7+1.66 ln N capped at 64, leaf size 1,
+ * cost ratio 0.8 (+ penalty above 65536 prims), empty bonus 0.33.  Split search is a 32-bin SAH
+ * over triangle bounds; a triangle is referenced by every leaf its bounding box overlaps. */
+typedef struct { v3 lo, hi; } aabb_t;
+typedef struct
+{
+	yor_scene *s;
+	const aabb_t *tb;
+	int max_depth;
+	float cost_ratio, e_bonus;
+} build_ctx;
+
+static uint32_t kd_alloc_node(yor_scene *s)
+{
+	if(s->n_nodes == s->cap_nodes)
+	{
+		s->cap_nodes = s->cap_nodes ? s->cap_nodes * 2 : 1024;
+		s->nodes = (kdnode_t *)realloc(s->nodes, sizeof(kdnode_t) * s->cap_nodes);
+	}
+	return s->n_nodes++;
+}
+static void kd_make_leaf(yor_scene *s, uint32_t node, const uint32_t *prims_idx, uint32_t np)
+{
+	if(s->n_refs + np > s->cap_refs)
+	{
+		while(s->n_refs + np > s->cap_refs) s->cap_refs = s->cap_refs ? s->cap_refs * 2 : 4096;
+		s->leaf_refs = (uint32_t *)realloc(s->leaf_refs, sizeof(uint32_t) * s->cap_refs);
+	}
+	s->nodes[node].u.first = s->n_refs;
+	s->nodes[node].flags = (np << 2) | 3u;
+	memcpy(s->leaf_refs + s->n_refs, prims_idx, sizeof(uint32_t) * np);
+	s->n_refs += np;
+}
+
+#define KD_BINS 32
+static void kd_build(build_ctx *c, uint32_t node, aabb_t box, uint32_t *prims_idx, uint32_t np, int depth, int bad_refines)
+{
+	yor_scene *s = c->s;
+	if(np <= 1 || depth >= c->max_depth) { kd_make_leaf(s, node, prims_idx, np); return; }
+	float d[3] = {box.hi.x - box.lo.x, box.hi.y - box.lo.y, box.hi.z - box.lo.z};
+	float lo[3] = {box.lo.x, box.lo.y, box.lo.z};
+	float total_sa = d[0] * d[1] + d[0] * d[2] + d[1] * d[2];
+	float inv_total_sa = total_sa > 0 ? 1.f / total_sa : 0.f;
+	float best_cost = INFINITY, old_cost = (float)np;
+	int best_axis = -1; float best_pos = 0;
+	uint32_t best_nl = 0, best_nr = 0;
+	for(int axis = 0; axis < 3; ++axis)
+	{
+		if(!(d[axis] > 0)) continue;
+		uint32_t cnt_lo[KD_BINS + 1], cnt_hi[KD_BINS + 1];
+		memset(cnt_lo, 0, sizeof cnt_lo); memset(cnt_hi, 0, sizeof cnt_hi);
+		float scale = (float)KD_BINS / d[axis];
+		for(uint32_t i = 0; i < np; ++i)
+		{
+			const aabb_t *b = &c->tb[prims_idx[i]];
+			float bl = vcomp(b->lo, axis), bh = vcomp(b->hi, axis);
+			int il = (int)floorf((bl - lo[axis]) * scale); if(il < 0) il = 0; if(il > KD_BINS) il = KD_BINS;
+			int ih = (int)ceilf((bh - lo[axis]) * scale); if(ih < 0) ih = 0; if(ih > KD_BINS) ih = KD_BINS;
+			/* il: first plane index k (plane k at lo + k/scale) with plane > bl is il+1 -> counted left of planes > il
+			 * ih: prim ends at or before plane ih */
+			cnt_lo[il]++; cnt_hi[ih]++;
+		}
+		/* plane k (1..KD_BINS-1): n_left = #prims with il < k ; n_right = #prims with ih > k */
+		uint32_t nl = 0, nr = np;
+		int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+		for(int k = 1; k < KD_BINS; ++k)
+		{
+			nl += cnt_lo[k - 1];
+			nr -= cnt_hi[k];
+			/* prims ending exactly at plane k were removed from the right; those with ih==k and il<k stay left */
+			float pos = lo[axis] + (float)k / scale;
+			float l1 = pos - lo[axis], l2 = d[axis] - l1;
+			float below_sa = d[a1] * d[a2] + l1 * (d[a1] + d[a2]);
+			float above_sa = d[a1] * d[a2] + l2 * (d[a1] + d[a2]);
+			float eb = (nl == 0 || nr == 0) ? c->e_bonus : 0.f;
+			float cost = c->cost_ratio + inv_total_sa * (below_sa * (float)nl + above_sa * (float)nr) * (1.f - eb);
+			if(cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; best_nl = nl; best_nr = nr; }
+		}
+	}
+	if(best_axis < 0) { kd_make_leaf(s, node, prims_idx, np); return; }
+	if(best_cost > old_cost) ++bad_refines;
+	if((best_cost > 1.6f * old_cost && np < 16) || bad_refines >= 2) { kd_make_leaf(s, node, prims_idx, np); return; }
+	(void)best_nl; (void)best_nr;
+	/* partition: conservative on the bounds (<= / >= so that a prim lying in the plane goes to both) */
+	uint32_t *left = (uint32_t *)malloc(sizeof(uint32_t) * np), *right = (uint32_t *)malloc(sizeof(uint32_t) * np);
+	uint32_t nl = 0, nr = 0;
+	for(uint32_t i = 0; i < np; ++i)
+	{
+		const aabb_t *b = &c->tb[prims_idx[i]];
+		float bl = vcomp(b->lo, best_axis), bh = vcomp(b->hi, best_axis);
+		if(bl <= best_pos) left[nl++] = prims_idx[i];
+		if(bh >= best_pos) right[nr++] = prims_idx[i];
+	}
+	if(nl == np && nr == np) { free(left); free(right); kd_make_leaf(s, node, prims_idx, np); return; }
+	s->nodes[node].u.split = best_pos;
+	s->nodes[node].flags = (uint32_t)best_axis;
+	aabb_t lb = box, rb = box;
+	if(best_axis == 0) { lb.hi.x = best_pos; rb.lo.x = best_pos; }
+	else if(best_axis == 1) { lb.hi.y = best_pos; rb.lo.y = best_pos; }
+	else { lb.hi.z = best_pos; rb.lo.z = best_pos; }
+	uint32_t lchild = kd_alloc_node(s); /* == node + 1 */
+	kd_build(c, lchild, lb, left, nl, depth + 1, bad_refines);
+	free(left);
+	uint32_t rchild = kd_alloc_node(s);
+	s->nodes[node].flags = (s->nodes[node].flags & 3u) | (rchild << 2);
+	kd_build(c, rchild, rb, right, nr, depth + 1, bad_refines);
+	free(right);
+}
+
+static void build_tree(yor_scene *s)
+{
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	int np = s->n_tris;
+	s->n_nodes = 0; s->n_refs = 0;
+	if(np <= 0) { s->build_seconds = 0; return; }
+	aabb_t *tb = (aabb_t *)malloc(sizeof(aabb_t) * (size_t)np);
+	aabb_t all;
+	for(int i = 0; i < np; ++i)
+	{
+		const tri_t *t = &s->tris[i];
+		tb[i].lo = V(fminf(fminf(t->a.x, t->b.x), t->c.x), fminf(fminf(t->a.y, t->b.y), t->c.y), fminf(fminf(t->a.z, t->b.z), t->c.z));
+		tb[i].hi = V(fmaxf(fmaxf(t->a.x, t->b.x), t->c.x), fmaxf(fmaxf(t->a.y, t->b.y), t->c.y), fmaxf(fmaxf(t->a.z, t->b.z), t->c.z));
+		if(i)
+		{
+			all.lo = V(fminf(all.lo.x, tb[i].lo.x), fminf(all.lo.y, tb[i].lo.y), fminf(all.lo.z, tb[i].lo.z));
+			all.hi = V(fmaxf(all.hi.x, tb[i].hi.x), fmaxf(all.hi.y, tb[i].hi.y), fmaxf(all.hi.z, tb[i].hi.z));
+		}
+		else all = tb[i];
+	}
+	/* kdtree_triangle.cc:110-116: grow the tree bound by 0.1 % per side */
+	{
+		float *lo = &all.lo.x, *hi = &all.hi.x;
+		for(int i = 0; i < 3; ++i)
+		{
+			double foo = (double)(hi[i] - lo[i]) * 0.001;
+			lo[i] = (float)((double)lo[i] - foo); hi[i] = (float)((double)hi[i] + foo);
+		}
+	}
+	s->tb_a = all.lo; s->tb_g = all.hi;
+	build_ctx c;
+	c.s = s; c.tb = tb;
+	c.max_depth = (int)(7.0f + 1.66f * logf((float)np)); /* kdtree_triangle.cc:89 */
+	if(c.max_depth > KD_MAX_STACK) c.max_depth = KD_MAX_STACK;
+	c.cost_ratio = 0.8f; c.e_bonus = 0.33f;              /* scene.cc:818 */
+	{
+		double log_leaves = 1.442695f * log((double)np);   /* kdtree_triangle.cc:90,100 */
+		if(log_leaves > 16.0) c.cost_ratio += (float)(0.25 * (log_leaves - 16.0));
+	}
+	uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)np);
+	for(int i = 0; i < np; ++i) idx[i] = (uint32_t)i;
+	uint32_t root = kd_alloc_node(s);
+	kd_build(&c, root, all, idx, (uint32_t)np, 0, 0);
+	free(idx); free(tb);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	s->build_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ------------------------------------------------------------------ kd traversal
+ * TriKdTree::intersect, kdtree_triangle.cc:684-837.  Same control flow (Havran entry/exit
+ * stack); nodes are indices instead of pointers.  Tie rule: strictly `t_hit < z`, so the
+ * first triangle visited wins (:782,806); leaf order here is ascending triangle index. */
+typedef struct { uint32_t node; float t; v3 pb; int prev; } kdstack_t;
+#define KD_NONE 0xFFFFFFFFu
+
+static int kd_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float dist, int *tri_out, float *z_out, float *bu, float *bv, counters_t *cn)
+{
+	float z = dist;
+	float a, b, t, t_hit;
+	int hit = 0;
+	*z_out = z;
+	if(s->n_nodes == 0) return 0;
+	if(!bound_cross(s->tb_a, s->tb_g, from, dir, &a, &b, dist)) return 0;
+	v3 inv_dir = V((float)(1.0 / (double)dir.x), (float)(1.0 / (double)dir.y), (float)(1.0 / (double)dir.z));
+	kdstack_t stack[KD_MAX_STACK];
+	uint32_t far_child, curr = 0;
+	int en_pt = 0;
+	stack[en_pt].t = a;
+	if(a >= 0.0) stack[en_pt].pb = vadd(from, vmul(dir, a));
+	else stack[en_pt].pb = from;
+	int ex_pt = 1;
+	stack[ex_pt].t = b;
+	stack[ex_pt].pb = vadd(from, vmul(dir, b));
+	stack[ex_pt].node = KD_NONE;
+	float cur_u = 0, cur_v = 0;
+	while(curr != KD_NONE)
+	{
+		if(dist < stack[en_pt].t) break;
+		while((s->nodes[curr].flags & 3u) != 3u)
+		{
+			int axis = (int)(s->nodes[curr].flags & 3u);
+			float split_val = s->nodes[curr].u.split;
+			uint32_t right = s->nodes[curr].flags >> 2;
+			if(cn) cn->interior++;
+			if(vcomp(stack[en_pt].pb, axis) <= split_val)
+			{
+				if(vcomp(stack[ex_pt].pb, axis) <= split_val) { curr++; continue; }
+				if(vcomp(stack[ex_pt].pb, axis) == split_val) { curr = right; continue; }
+				far_child = right;
+				curr++;
+			}
+			else
+			{
+				if(split_val < vcomp(stack[ex_pt].pb, axis)) { curr = right; continue; }
+				far_child = curr + 1;
+				curr = right;
+			}
+			t = (split_val - vcomp(from, axis)) * vcomp(inv_dir, axis);
+			int tmp = ex_pt;
+			ex_pt++;
+			if(ex_pt == en_pt) ex_pt++;
+			{
+				static const int np_axis[2][3] = {{1, 2, 0}, {2, 0, 1}};
+				int next_axis = np_axis[0][axis], prev_axis = np_axis[1][axis];
+				float pbv[3];
+				stack[ex_pt].prev = tmp;
+				stack[ex_pt].t = t;
+				stack[ex_pt].node = far_child;
+				pbv[axis] = split_val;
+				pbv[next_axis] = vcomp(from, next_axis) + t * vcomp(dir, next_axis);
+				pbv[prev_axis] = vcomp(from, prev_axis) + t * vcomp(dir, prev_axis);
+				stack[ex_pt].pb = V(pbv[0], pbv[1], pbv[2]);
+			}
+		}
+		{
+			uint32_t n_primitives = s->nodes[curr].flags >> 2;
+			uint32_t first = s->nodes[curr].u.first;
+			if(cn) cn->leaves++;
+			for(uint32_t i = 0; i < n_primitives; ++i)
+			{
+				uint32_t ti = s->leaf_refs[first + i];
+				const tri_t *mp = &s->tris[ti];
+				float uu, vv;
+				if(cn) cn->tests++;
+				if(tri_intersect(mp, from, dir, &t_hit, &uu, &vv))
+				{
+					if(t_hit < z && t_hit >= tmin)
+					{
+						if(mat_visible_primary(&s->mats[mp->mat]))
+						{
+							z = t_hit; *tri_out = (int)ti; cur_u = uu; cur_v = vv; hit = 1;
+						}
+					}
+				}
+			}
+		}
+		if(hit && z <= stack[ex_pt].t) { *z_out = z; *bu = cur_u; *bv = cur_v; return 1; }
+		en_pt = ex_pt;
+		curr = stack[ex_pt].node;
+		ex_pt = stack[en_pt].prev;
+	}
+	*z_out = z; *bu = cur_u; *bv = cur_v;
+	return hit;
+}
+
+/* TriKdTree::intersectS, kdtree_triangle.cc:840-977 */
+static int kd_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist, counters_t *cn)
+{
+	float a, b, t, t_hit;
+	if(s->n_nodes == 0) return 0;
+	if(!bound_cross(s->tb_a, s->tb_g, from, dir, &a, &b, dist)) return 0;
+	v3 inv_dir = V(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+	kdstack_t stack[KD_MAX_STACK];
+	uint32_t far_child, curr = 0;
+	int en_pt = 0;
+	stack[en_pt].t = a;
+	if(a >= 0.0) stack[en_pt].pb = vadd(from, vmul(dir, a));
+	else stack[en_pt].pb = from;
+	int ex_pt = 1;
+	stack[ex_pt].t = b;
+	stack[ex_pt].pb = vadd(from, vmul(dir, b));
+	stack[ex_pt].node = KD_NONE;
+	while(curr != KD_NONE)
+	{
+		if(dist < stack[en_pt].t) break;
+		while((s->nodes[curr].flags & 3u) != 3u)
+		{
+			int axis = (int)(s->nodes[curr].flags & 3u);
+			float split_val = s->nodes[curr].u.split;
+			uint32_t right = s->nodes[curr].flags >> 2;
+			if(cn) cn->interior++;
+			if(vcomp(stack[en_pt].pb, axis) <= split_val)
+			{
+				if(vcomp(stack[ex_pt].pb, axis) <= split_val) { curr++; continue; }
+				if(vcomp(stack[ex_pt].pb, axis) == split_val) { curr = right; continue; }
+				far_child = right;
+				curr++;
+			}
+			else
+			{
+				if(split_val < vcomp(stack[ex_pt].pb, axis)) { curr = right; continue; }
+				far_child = curr + 1;
+				curr = right;
+			}
+			t = (split_val - vcomp(from, axis)) * vcomp(inv_dir, axis);
+			int tmp = ex_pt;
+			ex_pt++;
+			if(ex_pt == en_pt) ex_pt++;
+			{
+				static const int np_axis[2][3] = {{1, 2, 0}, {2, 0, 1}};
+				int next_axis = np_axis[0][axis], prev_axis = np_axis[1][axis];
+				float pbv[3];
+				stack[ex_pt].prev = tmp;
+				stack[ex_pt].t = t;
+				stack[ex_pt].node = far_child;
+				pbv[axis] = split_val;
+				pbv[next_axis] = vcomp(from, next_axis) + t * vcomp(dir, next_axis);
+				pbv[prev_axis] = vcomp(from, prev_axis) + t * vcomp(dir, prev_axis);
+				stack[ex_pt].pb = V(pbv[0], pbv[1], pbv[2]);
+			}
+		}
+		{
+			uint32_t n_primitives = s->nodes[curr].flags >> 2;
+			uint32_t first = s->nodes[curr].u.first;
+			if(cn) cn->leaves++;
+			for(uint32_t i = 0; i < n_primitives; ++i)
+			{
+				const tri_t *mp = &s->tris[s->leaf_refs[first + i]];
+				float uu, vv;
+				if(cn) cn->tests++;
+				if(tri_intersect(mp, from, dir, &t_hit, &uu, &vv))
+				{
+					if(t_hit < dist && t_hit >= 0.f)
+					{
+						if(mat_visible_shadow(&s->mats[mp->mat])) return 1;
+					}
+				}
+			}
+		}
+		en_pt = ex_pt;
+		curr = stack[ex_pt].node;
+		ex_pt = stack[en_pt].prev;
+	}
+	return 0;
+}
+
+/* brute-force versions: the traversal-independent definition of the same queries */
+static int brute_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float dist, int *tri_out, float *z_out, float *bu, float *bv)
+{
+	float z = dist, t_hit, uu, vv; int hit = 0;
+	for(int i = 0; i < s->n_tris; ++i)
+	{
+		const tri_t *mp = &s->tris[i];
+		if(tri_intersect(mp, from, dir, &t_hit, &uu, &vv))
+			if(t_hit < z && t_hit >= tmin && mat_visible_primary(&s->mats[mp->mat])) { z = t_hit; *tri_out = i; *bu = uu; *bv = vv; hit = 1; }
+	}
+	*z_out = z;
+	return hit;
+}
+static int brute_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist)
+{
+	float t_hit, uu, vv;
+	for(int i = 0; i < s->n_tris; ++i)
+	{
+		const tri_t *mp = &s->tris[i];
+		if(tri_intersect(mp, from, dir, &t_hit, &uu, &vv))
+			if(t_hit < dist && t_hit >= 0.f && mat_visible_shadow(&s->mats[mp->mat])) return 1;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------ surface point
+ * the subset of SurfacePoint (surface.h:58-100) the path uses */
+typedef struct { v3 p, n, ng, nu, nv; int mat; } sp_t;
+
+/* Triangle::getSurface, triangle.cc:30-133 (no UV, no orco branch) */
+static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, sp_t *sp)
+{
+	const tri_t *tr = &s->tris[ti];
+	sp->ng = tr->ng;
+	/* data.b_0_ = 1-u-v, b_1_ = u, b_2_ = v (triangle.h:252-254); getSurface names them u,v,w (:34) */
+	float u = 1 - bu - bv, v = bu, w = bv;
+	if(tr->smooth)
+	{
+		sp->n = vadd(vadd(vmul(tr->na, u), vmul(tr->nb, v)), vmul(tr->nc, w));
+		sp->n = vnormalize(sp->n);
+	}
+	else sp->n = sp->ng;
+	sp->mat = tr->mat;
+	sp->p = hit;
+	create_cs(sp->n, &sp->nu, &sp->nv);
+}
+
+/* Scene::intersect, scene.cc:896-927 */
+static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float *tmax, sp_t *sp, counters_t *cn)
+{
+	float dis, z, bu = 0, bv = 0; int ti = -1;
+	if(*tmax < 0) dis = INFINITY;
+	else dis = *tmax;
+	if(cn) cn->rays_closest++;
+	if(!kd_intersect(s, from, dir, tmin, dis, &ti, &z, &bu, &bv, cn)) return 0;
+	v3 h = vadd(from, vmul(dir, z)); /* ray.from_ + z * ray.dir_ */
+	get_surface(s, ti, h, bu, bv, sp);
+	*tmax = z;
+	return 1;
+}
+
+/* Scene::isShadowed, scene.cc:962-994 */
+static int scene_is_shadowed(const yor_scene *s, v3 from, v3 dir, float tmin, float tmax, counters_t *cn)
+{
+	v3 sfrom = vadd(from, vmul(dir, tmin));
+	float dis;
+	if(tmax < 0) dis = INFINITY;
+	else dis = tmax - 2 * tmin;
+	if(cn) cn->rays_shadow++;
+	return kd_intersect_s(s, sfrom, dir, dis, cn);
+}
+
+/* ------------------------------------------------------------------ materials */
+typedef struct { float component[4]; float m_diffuse, m_glossy, p_diffuse; } bsdf_dat; /* SdDat / MDatT */
+typedef struct { float s_1, s_2, pdf; unsigned flags, sampled_flags; } sample_t;         /* material.h:68-78 */
+
+static void mat_configure(mat_t *m, const yor_material_desc *d)
+{
+	memset(m, 0, sizeof *m);
+	m->type = d->type; m->visibility = d->visibility; m->receive_shadows = d->receive_shadows; m->flat = d->flat_material;
+	if(d->type == YOR_MAT_SHINYDIFFUSE)
+	{
+		/* ctor material_shiny_diffuse.cc:26-36 and factory :599-690 */
+		m->diffuse_color = C(d->color[0], d->color[1], d->color[2]);
+		m->mirror_color = C(d->mirror_color[0], d->mirror_color[1], d->mirror_color[2]);
+		m->diffuse_strength = d->diffuse_reflect; m->mirror_strength = d->specular_reflect;
+		m->transparency_strength = d->transparency; m->translucency_strength = d->translucency;
+		m->emit_strength = d->emit; m->transmit_filter = d->transmit_filter;
+		m->emit_color = cscale(m->diffuse_color, d->emit);
+		m->flags = BSDF_NONE;
+		if(m->emit_strength > 0.f) m->flags |= BSDF_EMIT;
+		m->ior_squared = 1.f;
+		if(d->fresnel_effect) { m->ior_squared = d->ior * d->ior; m->has_fresnel = 1; }
+		if(d->oren_nayar)
+		{	/* initOrenNayar :190-196 */
+			double sigma_squared = d->sigma * d->sigma;
+			m->oren_a = (float)(1.0 - 0.5 * (sigma_squared / (sigma_squared + 0.33)));
+			m->oren_b = (float)(0.45 * sigma_squared / (sigma_squared + 0.09));
+			m->use_oren = 1;
+		}
+		/* config() :46-92 */
+		float acc = 1.f;
+		m->n_bsdf = 0;
+		if(m->mirror_strength > 0.00001f)
+		{
+			m->is_mirror = 1;
+			if(!m->has_fresnel) acc = 1.f - m->mirror_strength;
+			m->flags |= BSDF_SPECULAR | BSDF_REFLECT;
+			m->c_flags[m->n_bsdf] = BSDF_SPECULAR | BSDF_REFLECT; m->c_index[m->n_bsdf] = 0; ++m->n_bsdf;
+		}
+		if(m->transparency_strength * acc > 0.00001f)
+		{
+			m->is_transparent = 1;
+			acc *= 1.f - m->transparency_strength;
+			m->flags |= BSDF_TRANSMIT | BSDF_FILTER;
+			m->c_flags[m->n_bsdf] = BSDF_TRANSMIT | BSDF_FILTER; m->c_index[m->n_bsdf] = 1; ++m->n_bsdf;
+		}
+		if(m->translucency_strength * acc > 0.00001f)
+		{
+			m->is_translucent = 1;
+			acc *= 1.f - m->transparency_strength; /* sic: the reference multiplies by transparency here (:72) */
+			m->flags |= BSDF_DIFFUSE | BSDF_TRANSMIT;
+			m->c_flags[m->n_bsdf] = BSDF_DIFFUSE | BSDF_TRANSMIT; m->c_index[m->n_bsdf] = 2; ++m->n_bsdf;
+		}
+		if(m->diffuse_strength * acc > 0.00001f)
+		{
+			m->is_diffuse = 1;
+			m->flags |= BSDF_DIFFUSE | BSDF_REFLECT;
+			m->c_flags[m->n_bsdf] = BSDF_DIFFUSE | BSDF_REFLECT; m->c_index[m->n_bsdf] = 3; ++m->n_bsdf;
+		}
+	}
+	else if(d->type == YOR_MAT_GLOSSY)
+	{
+		/* material_glossy.cc:32-50 */
+		m->gloss_color = C(d->glossy_color[0], d->glossy_color[1], d->glossy_color[2]);
+		m->diff_color = C(d->diffuse_color[0], d->diffuse_color[1], d->diffuse_color[2]);
+		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
+		m->as_diffuse = d->as_diffuse;
+		m->flags = BSDF_NONE;
+		if(m->diffuse > 0) { m->flags = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; }
+		m->flags |= m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
+		if(d->oren_nayar)
+		{	/* :66-72 */
+			double sigma_2 = d->sigma * d->sigma;
+			m->oren_a = (float)(1.0 - 0.5 * (sigma_2 / (sigma_2 + 0.33)));
+			m->oren_b = (float)(0.45 * sigma_2 / (sigma_2 + 0.09));
+			m->use_oren = 1;
+		}
+	}
+	else
+	{
+		/* material_simple.cc:36-39,63-73: col * (float)power */
+		m->light_col = cscale(C(d->light_color[0], d->light_color[1], d->light_color[2]), d->light_power);
+		m->double_sided = d->double_sided;
+		m->flags = BSDF_EMIT;
+	}
+}
+
+static inline v3 face_forward(v3 ng, v3 n, v3 i) { return (vdot(ng, i) < 0) ? vneg(n) : n; } /* material.h:33 */
+
+/* getFresnel, material_shiny_diffuse.cc:119-147 */
+static float sd_fresnel(const mat_t *m, v3 wo, v3 n)
+{
+	if(m->has_fresnel)
+	{
+		v3 N = (vdot(wo, n) < 0.f) ? vneg(n) : n;
+		float c = vdot(wo, N);
+		float g = m->ior_squared + c * c - 1.f;
+		if(g < 0.f) g = 0.f;
+		else g = yor_fsqrt(g);
+		float aux = c * (g + c);
+		return ((0.5f * (g - c) * (g - c)) / ((g + c) * (g + c))) *
+		       (1.f + ((aux - 1) * (aux - 1)) / ((aux + 1) * (aux + 1)));
+	}
+	return 1.f;
+}
+/* accumulate__, :152-161 */
+static void sd_accumulate(const float *component, float *accum, float kr)
+{
+	accum[0] = component[0] * kr;
+	float acc = 1.f - accum[0];
+	accum[1] = component[1] * acc;
+	acc *= 1.f - component[1];
+	accum[2] = component[2] * acc;
+	acc *= 1.f - component[2];
+	accum[3] = component[3] * acc;
+}
+/* orenNayar, :204-241 and material_glossy.cc:74-111 (identical bodies); a,b are float members */
+static float oren_nayar(float oren_a, float oren_b, v3 wi, v3 wo, v3 n)
+{
+	float cos_ti = fmaxf_(-1.f, fminf_(1.f, vdot(n, wi)));
+	float cos_to = fmaxf_(-1.f, fminf_(1.f, vdot(n, wo)));
+	float maxcos_f = 0.f;
+	if(cos_ti < 0.9999f && cos_to < 0.9999f)
+	{
+		v3 v_1 = vnormalize(vsub(wi, vmul(n, cos_ti)));
+		v3 v_2 = vnormalize(vsub(wo, vmul(n, cos_to)));
+		maxcos_f = fmaxf_(0.f, vdot(v_1, v_2));
+	}
+	float sin_alpha, tan_beta;
+	if(cos_to >= cos_ti)
+	{
+		sin_alpha = yor_fsqrt(1.f - cos_ti * cos_ti);
+		tan_beta = yor_fsqrt(1.f - cos_to * cos_to) / ((cos_to == 0.f) ? 1e-8f : cos_to);
+	}
+	else
+	{
+		sin_alpha = yor_fsqrt(1.f - cos_to * cos_to);
+		tan_beta = yor_fsqrt(1.f - cos_ti * cos_ti) / ((cos_ti == 0.f) ? 1e-8f : cos_ti);
+	}
+	return fminf_(1.f, fmaxf_(0.f, (float)(oren_a + oren_b * maxcos_f * sin_alpha * tan_beta)));
+}
+
+static void mat_init_bsdf(const mat_t *m, bsdf_dat *dat, unsigned *bsdf_types)
+{
+	memset(dat, 0, sizeof *dat);
+	*bsdf_types = m->flags;
+	if(m->type == YOR_MAT_SHINYDIFFUSE)
+	{	/* initBsdf :163-183 + getComponents :98-117 */
+		if(m->is_mirror) dat->component[0] = m->mirror_strength;
+		if(m->is_transparent) dat->component[1] = m->transparency_strength;
+		if(m->is_translucent) dat->component[2] = m->translucency_strength;
+		if(m->is_diffuse) dat->component[3] = m->diffuse_strength;
+	}
+	else if(m->type == YOR_MAT_GLOSSY)
+	{	/* material_glossy.cc:51-64 */
+		dat->m_diffuse = m->diffuse;
+		dat->m_glossy = m->reflectivity;
+		dat->p_diffuse = fminf_(0.6f, 1.f - (dat->m_glossy / (dat->m_glossy + (1.f - dat->m_glossy) * dat->m_diffuse)));
+	}
+}
+
+/* microfacet helpers, material_utils_microfacet.h */
+static inline float blinn_d(float cos_h, float e) { return (e + 1.f) * yor_fpow(cos_h, e); }             /* :89-92 */
+static inline double pdf_divisor(float c) { return (double)8.f * Y_M_PI * (double)(c * 0.99f + 0.04f); } /* :35 */
+static inline float blinn_pdf(float costheta, float cos_w_h, float e) { return (float)((double)blinn_d(costheta, e) / pdf_divisor(cos_w_h)); } /* :94-97 */
+static inline double as_divisor(float cos1, float cos_i, float cos_o) { return (double)8.f * Y_M_PI * (double)((cos1 * fmaxf_(cos_i, cos_o)) * 0.99f + 0.04f); } /* :36 */
+static inline float schlick_fresnel(float costheta, float r) /* :188-193 */
+{
+	float c_1 = (1.f - costheta);
+	float c_2 = c_1 * c_1;
+	return r + ((1.f - r) * c_1 * c_2 * c_2);
+}
+static inline rgb diffuse_reflect(float wi_n, float wo_n, float glossy, float diffuse, rgb diff_base) /* :195-206 */
+{
+	float temp = 0.f;
+	float f_wi = (1.f - (0.5f * wi_n));
+	temp = f_wi * f_wi;
+	f_wi = temp * temp * f_wi;
+	float f_wo = (1.f - (0.5f * wo_n));
+	temp = f_wo * f_wo;
+	f_wo = temp * temp * f_wo;
+	/* DIFFUSE_RATIO is a double literal: the scalar chain runs in double, then narrows for Rgb*float */
+	double k = 0.387507688 * (double)diffuse * (double)(1.f - glossy) * (double)(1.f - f_wi) * (double)(1.f - f_wo);
+	return cscale(diff_base, (float)k);
+}
+static inline v3 blinn_sample(float s_1, float s_2, float exponent) /* :99-106 */
+{
+	float cos_theta = yor_fpow(1.f - s_2, 1.f / (exponent + 1.f));
+	float sin_theta = yor_fsqrt(1.f - cos_theta * cos_theta);
+	float phi = (float)((double)s_1 * Y_M_2PI);
+	return V(sin_theta * yor_fcos(phi), sin_theta * yor_fsin(phi), cos_theta);
+}
+
+static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 wl, unsigned bsdfs)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE)
+	{	/* material_shiny_diffuse.cc:244-293 */
+		float cos_ng_wo = vdot(sp->ng, wo);
+		float cos_ng_wl = vdot(sp->ng, wl);
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		if(!(bsdfs & m->flags & BSDF_DIFFUSE)) return C(0, 0, 0);
+		float kr = sd_fresnel(m, wo, n);
+		float m_t = (1.f - kr * dat->component[0]) * (1.f - dat->component[1]);
+		int transmit = (cos_ng_wo * cos_ng_wl) < 0.f;
+		if(transmit)
+		{
+			if(m->is_translucent) return cscale(m->diffuse_color, dat->component[2] * m_t);
+		}
+		if(vdot(n, wl) < 0.0 && !m->flat) return C(0, 0, 0);
+		float m_d = m_t * (1.f - dat->component[2]) * dat->component[3];
+		if(m->use_oren) m_d *= oren_nayar(m->oren_a, m->oren_b, wo, wl, n);
+		return cscale(m->diffuse_color, m_d);
+	}
+	else if(m->type == YOR_MAT_GLOSSY)
+	{	/* material_glossy.cc:113-173 */
+		if(!(bsdfs & BSDF_DIFFUSE) || (vdot(sp->ng, wl) * vdot(sp->ng, wo)) < 0.f) return C(0, 0, 0);
+		rgb col = C(0, 0, 0);
+		int diffuse_flag = (bsdfs & BSDF_DIFFUSE) != 0;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float wi_n = fabsf(vdot(wl, n));
+		float wo_n = fabsf(vdot(wo, n));
+		if((m->as_diffuse && diffuse_flag) || (!m->as_diffuse && (bsdfs & BSDF_GLOSSY)))
+		{
+			v3 h = vnormalize(vadd(wo, wl));
+			float cos_wi_h = fmaxf_(0.f, vdot(wl, h));
+			float glossy = (float)((double)(blinn_d(vdot(h, n), m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			col = cscale(m->gloss_color, glossy);
+		}
+		if(m->with_diffuse && diffuse_flag)
+		{
+			rgb add_col = cscale(m->diff_color, dat->m_diffuse * (1.f - dat->m_glossy));
+			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, wl, wo, n));
+			col = cadd(col, add_col);
+		}
+		return col;
+	}
+	return C(0, 0, 0); /* LightMaterial::eval, material_simple.h */
+}
+
+static float mat_pdf(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 wi, unsigned bsdfs)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE)
+	{	/* material_shiny_diffuse.cc:410-460 */
+		if(!(bsdfs & BSDF_DIFFUSE)) return 0.f;
+		float pdf = 0.f, accum_c[4];
+		float cos_ng_wo = vdot(sp->ng, wo), cos_ng_wi;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr = sd_fresnel(m, wo, n);
+		sd_accumulate(dat->component, accum_c, kr);
+		float sum = 0.f, width;
+		int n_match = 0;
+		for(int i = 0; i < m->n_bsdf; ++i)
+		{
+			if((bsdfs & m->c_flags[i]))
+			{
+				width = accum_c[m->c_index[i]];
+				sum += width;
+				if(m->c_flags[i] == (BSDF_DIFFUSE | BSDF_TRANSMIT))
+				{
+					cos_ng_wi = vdot(sp->ng, wi);
+					if(cos_ng_wo * cos_ng_wi < 0) pdf += fabsf(vdot(wi, n)) * width;
+				}
+				else if(m->c_flags[i] == (BSDF_DIFFUSE | BSDF_REFLECT))
+				{
+					pdf += fabsf(vdot(wi, n)) * width;
+				}
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) return 0.f;
+		return pdf / sum;
+	}
+	else if(m->type == YOR_MAT_GLOSSY)
+	{	/* material_glossy.cc:359-405 */
+		if(vdot(sp->ng, wo) * vdot(sp->ng, wi) < 0.f) return 0.f;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float pdf = 0.f;
+		float cur_p_diffuse = dat->p_diffuse;
+		int use_glossy = m->as_diffuse ? (bsdfs & BSDF_DIFFUSE) != 0 : (bsdfs & BSDF_GLOSSY) != 0;
+		int use_diffuse = m->with_diffuse && (bsdfs & BSDF_DIFFUSE);
+		if(use_diffuse)
+		{
+			pdf = fabsf(vdot(wi, n));
+			if(use_glossy)
+			{
+				v3 h = vnormalize(vadd(wi, wo));
+				float cos_wo_h = vdot(wo, h);
+				float cos_n_h = vdot(n, h);
+				pdf = pdf * cur_p_diffuse + blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * (1.f - cur_p_diffuse);
+			}
+			return pdf;
+		}
+		if(use_glossy)
+		{
+			v3 h = vnormalize(vadd(wi, wo));
+			float cos_wo_h = vdot(wo, h);
+			float cos_n_h = vdot(n, h);
+			pdf = blinn_pdf(cos_n_h, cos_wo_h, m->exponent);
+		}
+		return pdf;
+	}
+	return 0.f;
+}
+
+/* getAlpha, material_shiny_diffuse.cc:568-597 */
+static float sd_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo)
+{
+	if(m->is_transparent)
+	{
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr = sd_fresnel(m, wo, n);
+		float refl = (1.f - dat->component[0] * kr) * dat->component[1];
+		return 1.f - refl;
+	}
+	return 1.f;
+}
+
+static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 *wi, sample_t *s, float *w)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE)
+	{	/* material_shiny_diffuse.cc:308-408 */
+		float accum_c[4];
+		float cos_ng_wo = vdot(sp->ng, wo), cos_ng_wi, cos_n;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr = sd_fresnel(m, wo, n);
+		sd_accumulate(dat->component, accum_c, kr);
+		float sum = 0.f, val[4], width[4];
+		unsigned choice[4];
+		int n_match = 0, pick = -1;
+		for(int i = 0; i < m->n_bsdf; ++i)
+		{
+			if((s->flags & m->c_flags[i]) == m->c_flags[i])
+			{
+				width[n_match] = accum_c[m->c_index[i]];
+				sum += width[n_match];
+				choice[n_match] = m->c_flags[i];
+				val[n_match] = sum;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) { s->sampled_flags = BSDF_NONE; s->pdf = 0.f; return C(1, 1, 1); }
+		float inv_sum = 1.f / sum;
+		for(int i = 0; i < n_match; ++i)
+		{
+			val[i] *= inv_sum;
+			width[i] *= inv_sum;
+			if((s->s_1 <= val[i]) && (pick < 0)) pick = i;
+		}
+		if(pick < 0) pick = n_match - 1;
+		float s_1;
+		if(pick > 0) s_1 = (s->s_1 - val[pick - 1]) / width[pick];
+		else s_1 = s->s_1 / width[pick];
+		rgb scolor = C(0, 0, 0);
+		switch(choice[pick])
+		{
+			case(BSDF_SPECULAR | BSDF_REFLECT):
+				*wi = reflect_dir(n, wo);
+				s->pdf = width[pick];
+				scolor = cscale(m->mirror_color, accum_c[0]);
+				scolor = cscale(scolor, 1.f / fmaxf_(fabsf(vdot(sp->n, *wi)), 1.0e-6f));
+				break;
+			case(BSDF_TRANSMIT | BSDF_FILTER):
+				*wi = vneg(wo);
+				scolor = cscale(cadd(cscale(m->diffuse_color, m->transmit_filter), C(1.f - m->transmit_filter, 1.f - m->transmit_filter, 1.f - m->transmit_filter)), accum_c[1]);
+				cos_n = fabsf(vdot(*wi, n));
+				if((double)cos_n < 1e-6) s->pdf = 0.f;
+				else s->pdf = width[pick];
+				break;
+			case(BSDF_DIFFUSE | BSDF_TRANSMIT):
+				*wi = sample_cos_hemisphere(vneg(n), sp->nu, sp->nv, s_1, s->s_2);
+				cos_ng_wi = vdot(sp->ng, *wi);
+				if(cos_ng_wo * cos_ng_wi < 0) scolor = cscale(m->diffuse_color, accum_c[2]);
+				s->pdf = fabsf(vdot(*wi, n)) * width[pick]; break;
+			case(BSDF_DIFFUSE | BSDF_REFLECT):
+			default:
+				*wi = sample_cos_hemisphere(n, sp->nu, sp->nv, s_1, s->s_2);
+				cos_ng_wi = vdot(sp->ng, *wi);
+				if(cos_ng_wo * cos_ng_wi > 0) scolor = cscale(m->diffuse_color, accum_c[3]);
+				if(m->use_oren) scolor = cscale(scolor, oren_nayar(m->oren_a, m->oren_b, wo, *wi, n));
+				s->pdf = fabsf(vdot(*wi, n)) * width[pick]; break;
+		}
+		s->sampled_flags = choice[pick];
+		*w = (fabsf(vdot(*wi, sp->n))) / (s->pdf * 0.99f + 0.01f);
+		{
+			const float alpha = sd_alpha(m, dat, sp, wo);
+			*w = *w * (alpha) + 1.f * (1.f - alpha);
+		}
+		return scolor;
+	}
+	else if(m->type == YOR_MAT_GLOSSY)
+	{	/* material_glossy.cc:176-357, isotropic (Blinn) branch */
+		float cos_ng_wo = vdot(sp->ng, wo), cos_ng_wi;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		s->pdf = 0.f;
+		float wi_n = 0.f;
+		float wo_n = fabsf(vdot(wo, n));
+		float cos_wo_h = 0.f;
+		rgb scolor = C(0, 0, 0);
+		float s_1 = s->s_1;
+		float cur_p_diffuse = dat->p_diffuse;
+		int use_glossy = m->as_diffuse ? (s->flags & BSDF_DIFFUSE) != 0 : (s->flags & BSDF_GLOSSY) != 0;
+		int use_diffuse = m->with_diffuse && (s->flags & BSDF_DIFFUSE);
+		float glossy = 0.f;
+		if(use_diffuse)
+		{
+			float s_p_diffuse = use_glossy ? cur_p_diffuse : 1.f;
+			if(s_1 < s_p_diffuse)
+			{
+				s_1 /= s_p_diffuse;
+				*wi = sample_cos_hemisphere(n, sp->nu, sp->nv, s_1, s->s_2);
+				cos_ng_wi = vdot(sp->ng, *wi);
+				if(cos_ng_wi * cos_ng_wo < 0.f) return scolor;
+				wi_n = fabsf(vdot(*wi, n));
+				s->pdf = wi_n;
+				if(use_glossy)
+				{
+					v3 h = vnormalize(vadd(*wi, wo));
+					cos_wo_h = vdot(wo, h);
+					float cos_wi_h = fabsf(vdot(*wi, h));
+					float cos_n_h = vdot(n, h);
+					s->pdf = s->pdf * cur_p_diffuse + blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * (1.f - cur_p_diffuse);
+					glossy = (float)((double)(blinn_d(cos_n_h, m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+				}
+				s->sampled_flags = BSDF_DIFFUSE | BSDF_REFLECT;
+				if(!(s->flags & BSDF_REFLECT)) return C(0, 0, 0);
+				scolor = cscale(m->gloss_color, glossy);
+				{
+					rgb add_col = diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color);
+					if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+					scolor = cadd(scolor, add_col);
+				}
+				*w = wi_n / (s->pdf * 0.99f + 0.01f);
+				return scolor;
+			}
+			s_1 -= cur_p_diffuse;
+			s_1 /= (1.f - cur_p_diffuse);
+		}
+		if(use_glossy)
+		{
+			v3 hs = blinn_sample(s_1, s->s_2, m->exponent);
+			v3 h = vadd(vadd(vmul(sp->nu, hs.x), vmul(sp->nv, hs.y)), vmul(n, hs.z));
+			cos_wo_h = vdot(wo, h);
+			if(cos_wo_h < 0.f)
+			{	/* h.reflect(n), vector.h:265-272 */
+				const float vn = 2.0f * (h.x * n.x + h.y * n.y + h.z * n.z);
+				h = V(vn * n.x - h.x, vn * n.y - h.y, vn * n.z - h.z);
+				cos_wo_h = vdot(wo, h);
+			}
+			*wi = reflect_dir(h, wo);
+			cos_ng_wi = vdot(sp->ng, *wi);
+			if(cos_ng_wo * cos_ng_wi < 0.f) return C(0, 0, 0);
+			wi_n = fabsf(vdot(*wi, n));
+			{
+				float cos_hn = vdot(h, n);
+				s->pdf = blinn_pdf(cos_hn, cos_wo_h, m->exponent);
+				glossy = (float)((double)(blinn_d(cos_hn, m->exponent) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+			}
+			scolor = cscale(m->gloss_color, glossy);
+			s->sampled_flags = m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
+		}
+		if(use_diffuse)
+		{
+			rgb add_col = diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color);
+			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+			s->pdf = wi_n * cur_p_diffuse + s->pdf * (1.f - cur_p_diffuse);
+			scolor = cadd(scolor, add_col);
+		}
+		*w = wi_n / (s->pdf * 0.99f + 0.01f);
+		return scolor;
+	}
+	/* LightMaterial::sample, material_simple.cc:41-46 */
+	s->pdf = 0.f; *w = 0.f;
+	return C(0, 0, 0);
+}
+
+static rgb mat_emit(const mat_t *m, const sp_t *sp, v3 wo, int include_lights)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE) return m->emit_color; /* material_shiny_diffuse.cc:295-306 */
+	if(m->type == YOR_MAT_LIGHT)
+	{	/* material_simple.cc:50-57 */
+		if(!include_lights) return C(0, 0, 0);
+		if(m->double_sided) return m->light_col;
+		float angle = vdot(wo, sp->n);
+		return (angle > 0) ? m->light_col : C(0, 0, 0);
+	}
+	return C(0, 0, 0);
+}
+
+/* ------------------------------------------------------------------ lights */
+static void light_configure(light_t *l, const yor_light_desc *d)
+{
+	memset(l, 0, sizeof *l);
+	l->type = d->type; l->samples = d->samples; l->cast_shadows = d->cast_shadows;
+	rgb col = C(d->color[0], d->color[1], d->color[2]);
+	if(d->type == YOR_LIGHT_AREA)
+	{	/* factory light_area.cc:197: (corner, p1 - corner, p2 - corner); ctor :34-52 */
+		l->corner = V(d->corner[0], d->corner[1], d->corner[2]);
+		l->to_x = vsub(V(d->point1[0], d->point1[1], d->point1[2]), l->corner);
+		l->to_y = vsub(V(d->point2[0], d->point2[1], d->point2[2]), l->corner);
+		l->fnormal = vcross(l->to_y, l->to_x);
+		l->color = cscale(cscale(col, d->power), (float)Y_M_PI);
+		{	/* normLen, vector.h:61-71 */
+			float vl = l->fnormal.x * l->fnormal.x + l->fnormal.y * l->fnormal.y + l->fnormal.z * l->fnormal.z;
+			if(vl != 0.0)
+			{
+				vl = yor_fsqrt(vl);
+				const float dd = (float)(1.0 / (double)vl);
+				l->fnormal.x *= dd; l->fnormal.y *= dd; l->fnormal.z *= dd;
+			}
+			l->area = vl;
+		}
+		l->inv_area = (float)(1.0 / (double)l->area);
+		l->normal = vneg(l->fnormal);
+		l->c2 = vadd(l->corner, l->to_x);
+		l->c3 = vadd(l->corner, vadd(l->to_x, l->to_y));
+		l->c4 = vadd(l->corner, l->to_y);
+	}
+	else
+	{	/* light_point.cc:28-36 */
+		l->position = V(d->corner[0], d->corner[1], d->corner[2]);
+		l->color = cscale(col, d->power);
+	}
+}
+
+/* AreaLight::illumSample, light_area.cc:67-97 */
+static int arealight_illum_sample(const light_t *l, v3 sp_p, float s_1, float s_2, v3 *wi_dir, float *wi_tmax, float *pdf, rgb *col)
+{
+	v3 p = vadd(vadd(l->corner, vmul(l->to_x, s_1)), vmul(l->to_y, s_2));
+	v3 ldir = vsub(p, sp_p);
+	float dist_sqr = ldir.x * ldir.x + ldir.y * ldir.y + ldir.z * ldir.z;
+	float dist = yor_fsqrt(dist_sqr);
+	if(dist <= 0.0) return 0;
+	{
+		float inv = 1.f / dist;
+		ldir.x *= inv; ldir.y *= inv; ldir.z *= inv;
+	}
+	float cos_angle = vdot(ldir, l->fnormal);
+	if(cos_angle <= 0) return 0;
+	*wi_tmax = dist;
+	*wi_dir = ldir;
+	*col = l->color;
+	*pdf = (float)((double)dist_sqr * Y_M_PI / (double)(l->area * cos_angle));
+	return 1;
+}
+/* triIntersect__, light_area.cc:118-137 */
+static int tri_intersect_plain(v3 a, v3 b, v3 c, v3 from, v3 dir, float *t)
+{
+	v3 edge_1 = vsub(b, a), edge_2 = vsub(c, a);
+	v3 pvec = vcross(dir, edge_2);
+	float det = vdot(edge_1, pvec);
+	if(det == 0.0) return 0;
+	float inv_det = (float)(1.0 / (double)det);
+	v3 tvec = vsub(from, a);
+	float u = vdot(tvec, pvec) * inv_det;
+	if(u < 0.0 || u > 1.0) return 0;
+	v3 qvec = vcross(tvec, edge_1);
+	float v = vdot(dir, qvec) * inv_det;
+	if((v < 0.0) || ((u + v) > 1.0)) return 0;
+	*t = vdot(edge_2, qvec) * inv_det;
+	return 1;
+}
+/* AreaLight::intersect, light_area.cc:139-155 */
+static int arealight_intersect(const light_t *l, v3 from, v3 dir, float *t, rgb *col, float *ipdf)
+{
+	float cos_angle = vdot(dir, l->fnormal);
+	if(cos_angle <= 0) return 0;
+	if(!tri_intersect_plain(l->corner, l->c2, l->c3, from, dir, t))
+	{
+		if(!tri_intersect_plain(l->corner, l->c3, l->c4, from, dir, t)) return 0;
+	}
+	if(!(*t > 1.0e-10f)) return 0;
+	*col = l->color;
+	*ipdf = (float)((double)(1.f / (*t * *t) * l->area * cos_angle) * Y_M_1_PI);
+	return 1;
+}
+/* PointLight::illuminate, light_point.cc:38-56 */
+static int pointlight_illuminate(const light_t *l, v3 sp_p, rgb *col, v3 *wi_dir, float *wi_tmax)
+{
+	v3 ldir = vsub(l->position, sp_p);
+	float dist_sqr = ldir.x * ldir.x + ldir.y * ldir.y + ldir.z * ldir.z;
+	float dist = yor_fsqrt(dist_sqr);
+	if(dist == 0.0) return 0;
+	float idist_sqr = 1.f / (dist_sqr);
+	{
+		float inv = 1.f / dist;
+		ldir.x *= inv; ldir.y *= inv; ldir.z *= inv;
+	}
+	*wi_tmax = dist;
+	*wi_dir = ldir;
+	*col = cscale(l->color, (float)idist_sqr);
+	return 1;
+}
+
+/* ------------------------------------------------------------------ camera
+ * Camera::Camera camera.cc:46-66, PerspectiveCamera ctor + setAxis camera_perspective.cc:28-74 */
+static void camera_configure(camera_t *c, const yor_camera_desc *d)
+{
+	v3 pos = V(d->from[0], d->from[1], d->from[2]), look = V(d->to[0], d->to[1], d->to[2]), up = V(d->up[0], d->up[1], d->up[2]);
+	c->position = pos; c->resx = d->resx; c->resy = d->resy;
+	c->aspect_ratio = d->aspect_ratio * (float)d->resy / (float)d->resx;
+	c->cam_y = vsub(up, pos);
+	c->cam_z = vsub(look, pos);
+	c->cam_x = vcross(c->cam_z, c->cam_y);
+	c->cam_y = vcross(c->cam_z, c->cam_x);
+	c->cam_x = vnormalize(c->cam_x);
+	c->cam_y = vnormalize(c->cam_y);
+	c->cam_z = vnormalize(c->cam_z);
+	c->near_n = c->cam_z; c->near_p = vadd(pos, vmul(c->cam_z, d->near_clip));
+	c->far_n = c->cam_z; c->far_p = vadd(pos, vmul(c->cam_z, d->far_clip));
+	c->focal = d->focal; c->aperture = d->aperture;
+	c->vright = c->cam_x;
+	c->vup = vmul(c->cam_y, c->aspect_ratio);
+	c->vto = vsub(vmul(c->cam_z, c->focal), vmul(vadd(c->vup, c->vright), 0.5f));
+	c->vup = V(c->vup.x / (float)c->resy, c->vup.y / (float)c->resy, c->vup.z / (float)c->resy);
+	c->vright = V(c->vright.x / (float)c->resx, c->vright.y / (float)c->resx, c->vright.z / (float)c->resx);
+}
+/* rayPlaneIntersection__, util_geometry.h:34-37 */
+static inline float ray_plane(v3 from, v3 dir, v3 pp, v3 pn) { return vdot(pn, vsub(pp, from)) / vdot(dir, pn); }
+/* shootRay, camera_perspective.cc:133-156 (aperture == 0) */
+static void camera_shoot(const camera_t *c, float px, float py, v3 *from, v3 *dir, float *tmin, float *tmax, float *wt)
+{
+	*wt = 1;
+	*from = c->position;
+	*dir = vadd(vadd(vmul(c->vright, px), vmul(c->vup, py)), c->vto);
+	*dir = vnormalize(*dir);
+	*tmin = ray_plane(*from, *dir, c->near_p, c->near_n);
+	*tmax = ray_plane(*from, *dir, c->far_p, c->far_n);
+}
+
+/* ------------------------------------------------------------------ scene create */
+yor_scene *yor_scene_create(int32_t n_tris, const float *verts, const int32_t *tri_mat, const float *vnormals,
+                            int32_t n_mats, const yor_material_desc *mats,
+                            int32_t n_lights, const yor_light_desc *lights,
+                            const yor_camera_desc *cam)
+{
+	yor_scene *s = (yor_scene *)calloc(1, sizeof *s);
+	s->n_tris = n_tris;
+	s->tris = (tri_t *)calloc((size_t)(n_tris > 0 ? n_tris : 1), sizeof(tri_t));
+	for(int i = 0; i < n_tris; ++i)
+	{
+		tri_t *t = &s->tris[i];
+		const float *p = verts + 9 * (size_t)i;
+		t->a = V(p[0], p[1], p[2]); t->b = V(p[3], p[4], p[5]); t->c = V(p[6], p[7], p[8]);
+		t->e1 = vsub(t->b, t->a); t->e2 = vsub(t->c, t->a);              /* triangle.h:203-204 */
+		/* triangle.h:206: 0.1f * MIN_RAYDIST * max(|e1|,|e2|) — MIN_RAYDIST is a double literal */
+		t->eps = (float)((double)0.1f * MIN_RAYDIST * (double)fmaxf_(vlength(t->e1), vlength(t->e2)));
+		t->ng = vnormalize(vcross(vsub(t->b, t->a), vsub(t->c, t->a))); /* recNormal triangle.h:295-302 */
+		t->mat = tri_mat[i];
+		t->smooth = 0;
+		if(vnormals)
+		{
+			const float *q = vnormals + 9 * (size_t)i;
+			int any = 0;
+			for(int k = 0; k < 9; ++k) if(q[k] != 0.f) any = 1;
+			if(any)
+			{
+				t->smooth = 1;
+				t->na = V(q[0], q[1], q[2]); t->nb = V(q[3], q[4], q[5]); t->nc = V(q[6], q[7], q[8]);
+				if(t->na.x == 0 && t->na.y == 0 && t->na.z == 0) t->na = t->ng;
+				if(t->nb.x == 0 && t->nb.y == 0 && t->nb.z == 0) t->nb = t->ng;
+				if(t->nc.x == 0 && t->nc.y == 0 && t->nc.z == 0) t->nc = t->ng;
+			}
+		}
+	}
+	s->n_mats = n_mats;
+	s->mats = (mat_t *)calloc((size_t)(n_mats > 0 ? n_mats : 1), sizeof(mat_t));
+	for(int i = 0; i < n_mats; ++i) mat_configure(&s->mats[i], &mats[i]);
+	s->n_lights = n_lights;
+	s->lights = (light_t *)calloc((size_t)(n_lights > 0 ? n_lights : 1), sizeof(light_t));
+	for(int i = 0; i < n_lights; ++i) light_configure(&s->lights[i], &lights[i]);
+	camera_configure(&s->cam, cam);
+	build_tree(s);
+	return s;
+}
+void yor_scene_destroy(yor_scene *s)
+{
+	if(!s) return;
+	free(s->tris); free(s->mats); free(s->lights); free(s->nodes); free(s->leaf_refs); free(s);
+}
+
+/* ------------------------------------------------------------------ integrator */
+typedef struct
+{
+	const yor_scene *s;
+	const yor_render_desc *rd;
+	float shadow_bias, ray_min_dist;
+	counters_t cn;
+	/* RenderState subset, scene.h:74-118 */
+	unsigned pixel_sample;
+	unsigned sampling_offs;
+	int include_lights;
+	mwc_t *prng;
+	unsigned correlative_sample_number; /* integrator_tiled.h:91, per thread */
+} rstate_t;
+
+/* MonteCarloIntegrator::doLightEstimation, integrator_montecarlo.cc:78-345 (render passes disabled,
+ * tr_shad_ false, volume integrator = identity) */
+static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *sp, const mat_t *material, const bsdf_dat *dat, v3 wo, unsigned loffs)
+{
+	const yor_scene *s = st->s;
+	rgb col = C(0, 0, 0);
+	int shadowed;
+	unsigned l_offs = loffs * 4567u; /* LOFFS_DELTA :45 */
+	v3 lr_dir = V(0, 0, 0); float lr_tmin = 0.f, lr_tmax = -1.f;
+	rgb lcol = C(0, 0, 0);
+	int cast_shadows = light->cast_shadows && material->receive_shadows;
+	if(light->type == YOR_LIGHT_POINT)
+	{	/* :94-148 */
+		if(pointlight_illuminate(light, sp->p, &lcol, &lr_dir, &lr_tmax))
+		{
+			if(st->rd->shadow_bias_auto) lr_tmin = st->shadow_bias * fmaxf_(1.f, vlength(sp->p));
+			else lr_tmin = st->shadow_bias;
+			if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
+			else shadowed = 0;
+			float angle_light_normal = (material->flat ? 1.f : fabsf(vdot(sp->n, lr_dir)));
+			if(!shadowed)
+			{
+				rgb surf_col = mat_eval(material, dat, sp, wo, lr_dir, BSDF_ALL);
+				col = cadd(col, cscale(cmul(surf_col, lcol), angle_light_normal));
+			}
+		}
+	}
+	else
+	{	/* :149-342 */
+		halton_t hal_2, hal_3;
+		halton_init(&hal_2, 2); halton_init(&hal_3, 3);
+		int n = (int)ceilf((float)light->samples * st->rd->aa_light_sample_multiplier);
+		float inv_ns = 1.f / (float)n;
+		unsigned offs = (unsigned)n * st->pixel_sample + st->sampling_offs + l_offs;
+		rgb ccol = C(0, 0, 0);
+		halton_set_start(&hal_2, offs - 1);
+		halton_set_start(&hal_3, offs - 1);
+		for(int i = 0; i < n; ++i)
+		{
+			float ls_s1 = halton_next(&hal_2);
+			float ls_s2 = halton_next(&hal_3);
+			float ls_pdf; rgb ls_col;
+			if(arealight_illum_sample(light, sp->p, ls_s1, ls_s2, &lr_dir, &lr_tmax, &ls_pdf, &ls_col))
+			{
+				if(st->rd->shadow_bias_auto) lr_tmin = st->shadow_bias * fmaxf_(1.f, vlength(sp->p));
+				else lr_tmin = st->shadow_bias;
+				if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
+				else shadowed = 0;
+				if(!shadowed && ls_pdf > 1e-6f)
+				{
+					rgb surf_col = mat_eval(material, dat, sp, wo, lr_dir, BSDF_ALL);
+					float angle_light_normal = (material->flat ? 1.f : fabsf(vdot(sp->n, lr_dir)));
+					/* canIntersect() is true for area lights (light_area.h) */
+					float m_pdf = mat_pdf(material, dat, sp, wo, lr_dir, BSDF_GLOSSY | BSDF_DIFFUSE | BSDF_DISPERSIVE | BSDF_REFLECT | BSDF_TRANSMIT);
+					if(m_pdf > 1e-6f)
+					{
+						float l_2 = ls_pdf * ls_pdf;
+						float m_2 = m_pdf * m_pdf;
+						float w = l_2 / (l_2 + m_2);
+						ccol = cadd(ccol, cdiv(cscale(cscale(cmul(surf_col, ls_col), angle_light_normal), w), ls_pdf));
+					}
+					else
+					{
+						ccol = cadd(ccol, cdiv(cscale(cmul(surf_col, ls_col), angle_light_normal), ls_pdf));
+					}
+				}
+			}
+		}
+		col = cadd(col, cscale(ccol, inv_ns));
+		{	/* BSDF-sampling half of MIS :285-333 */
+			rgb ccol_2 = C(0, 0, 0);
+			halton_set_start(&hal_2, offs - 1);
+			halton_set_start(&hal_3, offs - 1);
+			for(int i = 0; i < n; ++i)
+			{
+				float b_tmin, b_tmax = -1.f; v3 b_dir = V(0, 0, 0);
+				if(st->rd->min_raydist_auto) b_tmin = st->ray_min_dist * fmaxf_(1.f, vlength(sp->p));
+				else b_tmin = st->ray_min_dist;
+				float s_1 = halton_next(&hal_2);
+				float s_2 = halton_next(&hal_3);
+				float W = 0.f;
+				sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.sampled_flags = BSDF_NONE;
+				sm.flags = BSDF_GLOSSY | BSDF_DIFFUSE | BSDF_DISPERSIVE | BSDF_REFLECT | BSDF_TRANSMIT;
+				rgb surf_col = mat_sample(material, dat, sp, wo, &b_dir, &sm, &W);
+				float light_pdf;
+				if(sm.pdf > 1e-6f && arealight_intersect(light, sp->p, b_dir, &b_tmax, &lcol, &light_pdf))
+				{
+					if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, b_dir, b_tmin, b_tmax, &st->cn);
+					else shadowed = 0;
+					if(!shadowed && light_pdf > 1e-6f)
+					{
+						float l_pdf = 1.f / light_pdf;
+						float l_2 = l_pdf * l_pdf;
+						float m_2 = sm.pdf * sm.pdf;
+						float w = m_2 / (l_2 + m_2);
+						ccol_2 = cadd(ccol_2, cscale(cscale(cmul(surf_col, lcol), w), W));
+					}
+				}
+			}
+			col = cadd(col, cscale(ccol_2, inv_ns));
+		}
+	}
+	return col;
+}
+
+/* estimateAllDirectLight, integrator_montecarlo.cc:47-60 */
+static rgb estimate_all_direct_light(rstate_t *st, const sp_t *sp, const mat_t *material, const bsdf_dat *dat, v3 wo)
+{
+	rgb col = C(0, 0, 0);
+	for(int l = 0; l < st->s->n_lights; ++l)
+		col = cadd(col, do_light_estimation(st, &st->s->lights[l], sp, material, dat, wo, (unsigned)l));
+	return col;
+}
+/* estimateOneDirectLight, :62-76.  With one light lnum is 0 whatever the counter holds. */
+static rgb estimate_one_direct_light(rstate_t *st, const sp_t *sp, const mat_t *material, const bsdf_dat *dat, v3 wo)
+{
+	int light_num = st->s->n_lights;
+	if(light_num == 0) return C(0, 0, 0);
+	halton_t hal_2; halton_init(&hal_2, 2);
+	halton_set_start(&hal_2, st->rd->base_sampling_offset + st->correlative_sample_number - 1);
+	int lnum = (int)(halton_next(&hal_2) * (float)light_num);
+	if(lnum > light_num - 1) lnum = light_num - 1;
+	++st->correlative_sample_number;
+	return cscale(do_light_estimation(st, &st->s->lights[lnum], sp, material, dat, wo, (unsigned)lnum), (float)light_num);
+}
+
+/* PathIntegrator::integrate, integrator_path_tracer.cc:112-347 (raylevel 0, no caustics, no
+ * recursive raytrace: materials with specular/glossy/filter lobes are rejected by yor_render) */
+static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, float out_rgba[4])
+{
+	const yor_scene *s = st->s;
+	const yor_render_desc *rd = st->rd;
+	rgb col = C(0, 0, 0);
+	float alpha;
+	sp_t sp;
+	float w = 0.f;
+	if(rd->bg_transp) alpha = 0.0f;
+	else alpha = 1.0f;
+	if(scene_intersect(s, from, dir, tmin, &tmax, &sp, &st->cn))
+	{
+		st->include_lights = 1; /* raylevel_ == 0, :131-135 */
+		unsigned bsdfs;
+		bsdf_dat dat0;
+		const mat_t *material = &s->mats[sp.mat];
+		mat_init_bsdf(material, &dat0, &bsdfs);
+		v3 wo = vneg(dir);
+		if(bsdfs & BSDF_EMIT) col = cadd(col, mat_emit(material, &sp, wo, st->include_lights));
+		if(bsdfs & BSDF_DIFFUSE) col = cadd(col, estimate_all_direct_light(st, &sp, material, &dat0, wo));
+		unsigned path_flags = rd->no_recursive ? BSDF_ALL : (BSDF_DIFFUSE);
+		if(rd->integrator == YOR_INTEGRATOR_PATH && (bsdfs & path_flags))
+		{
+			rgb path_col = C(0, 0, 0);
+			path_flags |= (BSDF_DIFFUSE | BSDF_REFLECT | BSDF_TRANSMIT);
+			int n_samples = rd->path_samples > 1 ? rd->path_samples : 1; /* max(1, n_paths_/ray_division_) */
+			for(int i = 0; i < n_samples; ++i)
+			{
+				unsigned offs = (unsigned)rd->path_samples * st->pixel_sample + st->sampling_offs + (unsigned)i;
+				rgb throughput, lcol, scol;
+				sp_t sp_1 = sp, sp_2;
+				sp_t *hit = &sp_1, *hit_2 = &sp_2;
+				v3 pwo = wo;
+				v3 p_dir = V(0, 0, 0); float p_tmin, p_tmax;
+				bsdf_dat dat_n;
+				float s_1 = yor_ri_vdc(offs, 0);
+				float s_2 = (float)yor_scr_halton(2, offs);
+				sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.flags = path_flags; sm.sampled_flags = BSDF_NONE;
+				scol = mat_sample(material, &dat0, &sp, pwo, &p_dir, &sm, &w);
+				scol = cscale(scol, w);
+				throughput = scol;
+				st->include_lights = 0;
+				p_tmin = st->ray_min_dist;
+				p_tmax = -1.0f;
+				if(!scene_intersect(s, sp.p, p_dir, p_tmin, &p_tmax, hit, &st->cn)) continue;
+				const mat_t *p_mat = &s->mats[hit->mat];
+				unsigned mat_bsdfs;
+				mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
+				if(sm.sampled_flags != BSDF_NONE) pwo = vneg(p_dir);
+				lcol = estimate_one_direct_light(st, hit, p_mat, &dat_n, pwo);
+				if(mat_bsdfs & BSDF_EMIT) lcol = cadd(lcol, mat_emit(p_mat, hit, pwo, st->include_lights));
+				path_col = cadd(path_col, cmul(lcol, throughput));
+				for(int depth = 1; depth < rd->bounces; ++depth)
+				{
+					int d_4 = 4 * depth;
+					sm.s_1 = (float)yor_scr_halton(d_4 + 3, offs);
+					sm.s_2 = (float)yor_scr_halton(d_4 + 4, offs);
+					sm.flags = BSDF_ALL;
+					scol = mat_sample(p_mat, &dat_n, hit, pwo, &p_dir, &sm, &w);
+					scol = cscale(scol, w);
+					if(cblack(scol)) break;
+					throughput = cmul(throughput, scol);
+					st->include_lights = 0; /* caustic = trace_caustics_ && ... ; trace_caustics_ is false */
+					p_tmin = st->ray_min_dist;
+					p_tmax = -1.0f;
+					if(!scene_intersect(s, hit->p, p_dir, p_tmin, &p_tmax, hit_2, &st->cn)) break;
+					{ sp_t *tmp = hit; hit = hit_2; hit_2 = tmp; }
+					p_mat = &s->mats[hit->mat];
+					mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
+					pwo = vneg(p_dir);
+					if(mat_bsdfs & BSDF_DIFFUSE) lcol = estimate_one_direct_light(st, hit, p_mat, &dat_n, pwo);
+					else lcol = C(0, 0, 0);
+					if(depth > rd->rr_min_bounces)
+					{	/* Russian roulette :282-288 */
+						float random_value = (float)mwc_next(st->prng);
+						float probability = fmaxf_(throughput.r, fmaxf_(throughput.g, throughput.b));
+						if(probability <= 0.f || probability < random_value) break;
+						throughput = cscale(throughput, 1.f / probability);
+					}
+					path_col = cadd(path_col, cmul(lcol, throughput));
+				}
+			}
+			col = cadd(col, cdiv(path_col, (float)n_samples));
+		}
+		if(rd->bg_transp_refract)
+		{
+			float m_alpha = (material->type == YOR_MAT_SHINYDIFFUSE) ? sd_alpha(material, &dat0, &sp, wo) : 1.f;
+			alpha = m_alpha + (1.f - m_alpha) * alpha;
+		}
+		else alpha = 1.0f;
+	}
+	else
+	{
+		if(rd->has_background && !rd->bg_transp_refract) col = cadd(col, C(rd->background[0], rd->background[1], rd->background[2]));
+	}
+	/* EmptyVolumeIntegrator: transmittance 1, integration 0 (integrator_empty_volume.cc:32-38) */
+	if(rd->bg_transp) alpha = fmaxf_(alpha, 1.f - 1.f);
+	out_rgba[0] = col.r; out_rgba[1] = col.g; out_rgba[2] = col.b; out_rgba[3] = alpha;
+}
+
+/* ------------------------------------------------------------------ film
+ * ImageFilm ctor imagefilm.cc:124-187, addSample :925-1015 */
+#define FILTER_TABLE_SIZE 16
+#define MAX_FILTER_SIZE 8
+typedef struct
+{
+	int w, h, cx0, cx1, cy0, cy1;
+	float filterw, table_scale;
+	float table[FILTER_TABLE_SIZE * FILTER_TABLE_SIZE];
+	float *pix; /* h*w*5 */
+} film_t;
+
+static float filt_box(float dx, float dy) { (void)dx; (void)dy; return 1.f; }
+static float filt_mitchell(float dx, float dy) /* :85-97 */
+{
+	float x = 2.f * yor_fsqrt(dx * dx + dy * dy);
+	if(x >= 2.f) return (0.f);
+	if(x >= 1.f) return (float)(x * (x * (x * -0.38888889f + 2.0f) - 3.33333333f) + 1.77777778f);
+	return (float)(x * x * (1.16666666f * x - 2.0f) + 0.88888889f);
+}
+static float filt_gauss(float dx, float dy) /* :100-104 ; fExp__ = fExp2__((float)M_LOG2E * a) */
+{
+	float r_2 = dx * dx + dy * dy;
+	float e = yor_fexp2((float)1.4426950408889634074 * (float)(-6 * r_2));
+	return fmaxf_(0.f, (float)((double)e - 0.00247875));
+}
+static float filt_lanczos(float dx, float dy) /* :107-121 */
+{
+	float x = yor_fsqrt(dx * dx + dy * dy);
+	if(x == 0.f) return 1.f;
+	if(-2 < x && x < 2)
+	{
+		float a = (float)(Y_M_PI * (double)x);
+		float b = (float)(Y_M_PI_2 * (double)x);
+		return ((yor_fsin(a) * yor_fsin(b)) / (a * b));
+	}
+	return 0.f;
+}
+static inline int round2int(double val) { return (int)(val + (.5 - 1.4e-11)); } /* util_math.h:34-43 */
+
+static void film_init(film_t *f, const yor_render_desc *rd, float *pix)
+{
+	f->w = rd->width; f->h = rd->height; f->cx0 = rd->xstart; f->cy0 = rd->ystart;
+	f->cx1 = rd->xstart + rd->width; f->cy1 = rd->ystart + rd->height;
+	f->filterw = (float)((double)rd->aa_pixelwidth * 0.5);
+	float (*ffunc)(float, float) = filt_box;
+	switch(rd->filter_type)
+	{
+		case YOR_FILTER_MITCHELL: ffunc = filt_mitchell; f->filterw *= 2.6f; break;
+		case YOR_FILTER_LANCZOS: ffunc = filt_lanczos; break;
+		case YOR_FILTER_GAUSS: ffunc = filt_gauss; f->filterw *= 2.f; break;
+		default: ffunc = filt_box;
+	}
+	f->filterw = fminf_(fmaxf_(0.501f, f->filterw), 0.5f * MAX_FILTER_SIZE);
+	float scale = 1.f / (float)FILTER_TABLE_SIZE;
+	float *tp = f->table;
+	for(int y = 0; y < FILTER_TABLE_SIZE; ++y)
+		for(int x = 0; x < FILTER_TABLE_SIZE; ++x)
+			*tp++ = ffunc((x + .5f) * scale, (y + .5f) * scale);
+	f->table_scale = (float)(0.9999 * FILTER_TABLE_SIZE / (double)f->filterw);
+	f->pix = pix;
+}
+
+typedef struct { int x, y; float c[4]; float wt; } splat_t;
+typedef struct { splat_t *v; size_t n, cap; } splat_list;
+
+/* addSample :925-1015, combined pass only, aa_clamp_samples_ = 0, premult false.
+ * own_only != NULL: contributions to pixels other than (x,y) are deferred into the list (used by
+ * the multi-threaded mode so that tiles never write each other's pixels concurrently). */
+static void film_add_sample(film_t *f, const float col[4], int x, int y, float dx, float dy, splat_list *deferred)
+{
+	int dx_0, dx_1, dy_0, dy_1, x_0, x_1, y_0, y_1;
+	dx_0 = round2int((double)dx - (double)f->filterw); if(f->cx0 - x > dx_0) dx_0 = f->cx0 - x;
+	dx_1 = round2int((double)dx + (double)f->filterw - 1.0); if(f->cx1 - x - 1 < dx_1) dx_1 = f->cx1 - x - 1;
+	dy_0 = round2int((double)dy - (double)f->filterw); if(f->cy0 - y > dy_0) dy_0 = f->cy0 - y;
+	dy_1 = round2int((double)dy + (double)f->filterw - 1.0); if(f->cy1 - y - 1 < dy_1) dy_1 = f->cy1 - y - 1;
+	double x_offs = (double)dx - 0.5;
+	int x_index[MAX_FILTER_SIZE + 1], y_index[MAX_FILTER_SIZE + 1];
+	for(int i = dx_0, n = 0; i <= dx_1; ++i, ++n)
+	{
+		double d = fabs(((double)i - x_offs) * (double)f->table_scale);
+		x_index[n] = (int)floor(d);
+	}
+	double y_offs = (double)dy - 0.5;
+	for(int i = dy_0, n = 0; i <= dy_1; ++i, ++n)
+	{
+		double d = fabs(((double)i - y_offs) * (double)f->table_scale);
+		y_index[n] = (int)floor(d);
+	}
+	x_0 = x + dx_0; x_1 = x + dx_1;
+	y_0 = y + dy_0; y_1 = y + dy_1;
+	for(int j = y_0; j <= y_1; ++j)
+		for(int i = x_0; i <= x_1; ++i)
+		{
+			int offset = y_index[j - y_0] * FILTER_TABLE_SIZE + x_index[i - x_0];
+			float filter_wt = f->table[offset];
+			if(deferred && (i != x || j != y))
+			{
+				if(deferred->n == deferred->cap)
+				{
+					deferred->cap = deferred->cap ? deferred->cap * 2 : 256;
+					deferred->v = (splat_t *)realloc(deferred->v, deferred->cap * sizeof(splat_t));
+				}
+				splat_t *sp = &deferred->v[deferred->n++];
+				sp->x = i; sp->y = j; memcpy(sp->c, col, sizeof sp->c); sp->wt = filter_wt;
+				continue;
+			}
+			float *p = f->pix + 5 * ((size_t)(j - f->cy0) * (size_t)f->w + (size_t)(i - f->cx0));
+			p[0] += col[0] * filter_wt; p[1] += col[1] * filter_wt; p[2] += col[2] * filter_wt; p[3] += col[3] * filter_wt;
+			p[4] += filter_wt;
+		}
+}
+
+/* ------------------------------------------------------------------ renderTile
+ * TiledIntegrator::renderTile, integrator_tiled.cc:309-521 (single pass, not adaptive) */
+typedef struct
+{
+	const yor_scene *s; const yor_render_desc *rd; film_t *film;
+	int n_tiles_x, n_tiles_y;
+	int thread_id, n_threads;
+	counters_t cn; uint64_t camera_samples;
+	splat_list deferred;
+} worker_t;
+
+static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
+{
+	const yor_render_desc *rd = wk->rd;
+	const camera_t *cam = &wk->s->cam;
+	int ax = rd->xstart + tx * rd->tile_size, ay = rd->ystart + ty * rd->tile_size;
+	int end_x = ax + rd->tile_size, end_y = ay + rd->tile_size;
+	if(end_x > rd->xstart + rd->width) end_x = rd->xstart + rd->width;
+	if(end_y > rd->ystart + rd->height) end_y = rd->ystart + rd->height;
+	int n_samples = rd->aa_minsamples;
+	int offset = (int)rd->base_sampling_offset; /* renderPass(samples, offset=0) + base offset, :203,263 */
+	int x = cam->resx;
+	float dx = 0.5, dy = 0.5, d_1 = (float)(1.0 / (double)(float)n_samples);
+	float wt;
+	mwc_t prng;
+	/* :319 — rand() of libc is replaced by rd->tile_seed_rand; only Russian roulette consumes the stream */
+	mwc_init(&prng, (uint32_t)((int)rd->tile_seed_rand + offset * (x * ay + ax) + 123));
+	st->prng = &prng;
+	int pass_offs = offset;
+	for(int i = ay; i < end_y; ++i)
+	{
+		for(int j = ax; j < end_x; ++j)
+		{
+			st->sampling_offs = yor_fnv32a((uint32_t)i * yor_fnv32a((uint32_t)j)); /* :379 */
+			for(int sample = 0; sample < n_samples; ++sample)
+			{
+				st->pixel_sample = (unsigned)(pass_offs + sample);
+				if(n_samples > 1)
+				{	/* :399-403 (aa_passes_ == 1) */
+					dx = (float)((0.5 + (double)(float)sample) * (double)d_1);
+					dy = yor_ri_lp((uint32_t)sample + st->sampling_offs, 0);
+				}
+				v3 from, dir; float tmin, tmax;
+				camera_shoot(cam, j + dx, i + dy, &from, &dir, &tmin, &tmax, &wt);
+				wk->camera_samples++;
+				float c[4];
+				integrate(st, from, dir, tmin, tmax, c);
+				if(c[3] > 1.f) c[3] = 1.f;                 /* :459 */
+				c[0] *= wt; c[1] *= wt; c[2] *= wt; c[3] *= wt; /* :512 */
+				film_add_sample(wk->film, c, j, i, dx, dy, wk->n_threads > 1 ? &wk->deferred : NULL);
+			}
+		}
+	}
+}
+
+static void *worker_main(void *arg)
+{
+	worker_t *wk = (worker_t *)arg;
+	const yor_render_desc *rd = wk->rd;
+	rstate_t st;
+	memset(&st, 0, sizeof st);
+	st.s = wk->s; st.rd = rd;
+	st.shadow_bias = rd->shadow_bias_auto ? (float)YAF_SHADOW_BIAS : rd->shadow_bias;   /* scene.cc:825 */
+	st.ray_min_dist = rd->min_raydist_auto ? (float)MIN_RAYDIST : rd->min_raydist;      /* scene.cc:826 */
+	int n_tiles = wk->n_tiles_x * wk->n_tiles_y;
+	int shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
+	int k = 0;
+	for(int t = 0; t < n_tiles; ++t)
+	{
+		if((t % shard_count) != rd->shard_index) continue;
+		if((k++ % wk->n_threads) != wk->thread_id) continue;
+		render_tile(wk, t % wk->n_tiles_x, t / wk->n_tiles_x, &st);
+	}
+	wk->cn = st.cn;
+	return NULL;
+}
+
+int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_stats *stats)
+{
+	if(rd->aa_passes != 1) return -1;
+	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
+	if(s->cam.aperture != 0.f) return -3;
+	for(int i = 0; i < s->n_mats; ++i)
+		if(s->mats[i].flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace not restated */
+	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
+	struct timespec t0, t1;
+	memset(film_out, 0, sizeof(float) * 5 * (size_t)rd->width * (size_t)rd->height);
+	film_t film;
+	film_init(&film, rd, film_out);
+	int ntx = (rd->width + rd->tile_size - 1) / rd->tile_size, nty = (rd->height + rd->tile_size - 1) / rd->tile_size;
+	int nthreads = rd->n_threads > 0 ? rd->n_threads : 1;
+	worker_t *wk = (worker_t *)calloc((size_t)nthreads, sizeof(worker_t));
+	pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for(int i = 0; i < nthreads; ++i)
+	{
+		wk[i].s = s; wk[i].rd = rd; wk[i].film = &film; wk[i].n_tiles_x = ntx; wk[i].n_tiles_y = nty;
+		wk[i].thread_id = i; wk[i].n_threads = nthreads;
+	}
+	if(nthreads == 1) worker_main(&wk[0]);
+	else
+	{
+		for(int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, worker_main, &wk[i]);
+		for(int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+		/* deferred cross-pixel splats, applied in thread order (sum order differs from the
+		 * single-thread run by at most the position of these few additions) */
+		for(int i = 0; i < nthreads; ++i)
+		{
+			for(size_t k = 0; k < wk[i].deferred.n; ++k)
+			{
+				splat_t *sp = &wk[i].deferred.v[k];
+				float *p = film.pix + 5 * ((size_t)(sp->y - film.cy0) * (size_t)film.w + (size_t)(sp->x - film.cx0));
+				p[0] += sp->c[0] * sp->wt; p[1] += sp->c[1] * sp->wt; p[2] += sp->c[2] * sp->wt; p[3] += sp->c[3] * sp->wt;
+				p[4] += sp->wt;
+			}
+			free(wk[i].deferred.v);
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if(stats)
+	{
+		memset(stats, 0, sizeof *stats);
+		for(int i = 0; i < nthreads; ++i)
+		{
+			stats->rays_closest += wk[i].cn.rays_closest; stats->rays_shadow += wk[i].cn.rays_shadow;
+			stats->interior_steps += wk[i].cn.interior; stats->leaves += wk[i].cn.leaves; stats->tri_tests += wk[i].cn.tests;
+			stats->camera_samples += wk[i].camera_samples;
+		}
+		stats->kd_nodes = s->n_nodes; stats->kd_leaf_refs = s->n_refs;
+		stats->build_seconds = s->build_seconds;
+		stats->render_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+	}
+	free(wk); free(th);
+	return 0;
+}
+
+/* ------------------------------------------------------------------ ray-level entry points */
+int yor_intersect(const yor_scene *s, int use_tree, const float from[3], const float dir[3], float tmin, float tmax,
+                  int32_t *tri, float *t, float bary[3])
+{
+	v3 f = V(from[0], from[1], from[2]), d = V(dir[0], dir[1], dir[2]);
+	float dis = tmax < 0 ? INFINITY : tmax, z = 0, bu = 0, bv = 0; int ti = -1;
+	int hit = use_tree ? kd_intersect(s, f, d, tmin, dis, &ti, &z, &bu, &bv, NULL) : brute_intersect(s, f, d, tmin, dis, &ti, &z, &bu, &bv);
+	*tri = hit ? ti : -1; *t = hit ? z : 0.f;
+	bary[0] = hit ? 1 - bu - bv : 0.f; bary[1] = hit ? bu : 0.f; bary[2] = hit ? bv : 0.f;
+	return hit;
+}
+int yor_is_shadowed(const yor_scene *s, int use_tree, const float from[3], const float dir[3], float tmin, float tmax)
+{
+	v3 f = V(from[0], from[1], from[2]), d = V(dir[0], dir[1], dir[2]);
+	v3 sfrom = vadd(f, vmul(d, tmin));
+	float dis = tmax < 0 ? INFINITY : tmax - 2 * tmin;
+	return use_tree ? kd_intersect_s(s, sfrom, d, dis, NULL) : brute_intersect_s(s, sfrom, d, dis);
+}
+
+/* ------------------------------------------------------------------ component entry points */
+void yor_create_cs(const float n[3], float u[3], float v[3])
+{
+	v3 uu, vv; create_cs(V(n[0], n[1], n[2]), &uu, &vv);
+	u[0] = uu.x; u[1] = uu.y; u[2] = uu.z; v[0] = vv.x; v[1] = vv.y; v[2] = vv.z;
+}
+void yor_sample_cos_hemisphere(const float n[3], const float ru[3], const float rv[3], float s1, float s2, float out[3])
+{
+	v3 r = sample_cos_hemisphere(V(n[0], n[1], n[2]), V(ru[0], ru[1], ru[2]), V(rv[0], rv[1], rv[2]), s1, s2);
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+int yor_bound_cross(const float a[3], const float g[3], const float from[3], const float dir[3], float dist, float *enter, float *leave)
+{
+	return bound_cross(V(a[0], a[1], a[2]), V(g[0], g[1], g[2]), V(from[0], from[1], from[2]), V(dir[0], dir[1], dir[2]), enter, leave, dist);
+}
+void yor_camera_shoot(const yor_camera_desc *cam, float px, float py, float out9[9])
+{
+	camera_t c; camera_configure(&c, cam);
+	v3 f, d; float tmin, tmax, wt;
+	camera_shoot(&c, px, py, &f, &d, &tmin, &tmax, &wt);
+	out9[0] = f.x; out9[1] = f.y; out9[2] = f.z; out9[3] = d.x; out9[4] = d.y; out9[5] = d.z; out9[6] = tmin; out9[7] = tmax; out9[8] = wt;
+}
+int yor_arealight_illum_sample(const yor_light_desc *ld, const float p[3], float s1, float s2, float out8[8])
+{
+	light_t l; light_configure(&l, ld);
+	v3 dir = V(0, 0, 0); float tmax = 0, pdf = 0; rgb col = C(0, 0, 0);
+	int ok = arealight_illum_sample(&l, V(p[0], p[1], p[2]), s1, s2, &dir, &tmax, &pdf, &col);
+	if(!ok) { dir = V(0, 0, 0); tmax = 0; pdf = 0; col = C(0, 0, 0); }
+	out8[0] = dir.x; out8[1] = dir.y; out8[2] = dir.z; out8[3] = tmax; out8[4] = pdf; out8[5] = col.r; out8[6] = col.g; out8[7] = col.b;
+	return ok;
+}
+int yor_arealight_intersect(const yor_light_desc *ld, const float from[3], const float dir[3], float out5[5])
+{
+	light_t l; light_configure(&l, ld);
+	float t = 0, ipdf = 0; rgb col = C(0, 0, 0);
+	int ok = arealight_intersect(&l, V(from[0], from[1], from[2]), V(dir[0], dir[1], dir[2]), &t, &col, &ipdf);
+	if(!ok) { t = 0; ipdf = 0; col = C(0, 0, 0); }
+	out5[0] = t; out5[1] = ipdf; out5[2] = col.r; out5[3] = col.g; out5[4] = col.b;
+	return ok;
+}
+int yor_pointlight_illuminate(const yor_light_desc *ld, const float p[3], float out7[7])
+{
+	light_t l; light_configure(&l, ld);
+	v3 dir = V(0, 0, 0); float tmax = 0; rgb col = C(0, 0, 0);
+	int ok = pointlight_illuminate(&l, V(p[0], p[1], p[2]), &col, &dir, &tmax);
+	out7[0] = dir.x; out7[1] = dir.y; out7[2] = dir.z; out7[3] = tmax; out7[4] = col.r; out7[5] = col.g; out7[6] = col.b;
+	return ok;
+}
+void yor_material_probe(const yor_material_desc *md, const float in14[14], int32_t sample_flags,
+                        int32_t *bsdf_flags, float eval3[3], float *pdf, int32_t *sampled_flags, float sample8[8])
+{
+	mat_t m; mat_configure(&m, md);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.n = V(in14[0], in14[1], in14[2]); sp.ng = V(in14[3], in14[4], in14[5]);
+	create_cs(sp.n, &sp.nu, &sp.nv);
+	v3 wo = V(in14[6], in14[7], in14[8]), wl = V(in14[9], in14[10], in14[11]);
+	bsdf_dat dat; unsigned flags;
+	mat_init_bsdf(&m, &dat, &flags);
+	*bsdf_flags = (int32_t)flags;
+	rgb e = mat_eval(&m, &dat, &sp, wo, wl, BSDF_ALL);
+	eval3[0] = e.r; eval3[1] = e.g; eval3[2] = e.b;
+	*pdf = mat_pdf(&m, &dat, &sp, wo, wl, BSDF_GLOSSY | BSDF_DIFFUSE | BSDF_DISPERSIVE | BSDF_REFLECT | BSDF_TRANSMIT);
+	sample_t s; s.s_1 = in14[12]; s.s_2 = in14[13]; s.pdf = 0.f; s.flags = (unsigned)sample_flags; s.sampled_flags = BSDF_NONE;
+	v3 wi = V(0, 0, 0); float w = 0.f;
+	rgb sc = mat_sample(&m, &dat, &sp, wo, &wi, &s, &w);
+	*sampled_flags = (int32_t)s.sampled_flags;
+	sample8[0] = sc.r; sample8[1] = sc.g; sample8[2] = sc.b; sample8[3] = wi.x; sample8[4] = wi.y; sample8[5] = wi.z; sample8[6] = s.pdf; sample8[7] = w;
+}
+void yor_lightmat_emit(const yor_material_desc *md, const float n[3], const float wo[3], int include_lights, float out3[3])
+{
+	mat_t m; mat_configure(&m, md);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.n = V(n[0], n[1], n[2]);
+	rgb e = mat_emit(&m, &sp, V(wo[0], wo[1], wo[2]), include_lights);
+	out3[0] = e.r; out3[1] = e.g; out3[2] = e.b;
+}

@@ -1,0 +1,142 @@
+/* yafaray_c_api.h — the drop-in boundary: libYafaRay's scene/render API as a C ABI.
+ *
+ * The reference snapshot has no C API; its public surface is the C++ class yafaray4::Interface
+ * (include/interface/interface.h:48-139, src/interface/interface.cc) reached through the single
+ * C-linkage factory getYafray__() (interface.cc:451-457).  This header flattens that class 1:1 —
+ * one function per Interface method, same name, same argument meaning, the object as first
+ * parameter — so a binding written against Interface ports by renaming.  Each declaration cites
+ * the method it replaces.  Error convention of the reference is kept: bool results (0 = wrong
+ * state / missing object), NULL from failed create*, no exceptions; additionally
+ * yafaray_getLastError() returns the diagnostic the reference would have logged.
+ *
+ * Scope: scenes of type "triangle"; materials shinydiffusemat / glossy(as_diffuse) /
+ * light_mat; lights arealight / pointlight; camera perspective (pinhole); background constant;
+ * integrators pathtracing / directlighting; volume integrator none.  Anything else fails loudly
+ * at create* or render time — nothing falls back to a CPU path.
+ */
+#ifndef YAFARAY_C_API_H
+#define YAFARAY_C_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int yafaray_bool_t;
+typedef struct yafaray_interface yafaray_interface_t;
+/* borrowed handles, owned by the interface until clearAll (environment.h:85-95) */
+typedef struct yafaray_material yafaray_material_t;
+typedef struct yafaray_light yafaray_light_t;
+typedef struct yafaray_camera yafaray_camera_t;
+typedef struct yafaray_background yafaray_background_t;
+typedef struct yafaray_integrator yafaray_integrator_t;
+
+/* ColorOutput (include/output/output.h:38-51) as a callback table; any member may be NULL.
+ * putPixel receives linear RGBA of the "combined" pass, x/y relative to the render window. */
+typedef struct yafaray_output
+{
+	void *user;
+	yafaray_bool_t (*putPixel)(void *user, int num_view, int x, int y, float r, float g, float b, float a);
+	void (*flush)(void *user, int num_view);
+	void (*flushArea)(void *user, int num_view, int x0, int y0, int x1, int y1);
+	void (*highlightArea)(void *user, int num_view, int x0, int y0, int x1, int y1);
+} yafaray_output_t;
+
+/* ProgressBar (include/common/monitor.h:29-44) */
+typedef struct yafaray_progress
+{
+	void *user;
+	void (*init)(void *user, int total_steps);
+	void (*update)(void *user, int steps);
+	void (*done)(void *user);
+	void (*setTag)(void *user, const char *text);
+} yafaray_progress_t;
+
+/* Interface::Interface / ~Interface, interface.cc:85-103 ; getYafray__ :451-457 */
+yafaray_interface_t *yafaray_createInterface(void);
+void yafaray_destroyInterface(yafaray_interface_t *yi);
+const char *yafaray_getLastError(const yafaray_interface_t *yi);
+const char *yafaray_getVersion(void);                                            /* interface.h:116 */
+
+/* scene state machine — Interface::startScene .. endGeometry, interface.cc:113-219 */
+yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type);            /* interface.h:107 */
+yafaray_bool_t yafaray_startGeometry(yafaray_interface_t *yi);                   /* :54 */
+yafaray_bool_t yafaray_endGeometry(yafaray_interface_t *yi);                     /* :55 */
+unsigned int yafaray_getNextFreeId(yafaray_interface_t *yi);                     /* :60 */
+yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, int vertices, int triangles,
+                                    yafaray_bool_t has_orco, yafaray_bool_t has_uv, int type, int obj_pass_index); /* :61 */
+yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi);                      /* :64 */
+int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z);    /* :66 */
+void yafaray_addNormal(yafaray_interface_t *yi, double nx, double ny, double nz);/* :68 */
+yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c, const yafaray_material_t *mat); /* :69 */
+yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle); /* :72 */
+/* extension (not in the reference): bulk form of addVertex/addTriangle for large meshes;
+ * verts = n_verts*3 floats, indices = n_tris*3 ints, one material for all triangles */
+yafaray_bool_t yafaray_addTriangles(yafaray_interface_t *yi, int n_verts, const float *verts, int n_tris, const int *indices,
+                                    const yafaray_material_t *mat);
+
+/* ParamMap builders — interface.cc:221-310 */
+void yafaray_paramsSetPoint(yafaray_interface_t *yi, const char *name, double x, double y, double z);   /* :76 */
+void yafaray_paramsSetString(yafaray_interface_t *yi, const char *name, const char *s);                 /* :77 */
+void yafaray_paramsSetBool(yafaray_interface_t *yi, const char *name, yafaray_bool_t b);                /* :78 */
+void yafaray_paramsSetInt(yafaray_interface_t *yi, const char *name, int i);                            /* :79 */
+void yafaray_paramsSetFloat(yafaray_interface_t *yi, const char *name, double f);                       /* :80 */
+void yafaray_paramsSetColor(yafaray_interface_t *yi, const char *name, float r, float g, float b, float a); /* :81 */
+void yafaray_paramsClearAll(yafaray_interface_t *yi);                                                   /* :87 */
+void yafaray_paramsStartList(yafaray_interface_t *yi);                                                  /* :88 */
+void yafaray_paramsPushList(yafaray_interface_t *yi);                                                   /* :89 */
+void yafaray_paramsEndList(yafaray_interface_t *yi);                                                    /* :90 */
+
+/* RenderEnvironment factories — interface.cc:312-372; dispatch on the "type" string exactly like
+ * Material::factory (src/material/material.cc:36-52), Light::factory (src/light/light.cc:36-51),
+ * Camera::factory (src/camera/camera.cc:34-44), Integrator::factory (src/integrator/integrator.cc:36-57) */
+yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name);            /* :92 */
+yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *name);      /* :94 */
+yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name);          /* :95 */
+yafaray_background_t *yafaray_createBackground(yafaray_interface_t *yi, const char *name);  /* :96 */
+yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const char *name);  /* :97 */
+void yafaray_clearAll(yafaray_interface_t *yi);                                             /* :101 */
+
+/* Interface::render, interface.cc:411-418 = RenderEnvironment::setupScene (environment.cc:679-813)
+ * + Scene::render (scene.cc:1037-1067).  Blocking.  Reads the render settings from the current
+ * ParamMap (camera_name, integrator_name, volintegrator_name, background_name, width, height,
+ * xstart, ystart, AA_*, filter_type, AA_pixelwidth, tile_size, tiles_order, threads, adv_*).
+ * Returns void in the reference; here 1 on success, 0 on failure (yafaray_getLastError). */
+yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *output, const yafaray_progress_t *progress);
+void yafaray_abort(yafaray_interface_t *yi);                                                 /* :110 */
+yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output); /* :112 */
+
+/* ---- additions for measurement and multi-GPU drivers (no reference counterpart) ---- */
+typedef struct yafaray_render_stats
+{
+	uint64_t rays_closest, rays_shadow, interior_steps, leaves, tri_tests, camera_samples, restarts;
+	double tree_build_seconds, upload_seconds, render_seconds; /* render_seconds: device time of the pass */
+	uint32_t kd_nodes, kd_leaf_refs, kd_max_depth, n_triangles;
+	uint64_t scene_device_bytes;
+} yafaray_render_stats_t;
+/* The float film of the last render: height*width*5 floats {r,g,b,a,weight} — the payload of the
+ * reference's film file (imagefilm.cc:1560-1657), i.e. what its ImageFilm holds before normalisation. */
+yafaray_bool_t yafaray_getFilm(yafaray_interface_t *yi, float *film, int width, int height);
+yafaray_bool_t yafaray_getRenderStats(yafaray_interface_t *yi, yafaray_render_stats_t *stats);
+/* pixel-tile sharding: must be set before render; tile t belongs to shard t % count */
+void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count);
+/* Two-step render for drivers that own device memory and streams (bench.py, RCCL reduce):
+ * prepare = setupScene + Scene::update (tree build, upload); renderPass launches one pass
+ * asynchronously on `stream` into caller-owned device memory d_planes (yafgpu_planes_bytes). */
+yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi);
+yafaray_bool_t yafaray_renderPassDevice(yafaray_interface_t *yi, float *d_planes, void *d_counters, void *stream);
+yafaray_bool_t yafaray_getRenderSize(yafaray_interface_t *yi, int *width, int *height);
+/* Scene::intersect / Scene::isShadowed (scene.cc:896-994) on host ray batches, after prepareRender:
+ * rays = n*8 floats {from.xyz, dir.xyz, tmin, tmax (<0 = infinite)}; tri = -1 on a miss */
+yafaray_bool_t yafaray_intersectRays(yafaray_interface_t *yi, int n, const float *rays, int *tri, float *t, float *bary);
+yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *rays, int *shadowed);
+
+/* XML scene loader: src/loader_xml/loader_xml.cc + src/common/import_xml.cc drive the same calls
+ * from a scene file.  Parses `path` and leaves the interface ready for yafaray_render. */
+yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

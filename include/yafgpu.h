@@ -1,0 +1,160 @@
+/* yafgpu.h — the narrow host<->device seam of the MI355X path-tracing core.
+ *
+ * This is the C ABI *inside* the drop-in ("second, narrower C ABI"): the wide,
+ * Interface-shaped API in yafaray_c_api.h flattens a scene into the POD blocks below and calls
+ * these entry points.  Plain pointers and sizes only; device buffers are raw HIP device pointers
+ * so that a caller may own them (e.g. a torch tensor's data_ptr()) or let the library allocate.
+ *
+ * What each entry point replaces in the reference:
+ *   yafgpu_scene_create   <- Scene::update()                (src/common/scene.cc:784-894): kd-tree
+ *                            build (TriKdTree ctor, kdtree_triangle.cc:76-157) + Triangle cached
+ *                            values (triangle.h:197-207) + Light::init
+ *   yafgpu_render_tiles   <- TiledIntegrator::renderPass / renderTile
+ *                            (src/integrator/integrator_tiled.cc:261-521) with
+ *                            PathIntegrator::integrate (integrator_path_tracer.cc:112-347) and
+ *                            ImageFilm::addSample (src/common/imagefilm.cc:925-1015) inside
+ *   yafgpu_film_combine   <- the per-pixel sum that addSample performs across neighbouring samples
+ *   yafgpu_trace_rays     <- Scene::intersect / Scene::isShadowed (scene.cc:896-994) on ray batches
+ */
+#ifndef YAFGPU_H
+#define YAFGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YAFGPU_FILM_CHANNELS 5   /* r,g,b,a,weight : Pixel, include/utility/util_image_buffers.h:36-48 */
+#define YAFGPU_FILM_PLANES   4   /* own, right, down, diagonal splat planes */
+
+enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2 };
+enum { YAFGPU_LIGHT_AREA = 0, YAFGPU_LIGHT_POINT = 1 };
+enum { YAFGPU_INTEGRATOR_PATH = 0, YAFGPU_INTEGRATOR_DIRECT = 1 };
+
+/* A material after its factory()/config() ran on the host (material_shiny_diffuse.cc:46-92,
+ * material_glossy.cc:32-50, material_simple.cc:36-39).  64 floats, 16-byte aligned. */
+typedef struct yafgpu_material
+{
+	int32_t type, visibility, receive_shadows, flat;
+	uint32_t bsdf_flags;
+	int32_t n_bsdf;
+	uint32_t c_flags[4];
+	int32_t c_index[4];
+	/* shinydiffuse */
+	float diffuse_color[3], mirror_color[3], emit_color[3];
+	float mirror_strength, transparency_strength, translucency_strength, diffuse_strength;
+	float transmit_filter, ior_squared;
+	int32_t is_mirror, is_transparent, is_translucent, is_diffuse, has_fresnel;
+	int32_t use_oren;
+	float oren_a, oren_b;
+	/* glossy */
+	float gloss_color[3], diff_color[3];
+	float exponent, reflectivity, diffuse;
+	int32_t as_diffuse, with_diffuse;
+	/* light material */
+	float light_col[3];
+	int32_t double_sided;
+	int32_t pad[7];
+} yafgpu_material;
+
+/* A light after its constructor ran on the host (light_area.cc:34-52, light_point.cc:28-36) */
+typedef struct yafgpu_light
+{
+	int32_t type, samples, cast_shadows, pad0;
+	float corner[3], c2[3], c3[3], c4[3], to_x[3], to_y[3], fnormal[3];
+	float color[3];
+	float area;
+	float position[3];
+	float pad1[2];
+} yafgpu_light;
+
+/* PerspectiveCamera after setAxis (camera_perspective.cc:60-74) */
+typedef struct yafgpu_camera
+{
+	float position[3], vto[3], vup[3], vright[3];
+	float near_p[3], near_n[3], far_p[3], far_n[3];
+	int32_t resx, resy;
+} yafgpu_camera;
+
+typedef struct yafgpu_scene_desc
+{
+	int32_t n_tris;
+	const float *verts;          /* n_tris*9: a,b,c */
+	const int32_t *tri_mat;      /* n_tris */
+	const float *vnormals;       /* NULL or n_tris*9; an all-zero triple means "use the geometric normal" */
+	int32_t n_materials;
+	const yafgpu_material *materials;
+	int32_t n_lights;
+	const yafgpu_light *lights;
+	yafgpu_camera camera;
+	int32_t build_threads;       /* host threads for the kd build; <=0: hardware concurrency */
+} yafgpu_scene_desc;
+
+typedef struct yafgpu_render_params
+{
+	int32_t integrator;            /* YAFGPU_INTEGRATOR_* */
+	int32_t path_samples, bounces, rr_min_bounces, no_recursive, bg_transp, bg_transp_refract;
+	int32_t width, height, xstart, ystart;
+	int32_t aa_minsamples;
+	float aa_pixelwidth;           /* box filter; the GPU film supports filterw <= 0.501 (AA_pixelwidth <= 1.002) */
+	int32_t tile_size;
+	uint32_t base_sampling_offset;
+	int32_t shadow_bias_auto; float shadow_bias;
+	int32_t min_raydist_auto; float min_raydist;
+	float aa_light_sample_multiplier;
+	float background[3]; int32_t has_background;
+	/* pixel-tile sharding across GPUs: tile t is rendered iff t % shard_count == shard_index */
+	int32_t shard_index, shard_count;
+} yafgpu_render_params;
+
+typedef struct yafgpu_counters   /* device atomics, accumulated per launch */
+{
+	uint64_t rays_closest, rays_shadow, interior_steps, leaves, tri_tests, camera_samples, restarts, pad;
+} yafgpu_counters;
+
+typedef struct yafgpu_tree_info
+{
+	uint32_t n_nodes, n_leaf_refs, max_depth, n_tris;
+	double build_seconds, upload_seconds;
+	uint64_t device_bytes;
+} yafgpu_tree_info;
+
+typedef struct yafgpu_scene yafgpu_scene_t;
+
+/* all functions return 0 on success, a negative code on failure; yafgpu_last_error() describes it */
+const char *yafgpu_last_error(void);
+int yafgpu_device_count(void);
+int yafgpu_set_device(int device);
+
+int yafgpu_scene_create(const yafgpu_scene_desc *desc, yafgpu_scene_t **out);
+void yafgpu_scene_destroy(yafgpu_scene_t *scene);
+int yafgpu_scene_info(const yafgpu_scene_t *scene, yafgpu_tree_info *info);
+
+/* bytes of one plane set: YAFGPU_FILM_PLANES*height*width*YAFGPU_FILM_CHANNELS floats */
+uint64_t yafgpu_planes_bytes(int32_t width, int32_t height);
+
+/* Render every tile of this shard.  d_planes: device pointer to yafgpu_planes_bytes() bytes (zeroed by
+ * the call); d_counters: device pointer to a yafgpu_counters (may be NULL); stream: hipStream_t or NULL.
+ * Asynchronous on `stream`. */
+int yafgpu_render_tiles(yafgpu_scene_t *scene, const yafgpu_render_params *rp, float *d_planes,
+                        yafgpu_counters *d_counters, void *stream);
+
+/* d_film[h][w][5] = own + right(x-1) + down(y-1) + diag(x-1,y-1), in that fixed order */
+int yafgpu_film_combine(const float *d_planes, float *d_film, int32_t width, int32_t height, void *stream);
+
+/* Convenience: allocate, render, combine, copy the film to host memory, synchronise. */
+int yafgpu_render_to_host(yafgpu_scene_t *scene, const yafgpu_render_params *rp, float *h_film, yafgpu_counters *h_counters);
+
+/* Ray batches (host pointers): rays = n*8 floats {from.xyz, dir.xyz, tmin, tmax}; closest-hit writes
+ * tri (int32, -1 = miss), t, and barycentrics b0,b1,b2 (n*3); any-hit writes 0/1 into shadowed. */
+int yafgpu_trace_closest(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *tri, float *t, float *bary);
+int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *shadowed);
+
+/* kd-tree built on the host, downloadable for inspection/tests: nodes = n_nodes*2 uint32, refs = n_leaf_refs uint32 */
+int yafgpu_scene_get_tree(const yafgpu_scene_t *scene, uint32_t *nodes, uint32_t *refs, float bound6[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

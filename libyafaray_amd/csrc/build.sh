@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds libyafaray_gpu.so (HIP kernels + narrow ABI + Interface-shaped C API) for gfx950, in-tree.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../libyafaray_gpu.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# -ffp-contract=off and IEEE divide/sqrt: the shading arithmetic must round like the reference's
+# expressions (discrete hit / lobe / shadow decisions decide image parity)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
+mkdir -p "$HERE/obj"
+"$HIPCC" $FLAGS -c "$HERE/yafgpu_device.hip" -o "$HERE/obj/yafgpu_device.o" ${YAFGPU_EXTRA_FLAGS:-}
+"$HIPCC" $FLAGS -c "$HERE/kdtree_build.cpp" -o "$HERE/obj/kdtree_build.o"
+SRCS_CPP=""
+for f in yafaray_c_api yafaray_xml; do
+  if [ -f "$HERE/$f.cpp" ]; then "$HIPCC" $FLAGS -c "$HERE/$f.cpp" -o "$HERE/obj/$f.o"; SRCS_CPP="$SRCS_CPP $HERE/obj/$f.o"; fi
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/yafgpu_device.o" "$HERE/obj/kdtree_build.o" $SRCS_CPP -lpthread
+echo "built $OUT"

@@ -1,0 +1,267 @@
+// Flattened SAH kd-tree build (host).  See kdtree_build.h.
+//
+// Strategy: recursive top-down build; nodes with many primitives pick their plane by binning the
+// primitive bounds (64 bins per axis), small nodes (<= 48 prims) by an exact sweep over the sorted
+// bound edges.  Subtrees below a fan-out level are built by a small thread pool into private arrays
+// and spliced into depth-first order afterwards, so a 1 M-triangle tree does not serialise on one
+// host core the way the reference's does (6.1 s measured).
+#include "kdtree_build.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <thread>
+
+namespace yafgpu {
+namespace {
+
+struct Box { float lo[3], hi[3]; };
+
+struct Params
+{
+	const Box *prim_box;
+	int depth_cap;
+	float cost_ratio, empty_bonus;
+};
+
+struct Sub   // a subtree in private storage, indices relative to its own arrays
+{
+	std::vector<KdNode> nodes;
+	std::vector<uint32_t> refs;
+	int depth = 0;
+};
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+constexpr int kBins = 64;
+constexpr int kSweepMax = 48;
+
+struct Split { int axis = -1; float pos = 0.f; float cost = INFINITY; };
+
+inline float sah_cost(const Params &p, const float d[3], int axis, float l1, uint32_t nl, uint32_t nr, float inv_total_sa)
+{
+	const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+	const float cap = d[a1] * d[a2], rim = d[a1] + d[a2];
+	const float below = cap + l1 * rim, above = cap + (d[axis] - l1) * rim;
+	const float eb = (nl == 0 || nr == 0) ? p.empty_bonus : 0.f;
+	return p.cost_ratio + inv_total_sa * (below * (float)nl + above * (float)nr) * (1.f - eb);
+}
+
+Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, uint32_t np)
+{
+	Split best;
+	float d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
+	const float total_sa = d[0] * d[1] + d[0] * d[2] + d[1] * d[2];
+	if(!(total_sa > 0.f)) return best;
+	const float inv_total_sa = 1.f / total_sa;
+	for(int axis = 0; axis < 3; ++axis)
+	{
+		if(!(d[axis] > 0.f)) continue;
+		uint32_t starts[kBins + 1] = {0}, ends[kBins + 1] = {0};
+		const float scale = (float)kBins / d[axis], lo = box.lo[axis];
+		for(uint32_t i = 0; i < np; ++i)
+		{
+			const Box &b = p.prim_box[prims[i]];
+			int s = (int)std::floor((b.lo[axis] - lo) * scale);
+			int e = (int)std::ceil((b.hi[axis] - lo) * scale);
+			s = std::min(std::max(s, 0), kBins);
+			e = std::min(std::max(e, 0), kBins);
+			++starts[s]; ++ends[e];
+		}
+		uint32_t nl = 0, nr = np;
+		for(int k = 1; k < kBins; ++k)
+		{
+			nl += starts[k - 1];   // prims beginning before plane k
+			nr -= ends[k];         // prims ending at or before plane k no longer reach the right side
+			const float l1 = (float)k / scale;
+			const float c = sah_cost(p, d, axis, l1, nl, nr, inv_total_sa);
+			if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = lo + l1; }
+		}
+	}
+	return best;
+}
+
+Split find_split_sweep(const Params &p, const Box &box, const uint32_t *prims, uint32_t np)
+{
+	Split best;
+	float d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
+	const float total_sa = d[0] * d[1] + d[0] * d[2] + d[1] * d[2];
+	if(!(total_sa > 0.f)) return best;
+	const float inv_total_sa = 1.f / total_sa;
+	struct Edge { float pos; int is_end; };
+	Edge edges[2 * kSweepMax];
+	for(int axis = 0; axis < 3; ++axis)
+	{
+		if(!(d[axis] > 0.f)) continue;
+		for(uint32_t i = 0; i < np; ++i)
+		{
+			const Box &b = p.prim_box[prims[i]];
+			edges[2 * i] = {b.lo[axis], 0};
+			edges[2 * i + 1] = {b.hi[axis], 1};
+		}
+		// ends sort before starts at equal position so a plane through touching prims separates them
+		std::sort(edges, edges + 2 * np, [](const Edge &x, const Edge &y) { return x.pos == y.pos ? x.is_end > y.is_end : x.pos < y.pos; });
+		uint32_t nl = 0, nr = np;
+		for(uint32_t i = 0; i < 2 * np; ++i)
+		{
+			if(edges[i].is_end) --nr;
+			const float pos = edges[i].pos;
+			if(pos > box.lo[axis] && pos < box.hi[axis])
+			{
+				const float c = sah_cost(p, d, axis, pos - box.lo[axis], nl, nr, inv_total_sa);
+				if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = pos; }
+			}
+			if(!edges[i].is_end) ++nl;
+		}
+	}
+	return best;
+}
+
+void emit_leaf(Sub &s, const uint32_t *prims, uint32_t np, int depth)
+{
+	KdNode n;
+	n.a = (uint32_t)s.refs.size();
+	n.b = 3u | (np << 2);
+	s.nodes.push_back(n);
+	// ascending triangle index inside a leaf: the first-visited-wins tie rule of the traversal
+	// (kdtree_triangle.cc:782) then prefers the lower index, independent of build order
+	size_t at = s.refs.size();
+	s.refs.insert(s.refs.end(), prims, prims + np);
+	std::sort(s.refs.begin() + (long)at, s.refs.end());
+	s.depth = std::max(s.depth, depth);
+}
+
+// returns false when the node must become a leaf
+bool choose_and_partition(const Params &p, const Box &box, const std::vector<uint32_t> &prims, int depth, int &bad_refines,
+                          Split &sp, std::vector<uint32_t> &left, std::vector<uint32_t> &right)
+{
+	const uint32_t np = (uint32_t)prims.size();
+	if(np <= 1 || depth >= p.depth_cap) return false;
+	sp = (np <= (uint32_t)kSweepMax) ? find_split_sweep(p, box, prims.data(), np) : find_split_binned(p, box, prims.data(), np);
+	if(sp.axis < 0) return false;
+	const float leaf_cost = (float)np;
+	if(sp.cost > leaf_cost) ++bad_refines;
+	if((sp.cost > 1.6f * leaf_cost && np < 16) || bad_refines >= 2) return false;
+	left.clear(); right.clear();
+	for(uint32_t i = 0; i < np; ++i)
+	{
+		const Box &b = p.prim_box[prims[i]];
+		// conservative: a prim whose bounds touch the plane is referenced on both sides
+		if(b.lo[sp.axis] <= sp.pos) left.push_back(prims[i]);
+		if(b.hi[sp.axis] >= sp.pos) right.push_back(prims[i]);
+	}
+	if(left.size() == np && right.size() == np) return false;
+	return true;
+}
+
+void build_seq(const Params &p, Sub &s, const Box &box, std::vector<uint32_t> &prims, int depth, int bad_refines)
+{
+	Split sp;
+	std::vector<uint32_t> left, right;
+	if(!choose_and_partition(p, box, prims, depth, bad_refines, sp, left, right)) { emit_leaf(s, prims.data(), (uint32_t)prims.size(), depth); return; }
+	std::vector<uint32_t>().swap(prims); // release before recursing
+	const size_t me = s.nodes.size();
+	s.nodes.push_back({f2u(sp.pos), (uint32_t)sp.axis});
+	Box lb = box, rb = box;
+	lb.hi[sp.axis] = sp.pos; rb.lo[sp.axis] = sp.pos;
+	build_seq(p, s, lb, left, depth + 1, bad_refines);
+	s.nodes[me].b = (uint32_t)sp.axis | ((uint32_t)s.nodes.size() << 2);
+	build_seq(p, s, rb, right, depth + 1, bad_refines);
+}
+
+void splice(Sub &dst, const Sub &src)
+{
+	const uint32_t node_off = (uint32_t)dst.nodes.size(), ref_off = (uint32_t)dst.refs.size();
+	for(KdNode n : src.nodes)
+	{
+		if((n.b & 3u) == 3u) n.a += ref_off;
+		else n.b = (n.b & 3u) | (((n.b >> 2) + node_off) << 2);
+		dst.nodes.push_back(n);
+	}
+	dst.refs.insert(dst.refs.end(), src.refs.begin(), src.refs.end());
+	dst.depth = std::max(dst.depth, src.depth);
+}
+
+// top levels: fan out into futures until fan_depth, then sequential subtrees
+Sub build_par(const Params &p, const Box &box, std::vector<uint32_t> prims, int depth, int bad_refines, int fan_depth)
+{
+	Sub s;
+	if(depth >= fan_depth || prims.size() < 4096)
+	{
+		build_seq(p, s, box, prims, depth, bad_refines);
+		return s;
+	}
+	Split sp;
+	std::vector<uint32_t> left, right;
+	if(!choose_and_partition(p, box, prims, depth, bad_refines, sp, left, right)) { emit_leaf(s, prims.data(), (uint32_t)prims.size(), depth); return s; }
+	std::vector<uint32_t>().swap(prims);
+	Box lb = box, rb = box;
+	lb.hi[sp.axis] = sp.pos; rb.lo[sp.axis] = sp.pos;
+	auto fr = std::async(std::launch::async, [&p, rb, depth, bad_refines, fan_depth](std::vector<uint32_t> r) {
+		return build_par(p, rb, std::move(r), depth + 1, bad_refines, fan_depth);
+	}, std::move(right));
+	Sub ls = build_par(p, lb, std::move(left), depth + 1, bad_refines, fan_depth);
+	Sub rs = fr.get();
+	s.nodes.reserve(1 + ls.nodes.size() + rs.nodes.size());
+	s.refs.reserve(ls.refs.size() + rs.refs.size());
+	s.nodes.push_back({f2u(sp.pos), (uint32_t)sp.axis});
+	splice(s, ls);
+	s.nodes[0].b = (uint32_t)sp.axis | ((uint32_t)s.nodes.size() << 2);
+	splice(s, rs);
+	return s;
+}
+
+} // namespace
+
+void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, KdTree &out)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	out.nodes.clear(); out.refs.clear(); out.max_depth = 0;
+	for(int k = 0; k < 3; ++k) { out.bound_lo[k] = 0.f; out.bound_hi[k] = 0.f; }
+	if(n_tris <= 0) { out.build_seconds = 0; return; }
+	std::vector<Box> boxes((size_t)n_tris);
+	Box all;
+	for(int i = 0; i < n_tris; ++i)
+	{
+		const float *v = verts + 9 * (size_t)i;
+		Box &b = boxes[(size_t)i];
+		for(int k = 0; k < 3; ++k)
+		{
+			b.lo[k] = std::min(v[k], std::min(v[3 + k], v[6 + k]));
+			b.hi[k] = std::max(v[k], std::max(v[3 + k], v[6 + k]));
+		}
+		if(i == 0) all = b;
+		else for(int k = 0; k < 3; ++k) { all.lo[k] = std::min(all.lo[k], b.lo[k]); all.hi[k] = std::max(all.hi[k], b.hi[k]); }
+	}
+	// the reference grows its tree bound by 0.1 % per side (kdtree_triangle.cc:110-116); same here so
+	// that rays clipped against it enter and leave at the same distances
+	for(int k = 0; k < 3; ++k)
+	{
+		const double grow = (double)(all.hi[k] - all.lo[k]) * 0.001;
+		all.lo[k] = (float)((double)all.lo[k] - grow);
+		all.hi[k] = (float)((double)all.hi[k] + grow);
+	}
+	Params p;
+	p.prim_box = boxes.data();
+	int md = (int)(7.0f + 1.66f * std::log((float)n_tris)); // kdtree_triangle.cc:89
+	p.depth_cap = std::min(md, depth_cap);
+	p.cost_ratio = 0.8f; p.empty_bonus = 0.33f;             // scene.cc:818
+	const double log_leaves = 1.442695f * std::log((double)n_tris); // kdtree_triangle.cc:90,100
+	if(log_leaves > 16.0) p.cost_ratio += (float)(0.25 * (log_leaves - 16.0));
+	if(threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+	int fan_depth = 0;
+	while((1 << fan_depth) < 2 * threads && fan_depth < 8) ++fan_depth;
+	if(threads == 1) fan_depth = 0;
+	std::vector<uint32_t> prims((size_t)n_tris);
+	for(int i = 0; i < n_tris; ++i) prims[(size_t)i] = (uint32_t)i;
+	Sub root = build_par(p, all, std::move(prims), 0, 0, fan_depth);
+	out.nodes = std::move(root.nodes);
+	out.refs = std::move(root.refs);
+	out.max_depth = root.depth;
+	for(int k = 0; k < 3; ++k) { out.bound_lo[k] = all.lo[k]; out.bound_hi[k] = all.hi[k]; }
+	out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace yafgpu

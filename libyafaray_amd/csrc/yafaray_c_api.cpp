@@ -1,0 +1,720 @@
+// The Interface-shaped C ABI (include/yafaray_c_api.h) over the MI355X path-tracing core.
+//
+// Host-side mirror of the reference's control path for ONE render: ParamMap building
+// (src/interface/interface.cc:221-310), the type-string factories of RenderEnvironment
+// (src/common/environment.cc:367-454 -> Material::factory etc.), the Scene geometry state machine
+// (src/common/scene.cc:110-131,283-338), RenderEnvironment::setupScene (environment.cc:679-813)
+// and Scene::update (scene.cc:784-894).  Everything per-sample happens on the device (yafgpu.h).
+#include "../../include/yafaray_c_api.h"
+#include "../../include/yafgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- ParamMap (include/common/param.h:37-107): strictly typed values, as Parameter::getVal (param.cc:49-53)
+struct Param
+{
+	enum Type { None, Int, Bool, Float, String, Point, Color } type = None;
+	int i = 0; bool b = false; double f = 0; std::string s; float v[4] = {0, 0, 0, 0};
+};
+struct ParamMap
+{
+	std::map<std::string, Param> dicc;
+	bool get(const std::string &n, int &o) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Int) return false; o = it->second.i; return true; }
+	bool get(const std::string &n, bool &o) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Bool) return false; o = it->second.b; return true; }
+	bool get(const std::string &n, float &o) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Float) return false; o = (float)it->second.f; return true; }
+	bool get(const std::string &n, double &o) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Float) return false; o = it->second.f; return true; }
+	bool get(const std::string &n, std::string &o) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::String) return false; o = it->second.s; return true; }
+	bool getPoint(const std::string &n, float o[3]) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Point) return false; o[0] = it->second.v[0]; o[1] = it->second.v[1]; o[2] = it->second.v[2]; return true; }
+	bool getColor(const std::string &n, float o[3]) const { auto it = dicc.find(n); if(it == dicc.end() || it->second.type != Param::Color) return false; o[0] = it->second.v[0]; o[1] = it->second.v[1]; o[2] = it->second.v[2]; return true; }
+};
+
+struct Mesh
+{
+	std::vector<float> points;        // xyz
+	std::vector<float> normals;       // xyz per vertex (addNormal) or empty
+	std::vector<int> tri;             // a,b,c
+	std::vector<int> tri_mat;
+	bool normals_exported = false, smooth = false, visible = true, base = false;
+	std::vector<float> smooth_normals; // per triangle corner, filled by smoothMesh
+};
+
+struct IntegratorCfg
+{
+	std::string type;
+	int path_samples = 32, bounces = 3, rr_min_bounces = 0, raydepth = 5;
+	bool no_recursive = false, bg_transp = false, bg_transp_refract = false;
+};
+
+struct CameraCfg { yafgpu_camera cam; };
+struct BackgroundCfg { float color[3]; };
+
+} // namespace
+
+struct yafaray_material { yafgpu_material m; int index; };
+struct yafaray_light { yafgpu_light l; };
+struct yafaray_camera { CameraCfg c; };
+struct yafaray_background { BackgroundCfg b; };
+struct yafaray_integrator { IntegratorCfg c; };
+
+struct yafaray_interface
+{
+	std::string err;
+	ParamMap params;
+	std::list<ParamMap> eparams;
+	ParamMap *cparams = &params;
+	// registries, name -> object (environment.h:85-95)
+	std::map<std::string, std::unique_ptr<yafaray_material>> materials;
+	std::vector<yafaray_material *> material_order;
+	std::map<std::string, std::unique_ptr<yafaray_light>> lights;
+	std::vector<yafaray_light *> light_order;
+	std::map<std::string, std::unique_ptr<yafaray_camera>> cameras;
+	std::map<std::string, std::unique_ptr<yafaray_background>> backgrounds;
+	std::map<std::string, std::unique_ptr<yafaray_integrator>> integrators;
+	// scene state (scene.cc:110-131): 0 ready, 1 geometry, 2 object
+	int state = -1;
+	std::map<unsigned int, Mesh> meshes;
+	Mesh *cur = nullptr;
+	unsigned int next_id = 1;
+	bool geometry_changed = true;
+	// render
+	yafgpu_scene_t *gpu = nullptr;
+	yafgpu_render_params rp{};
+	bool prepared = false;
+	int shard_index = 0, shard_count = 1;
+	std::vector<float> film;
+	yafaray_render_stats_t stats{};
+	volatile bool abort_flag = false;
+	std::string color_space = "Raw_Manual_Gamma"; float gamma = 1.f;
+};
+
+namespace {
+
+bool fail(yafaray_interface *yi, const std::string &m) { yi->err = m; return false; }
+
+inline void cross3(const float a[3], const float b[3], float o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+inline void normalize3(float v[3]) // Vec3::normalize, vector.h:227-238
+{
+	float len = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+	if(len != 0.f) { len = 1.0f / std::sqrt(len); v[0] *= len; v[1] *= len; v[2] *= len; }
+}
+
+int visibility_from(const std::string &s)
+{
+	if(s == "no_shadows") return 1;
+	if(s == "shadow_only") return 2;
+	if(s == "invisible") return 3;
+	return 0;
+}
+
+// ShinyDiffuseMaterial::factory + ctor + config, material_shiny_diffuse.cc:599-690, :26-36, :46-92
+bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+{
+	float color[3] = {1, 1, 1}, mirror_color[3] = {1, 1, 1};
+	float diffuse = 1.f, transp = 0.f, transl = 0.f, mirror = 0.f, emit = 0.f, ior = 1.33f, wire = 0.f;
+	bool fresnel = false, recv = true, flat = false;
+	double transmit_filter = 1.0;
+	std::string vis = "normal", brdf;
+	p.getColor("color", color); p.getColor("mirror_color", mirror_color);
+	p.get("transparency", transp); p.get("translucency", transl); p.get("diffuse_reflect", diffuse);
+	p.get("specular_reflect", mirror); p.get("emit", emit); p.get("IOR", ior); p.get("fresnel_effect", fresnel);
+	p.get("transmit_filter", transmit_filter); p.get("receive_shadows", recv); p.get("flat_material", flat);
+	p.get("visibility", vis); p.get("wireframe_amount", wire);
+	if(wire != 0.f) return fail(yi, "shinydiffusemat: wireframe shading is not supported by the GPU path");
+	if(!yi->eparams.empty()) return fail(yi, "shinydiffusemat: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_SHINYDIFFUSE; m.visibility = visibility_from(vis); m.receive_shadows = recv; m.flat = flat;
+	for(int k = 0; k < 3; ++k) { m.diffuse_color[k] = color[k]; m.mirror_color[k] = mirror_color[k]; m.emit_color[k] = emit * color[k]; }
+	m.diffuse_strength = diffuse; m.transparency_strength = transp; m.translucency_strength = transl; m.mirror_strength = mirror;
+	m.transmit_filter = (float)transmit_filter;
+	m.bsdf_flags = 0u;
+	if(emit > 0.f) m.bsdf_flags |= 0x80u;
+	m.ior_squared = 1.f;
+	if(fresnel) { m.ior_squared = ior * ior; m.has_fresnel = 1; }
+	if(p.get("diffuse_brdf", brdf) && brdf == "oren_nayar")
+	{	// initOrenNayar :190-196
+		double sigma = 0.1; p.get("sigma", sigma);
+		const double s2 = sigma * sigma;
+		m.oren_a = (float)(1.0 - 0.5 * (s2 / (s2 + 0.33)));
+		m.oren_b = (float)(0.45 * s2 / (s2 + 0.09));
+		m.use_oren = 1;
+	}
+	float acc = 1.f;
+	m.n_bsdf = 0;
+	if(m.mirror_strength > 0.00001f)
+	{
+		m.is_mirror = 1;
+		if(!m.has_fresnel) acc = 1.f - m.mirror_strength;
+		m.bsdf_flags |= 0x1u | 0x10u;
+		m.c_flags[m.n_bsdf] = 0x1u | 0x10u; m.c_index[m.n_bsdf] = 0; ++m.n_bsdf;
+	}
+	if(m.transparency_strength * acc > 0.00001f)
+	{
+		m.is_transparent = 1;
+		acc *= 1.f - m.transparency_strength;
+		m.bsdf_flags |= 0x20u | 0x40u;
+		m.c_flags[m.n_bsdf] = 0x20u | 0x40u; m.c_index[m.n_bsdf] = 1; ++m.n_bsdf;
+	}
+	if(m.translucency_strength * acc > 0.00001f)
+	{
+		m.is_translucent = 1;
+		acc *= 1.f - m.transparency_strength; // sic, material_shiny_diffuse.cc:72
+		m.bsdf_flags |= 0x4u | 0x20u;
+		m.c_flags[m.n_bsdf] = 0x4u | 0x20u; m.c_index[m.n_bsdf] = 2; ++m.n_bsdf;
+	}
+	if(m.diffuse_strength * acc > 0.00001f)
+	{
+		m.is_diffuse = 1;
+		m.bsdf_flags |= 0x4u | 0x10u;
+		m.c_flags[m.n_bsdf] = 0x4u | 0x10u; m.c_index[m.n_bsdf] = 3; ++m.n_bsdf;
+	}
+	return true;
+}
+
+// GlossyMaterial::factory + ctor, material_glossy.cc:407-472, :32-50
+bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+{
+	float col[3] = {1, 1, 1}, dcol[3] = {1, 1, 1};
+	float refl = 1.f, diff = 0.f, exponent = 50.f, wire = 0.f;
+	bool as_diff = true, aniso = false, recv = true;
+	std::string vis = "normal", brdf;
+	p.getColor("color", col); p.getColor("diffuse_color", dcol); p.get("diffuse_reflect", diff); p.get("glossy_reflect", refl);
+	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso);
+	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
+	if(aniso) return fail(yi, "glossy: the anisotropic (Ashikhmin-Shirley) lobe is not supported by the GPU path");
+	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
+	if(!yi->eparams.empty()) return fail(yi, "glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
+	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; }
+	m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
+	m.bsdf_flags = 0u;
+	if(diff > 0) { m.bsdf_flags = 0x4u | 0x10u; m.with_diffuse = 1; }
+	m.bsdf_flags |= as_diff ? (0x4u | 0x10u) : (0x2u | 0x10u);
+	if(p.get("diffuse_brdf", brdf) && brdf == "Oren-Nayar")
+	{	// :66-72
+		double sigma = 0.1; p.get("sigma", sigma);
+		const double s2 = sigma * sigma;
+		m.oren_a = (float)(1.0 - 0.5 * (s2 / (s2 + 0.33)));
+		m.oren_b = (float)(0.45 * s2 / (s2 + 0.09));
+		m.use_oren = 1;
+	}
+	return true;
+}
+
+// LightMaterial::factory, material_simple.cc:63-73
+bool make_lightmat(const ParamMap &p, yafgpu_material &m)
+{
+	float col[3] = {1, 1, 1}; double power = 1.0; bool ds = false;
+	p.getColor("color", col); p.get("power", power); p.get("double_sided", ds);
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_LIGHT; m.receive_shadows = 1;
+	for(int k = 0; k < 3; ++k) m.light_col[k] = (float)power * col[k];
+	m.double_sided = ds;
+	m.bsdf_flags = 0x80u;
+	return true;
+}
+
+// AreaLight::factory + ctor, light_area.cc:169-205, :34-52
+bool make_arealight(const ParamMap &p, yafgpu_light &l)
+{
+	float corner[3] = {0, 0, 0}, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0}, color[3] = {1, 1, 1};
+	float power = 1.f; int samples = 4; bool enabled = true, cast = true;
+	p.getPoint("corner", corner); p.getPoint("point1", p1); p.getPoint("point2", p2); p.getColor("color", color);
+	p.get("power", power); p.get("samples", samples); p.get("light_enabled", enabled); p.get("cast_shadows", cast);
+	std::memset(&l, 0, sizeof l);
+	l.type = YAFGPU_LIGHT_AREA; l.samples = samples; l.cast_shadows = cast;
+	float tx[3], ty[3];
+	for(int k = 0; k < 3; ++k) { l.corner[k] = corner[k]; tx[k] = p1[k] - corner[k]; ty[k] = p2[k] - corner[k]; l.to_x[k] = tx[k]; l.to_y[k] = ty[k]; }
+	float fn[3]; cross3(ty, tx, fn);
+	for(int k = 0; k < 3; ++k) l.color[k] = (power * color[k]) * (float)kPi;   // col * inte * M_PI
+	float vl = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];                 // normLen, vector.h:61-71
+	if(vl != 0.f) { vl = std::sqrt(vl); const float d = (float)(1.0 / (double)vl); fn[0] *= d; fn[1] *= d; fn[2] *= d; }
+	l.area = vl;
+	for(int k = 0; k < 3; ++k)
+	{
+		l.fnormal[k] = fn[k];
+		l.c2[k] = corner[k] + tx[k];
+		l.c3[k] = corner[k] + (tx[k] + ty[k]);
+		l.c4[k] = corner[k] + ty[k];
+	}
+	return enabled;
+}
+// PointLight::factory + ctor, light_point.cc:97-120, :28-36
+bool make_pointlight(const ParamMap &p, yafgpu_light &l)
+{
+	float from[3] = {0, 0, 0}, color[3] = {1, 1, 1}; float power = 1.f; bool enabled = true, cast = true;
+	p.getPoint("from", from); p.getColor("color", color); p.get("power", power); p.get("light_enabled", enabled); p.get("cast_shadows", cast);
+	std::memset(&l, 0, sizeof l);
+	l.type = YAFGPU_LIGHT_POINT; l.samples = 1; l.cast_shadows = cast;
+	for(int k = 0; k < 3; ++k) { l.position[k] = from[k]; l.color[k] = power * color[k]; }
+	return enabled;
+}
+
+// PerspectiveCamera::factory, Camera::Camera, setAxis — camera_perspective.cc:198-243, camera.cc:46-66, :60-74
+bool make_camera(yafaray_interface *yi, const ParamMap &p, yafgpu_camera &c)
+{
+	float from[3] = {0, 1, 0}, to[3] = {0, 0, 0}, up[3] = {0, 1, 1};
+	int resx = 320, resy = 200; float aspect = 1, dfocal = 1, apt = 0, near_clip = 0.f, far_clip = -1.f;
+	p.getPoint("from", from); p.getPoint("to", to); p.getPoint("up", up); p.get("resx", resx); p.get("resy", resy);
+	p.get("focal", dfocal); p.get("aperture", apt); p.get("aspect_ratio", aspect); p.get("nearClip", near_clip); p.get("farClip", far_clip);
+	if(apt != 0.f) return fail(yi, "perspective camera: depth of field (aperture != 0) is not supported by the GPU path");
+	const float aspect_ratio = aspect * (float)resy / (float)resx;
+	float cy[3], cz[3], cx[3];
+	for(int k = 0; k < 3; ++k) { cy[k] = up[k] - from[k]; cz[k] = to[k] - from[k]; }
+	cross3(cz, cy, cx);
+	cross3(cz, cx, cy);
+	normalize3(cx); normalize3(cy); normalize3(cz);
+	std::memset(&c, 0, sizeof c);
+	c.resx = resx; c.resy = resy;
+	for(int k = 0; k < 3; ++k)
+	{
+		c.position[k] = from[k];
+		c.near_n[k] = cz[k]; c.near_p[k] = from[k] + near_clip * cz[k];
+		c.far_n[k] = cz[k]; c.far_p[k] = from[k] + far_clip * cz[k];
+		const float vright = cx[k], vup = aspect_ratio * cy[k];
+		c.vto[k] = (dfocal * cz[k]) - 0.5f * (vup + vright);
+		c.vup[k] = vup / (float)resy;
+		c.vright[k] = vright / (float)resx;
+	}
+	return true;
+}
+
+void set_param(yafaray_interface *yi, const char *name, const Param &v) { if(name) yi->cparams->dicc[name] = v; }
+
+} // namespace
+
+extern "C" {
+
+yafaray_interface_t *yafaray_createInterface(void) { return new yafaray_interface(); }
+void yafaray_destroyInterface(yafaray_interface_t *yi)
+{
+	if(!yi) return;
+	if(yi->gpu) yafgpu_scene_destroy(yi->gpu);
+	delete yi;
+}
+const char *yafaray_getLastError(const yafaray_interface_t *yi) { return yi ? yi->err.c_str() : "null interface"; }
+const char *yafaray_getVersion(void) { return "yafgpu-0.1 (MI355X path-tracing core behind the libYafaRay v3 Interface API)"; }
+
+yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type)
+{
+	if(type != 0) return fail(yi, "startScene: only scene type 0 (\"triangle\") is supported (import_xml.cc:339-347)");
+	yi->state = 0; yi->meshes.clear(); yi->cur = nullptr; yi->geometry_changed = true; yi->prepared = false;
+	return 1;
+}
+yafaray_bool_t yafaray_startGeometry(yafaray_interface_t *yi) { if(yi->state != 0) return fail(yi, "startGeometry: wrong state"); yi->state = 1; return 1; }
+yafaray_bool_t yafaray_endGeometry(yafaray_interface_t *yi) { if(yi->state != 1) return fail(yi, "endGeometry: wrong state"); yi->state = 0; return 1; }
+unsigned int yafaray_getNextFreeId(yafaray_interface_t *yi) { while(yi->meshes.count(yi->next_id)) ++yi->next_id; return yi->next_id++; }
+
+yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, int vertices, int triangles, yafaray_bool_t has_orco, yafaray_bool_t has_uv, int type, int)
+{
+	if(yi->state != 1) return fail(yi, "startTriMesh: wrong state");
+	if((type & 0xFF) != 0) return fail(yi, "startTriMesh: only TRIM meshes (type 0) are supported");
+	if(has_orco) return fail(yi, "startTriMesh: orco coordinates are not supported");
+	(void)has_uv; // UVs are accepted and ignored: no textures on the GPU path
+	Mesh &m = yi->meshes[id];
+	m = Mesh();
+	m.visible = !(type & 0x0100); m.base = (type & 0x0200) != 0;
+	m.points.reserve((size_t)std::max(vertices, 0) * 3); m.tri.reserve((size_t)std::max(triangles, 0) * 3); m.tri_mat.reserve((size_t)std::max(triangles, 0));
+	yi->cur = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
+	return 1;
+}
+yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi) { if(yi->state != 2) return fail(yi, "endTriMesh: wrong state"); yi->state = 1; yi->cur = nullptr; return 1; }
+int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z)
+{
+	if(yi->state != 2) { fail(yi, "addVertex: wrong state"); return -1; }
+	Mesh &m = *yi->cur;
+	m.points.push_back((float)x); m.points.push_back((float)y); m.points.push_back((float)z);
+	return (int)(m.points.size() / 3) - 1;
+}
+void yafaray_addNormal(yafaray_interface_t *yi, double nx, double ny, double nz)
+{	// Scene::addNormal, scene.cc:380-400: attaches to the last vertex
+	if(yi->state != 2) { fail(yi, "addNormal: wrong state"); return; }
+	Mesh &m = *yi->cur;
+	const size_t nv = m.points.size() / 3;
+	if(nv == 0) return;
+	if(m.normals.size() < nv * 3) m.normals.resize(nv * 3, 0.f);
+	m.normals[(nv - 1) * 3] = (float)nx; m.normals[(nv - 1) * 3 + 1] = (float)ny; m.normals[(nv - 1) * 3 + 2] = (float)nz;
+	m.normals_exported = true;
+}
+yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c, const yafaray_material_t *mat)
+{
+	if(yi->state != 2) return fail(yi, "addTriangle: wrong state");
+	if(!mat) return fail(yi, "addTriangle: null material");
+	Mesh &m = *yi->cur;
+	const int nv = (int)(m.points.size() / 3);
+	if(a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) return fail(yi, "addTriangle: vertex index out of range");
+	m.tri.push_back(a); m.tri.push_back(b); m.tri.push_back(c); m.tri_mat.push_back(mat->index);
+	return 1;
+}
+yafaray_bool_t yafaray_addTriangles(yafaray_interface_t *yi, int n_verts, const float *verts, int n_tris, const int *indices, const yafaray_material_t *mat)
+{
+	if(yi->state != 2) return fail(yi, "addTriangles: wrong state");
+	if(!mat || !verts || !indices || n_verts < 0 || n_tris < 0) return fail(yi, "addTriangles: bad argument");
+	Mesh &m = *yi->cur;
+	const int base = (int)(m.points.size() / 3);
+	m.points.insert(m.points.end(), verts, verts + (size_t)n_verts * 3);
+	for(int i = 0; i < n_tris * 3; ++i)
+	{
+		if(indices[i] < 0 || indices[i] >= n_verts) return fail(yi, "addTriangles: vertex index out of range");
+		m.tri.push_back(base + indices[i]);
+	}
+	m.tri_mat.insert(m.tri_mat.end(), (size_t)n_tris, mat->index);
+	return 1;
+}
+yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle)
+{
+	(void)id; (void)angle;
+	return fail(yi, "smoothMesh: angle-based normal smoothing is not implemented; export vertex normals with addNormal");
+}
+
+void yafaray_paramsSetPoint(yafaray_interface_t *yi, const char *name, double x, double y, double z) { Param p; p.type = Param::Point; p.v[0] = (float)x; p.v[1] = (float)y; p.v[2] = (float)z; set_param(yi, name, p); }
+void yafaray_paramsSetString(yafaray_interface_t *yi, const char *name, const char *s) { Param p; p.type = Param::String; p.s = s ? s : ""; set_param(yi, name, p); }
+void yafaray_paramsSetBool(yafaray_interface_t *yi, const char *name, yafaray_bool_t b) { Param p; p.type = Param::Bool; p.b = b != 0; set_param(yi, name, p); }
+void yafaray_paramsSetInt(yafaray_interface_t *yi, const char *name, int i) { Param p; p.type = Param::Int; p.i = i; set_param(yi, name, p); }
+void yafaray_paramsSetFloat(yafaray_interface_t *yi, const char *name, double f) { Param p; p.type = Param::Float; p.f = f; set_param(yi, name, p); }
+void yafaray_paramsSetColor(yafaray_interface_t *yi, const char *name, float r, float g, float b, float a)
+{	// interface.cc:247-252; the default input colour space (RawManualGamma, gamma 1) leaves values unchanged
+	Param p; p.type = Param::Color; p.v[0] = r; p.v[1] = g; p.v[2] = b; p.v[3] = a; set_param(yi, name, p);
+}
+void yafaray_paramsClearAll(yafaray_interface_t *yi) { yi->params.dicc.clear(); yi->eparams.clear(); yi->cparams = &yi->params; }
+void yafaray_paramsStartList(yafaray_interface_t *yi) { yi->eparams.emplace_back(); yi->cparams = &yi->eparams.back(); }
+void yafaray_paramsPushList(yafaray_interface_t *yi) { yi->eparams.emplace_back(); yi->cparams = &yi->eparams.back(); }
+void yafaray_paramsEndList(yafaray_interface_t *yi) { yi->cparams = &yi->params; }
+
+yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *name)
+{
+	std::string type;
+	if(!name) { fail(yi, "createMaterial: null name"); return nullptr; }
+	if(yi->materials.count(name)) { fail(yi, std::string("createMaterial: \"") + name + "\" already defined"); return nullptr; }
+	if(!yi->params.get("type", type)) { fail(yi, "createMaterial: type of material not specified"); return nullptr; }
+	auto m = std::make_unique<yafaray_material>();
+	bool ok;
+	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m);
+	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m);
+	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
+	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, light_mat)"); return nullptr; }
+	if(!ok) return nullptr;
+	m->index = (int)yi->material_order.size();
+	yafaray_material *raw = m.get();
+	yi->material_order.push_back(raw);
+	yi->materials[name] = std::move(m);
+	yi->prepared = false;
+	return raw;
+}
+yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name)
+{
+	std::string type;
+	if(!name) { fail(yi, "createLight: null name"); return nullptr; }
+	if(yi->lights.count(name)) { fail(yi, std::string("createLight: \"") + name + "\" already defined"); return nullptr; }
+	if(!yi->params.get("type", type)) { fail(yi, "createLight: type of light not specified"); return nullptr; }
+	auto l = std::make_unique<yafaray_light>();
+	bool enabled;
+	if(type == "arealight") enabled = make_arealight(yi->params, l->l);
+	else if(type == "pointlight") enabled = make_pointlight(yi->params, l->l);
+	else { fail(yi, "createLight: light type \"" + type + "\" is outside the GPU path's scope (arealight, pointlight)"); return nullptr; }
+	yafaray_light *raw = l.get();
+	if(enabled) yi->light_order.push_back(raw);   // Scene::addLight only sees enabled lights (environment.cc:230-233)
+	yi->lights[name] = std::move(l);
+	yi->prepared = false;
+	return raw;
+}
+yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name)
+{
+	std::string type;
+	if(!name) { fail(yi, "createCamera: null name"); return nullptr; }
+	if(!yi->params.get("type", type)) { fail(yi, "createCamera: type of camera not specified"); return nullptr; }
+	if(type != "perspective") { fail(yi, "createCamera: camera type \"" + type + "\" is outside the GPU path's scope (perspective)"); return nullptr; }
+	auto c = std::make_unique<yafaray_camera>();
+	if(!make_camera(yi, yi->params, c->c.cam)) return nullptr;
+	yafaray_camera *raw = c.get();
+	yi->cameras[name] = std::move(c);
+	yi->prepared = false;
+	return raw;
+}
+yafaray_background_t *yafaray_createBackground(yafaray_interface_t *yi, const char *name)
+{
+	std::string type;
+	if(!name) { fail(yi, "createBackground: null name"); return nullptr; }
+	if(!yi->params.get("type", type)) { fail(yi, "createBackground: type of background not specified"); return nullptr; }
+	if(type != "constant") { fail(yi, "createBackground: background type \"" + type + "\" is outside the GPU path's scope (constant)"); return nullptr; }
+	bool ibl = false; yi->params.get("ibl", ibl);
+	if(ibl) { fail(yi, "createBackground: image-based lighting (ibl) is not supported by the GPU path"); return nullptr; }
+	float col[3] = {0, 0, 0}; float power = 1.f;
+	yi->params.getColor("color", col); yi->params.get("power", power);   // background_constant.cc:49-66
+	auto b = std::make_unique<yafaray_background>();
+	for(int k = 0; k < 3; ++k) b->b.color[k] = power * col[k];
+	yafaray_background *raw = b.get();
+	yi->backgrounds[name] = std::move(b);
+	yi->prepared = false;
+	return raw;
+}
+yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const char *name)
+{
+	std::string type;
+	if(!name) { fail(yi, "createIntegrator: null name"); return nullptr; }
+	if(!yi->params.get("type", type)) { fail(yi, "createIntegrator: type of integrator not specified"); return nullptr; }
+	auto it = std::make_unique<yafaray_integrator>();
+	IntegratorCfg &c = it->c;
+	c.type = type;
+	const ParamMap &p = yi->params;
+	if(type == "pathtracing" || type == "directlighting")
+	{
+		bool transp_shad = false, do_ao = false, caustics = false;
+		std::string c_method;
+		p.get("raydepth", c.raydepth); p.get("transpShad", transp_shad); p.get("do_AO", do_ao);
+		p.get("bg_transp", c.bg_transp); p.get("bg_transp_refract", c.bg_transp_refract);
+		if(transp_shad) { fail(yi, "createIntegrator: transparent shadows (transpShad) are not supported by the GPU path"); return nullptr; }
+		if(do_ao) { fail(yi, "createIntegrator: ambient occlusion is not supported by the GPU path"); return nullptr; }
+		if(type == "pathtracing")
+		{	// PathIntegrator::factory, integrator_path_tracer.cc:349-422
+			p.get("path_samples", c.path_samples); p.get("bounces", c.bounces);
+			p.get("russian_roulette_min_bounces", c.rr_min_bounces); p.get("no_recursive", c.no_recursive);
+			if(p.get("caustic_type", c_method) && (c_method == "photon" || c_method == "both"))
+			{ fail(yi, "createIntegrator: photon caustics are not supported by the GPU path (use caustic_type=none)"); return nullptr; }
+		}
+		else
+		{
+			p.get("caustics", caustics);
+			if(caustics) { fail(yi, "createIntegrator: photon caustics are not supported by the GPU path"); return nullptr; }
+		}
+	}
+	else if(type != "none")
+	{
+		fail(yi, "createIntegrator: integrator type \"" + type + "\" is outside the GPU path's scope (pathtracing, directlighting, none)");
+		return nullptr;
+	}
+	yafaray_integrator *raw = it.get();
+	yi->integrators[name] = std::move(it);
+	yi->prepared = false;
+	return raw;
+}
+
+void yafaray_clearAll(yafaray_interface_t *yi)
+{
+	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
+	yi->materials.clear(); yi->material_order.clear(); yi->lights.clear(); yi->light_order.clear();
+	yi->cameras.clear(); yi->backgrounds.clear(); yi->integrators.clear(); yi->meshes.clear();
+	yi->params.dicc.clear(); yi->eparams.clear(); yi->cparams = &yi->params;
+	yi->state = -1; yi->prepared = false; yi->geometry_changed = true; yi->film.clear();
+}
+
+void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count) { yi->shard_index = shard_index; yi->shard_count = std::max(1, shard_count); }
+
+// RenderEnvironment::setupScene (environment.cc:679-813) + createImageFilm (:456-584) + Scene::update (scene.cc:784-894)
+yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
+{
+	const ParamMap &p = yi->params;
+	std::string name;
+	if(!p.get("camera_name", name)) return fail(yi, "Specify a Camera!!");
+	auto cam = yi->cameras.find(name);
+	if(cam == yi->cameras.end()) return fail(yi, "Specify an _existing_ Camera!!");
+	if(!p.get("integrator_name", name)) return fail(yi, "Specify an Integrator!!");
+	auto inte = yi->integrators.find(name);
+	if(inte == yi->integrators.end()) return fail(yi, "Specify an _existing_ Integrator!!");
+	if(inte->second->c.type == "none") return fail(yi, "Integrator is no surface integrator!");
+	if(!p.get("volintegrator_name", name)) return fail(yi, "Specify a Volume Integrator!");
+	auto vol = yi->integrators.find(name);
+	if(vol == yi->integrators.end() || vol->second->c.type != "none") return fail(yi, "volume integrators other than type \"none\" are not supported by the GPU path");
+	const BackgroundCfg *bg = nullptr;
+	if(p.get("background_name", name))
+	{
+		auto b = yi->backgrounds.find(name);
+		if(b == yi->backgrounds.end()) return fail(yi, "please specify an _existing_ Background!!");
+		bg = &b->second->b;
+	}
+	int aa_passes = 1, aa_samples = 1, tile_size = 32, width = 320, height = 240, xstart = 0, ystart = 0;
+	int base_offset = 0, node = 0;
+	float filt_sz = 1.5f, shadow_bias = (float)0.0005, min_raydist = (float)0.00005, clamp_samples = 0.f, clamp_indirect = 0.f;
+	bool auto_bias = true, auto_dist = true, premult = false;
+	std::string filter = "box";
+	p.get("AA_passes", aa_passes); p.get("AA_minsamples", aa_samples); p.get("AA_pixelwidth", filt_sz);
+	p.get("width", width); p.get("height", height); p.get("xstart", xstart); p.get("ystart", ystart);
+	p.get("filter_type", filter); p.get("tile_size", tile_size); p.get("premult", premult);
+	p.get("AA_clamp_samples", clamp_samples); p.get("AA_clamp_indirect", clamp_indirect);
+	p.get("adv_auto_shadow_bias_enabled", auto_bias); p.get("adv_shadow_bias_value", shadow_bias);
+	p.get("adv_auto_min_raydist_enabled", auto_dist); p.get("adv_min_raydist_value", min_raydist);
+	p.get("adv_base_sampling_offset", base_offset); p.get("adv_computer_node", node);
+	p.get("color_space", yi->color_space); p.get("gamma", yi->gamma);
+	if(aa_passes != 1) return fail(yi, "render: adaptive multi-pass AA (AA_passes > 1) is not supported by the GPU path (SURVEY row N4)");
+	if(filter != "box" && !filter.empty()) return fail(yi, "render: filter_type \"" + filter + "\" is not supported by the GPU path (box with AA_pixelwidth <= 1.002 only)");
+	if(premult) return fail(yi, "render: premultiplied alpha is not supported by the GPU path");
+	if(clamp_samples != 0.f || clamp_indirect != 0.f) return fail(yi, "render: AA_clamp_samples / AA_clamp_indirect are not supported by the GPU path");
+	const IntegratorCfg &ic = inte->second->c;
+	yafgpu_render_params &rp = yi->rp;
+	std::memset(&rp, 0, sizeof rp);
+	rp.integrator = ic.type == "pathtracing" ? YAFGPU_INTEGRATOR_PATH : YAFGPU_INTEGRATOR_DIRECT;
+	rp.path_samples = ic.path_samples; rp.bounces = ic.bounces; rp.rr_min_bounces = ic.rr_min_bounces;
+	rp.no_recursive = ic.no_recursive; rp.bg_transp = ic.bg_transp; rp.bg_transp_refract = ic.bg_transp_refract;
+	rp.width = width; rp.height = height; rp.xstart = xstart; rp.ystart = ystart;
+	rp.aa_minsamples = aa_samples; rp.aa_pixelwidth = filt_sz; rp.tile_size = tile_size;
+	rp.base_sampling_offset = (uint32_t)base_offset + (uint32_t)node * 100000u;   // imagefilm.h:124
+	rp.shadow_bias_auto = auto_bias; rp.shadow_bias = shadow_bias; rp.min_raydist_auto = auto_dist; rp.min_raydist = min_raydist;
+	rp.aa_light_sample_multiplier = 1.f;
+	if(bg) { rp.has_background = 1; for(int k = 0; k < 3; ++k) rp.background[k] = bg->color[k]; }
+	rp.shard_index = yi->shard_index; rp.shard_count = yi->shard_count;
+
+	// Scene::update: flatten visible non-base meshes in object-id order (scene.cc:797-817)
+	if(yi->state != 0) return fail(yi, "render: scene is not in the ready state (missing endGeometry?)");
+	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
+	std::vector<float> verts; std::vector<int32_t> tri_mat; std::vector<float> vnormals; bool any_normals = false;
+	for(auto &kv : yi->meshes) if(kv.second.normals_exported) any_normals = true;
+	for(auto &kv : yi->meshes)
+	{
+		const Mesh &m = kv.second;
+		if(!m.visible || m.base) continue;
+		const size_t nt = m.tri_mat.size();
+		for(size_t t = 0; t < nt; ++t)
+		{
+			for(int c = 0; c < 3; ++c)
+			{
+				const int vi = m.tri[3 * t + (size_t)c];
+				verts.push_back(m.points[3 * (size_t)vi]); verts.push_back(m.points[3 * (size_t)vi + 1]); verts.push_back(m.points[3 * (size_t)vi + 2]);
+				if(any_normals)
+				{
+					if(m.normals_exported && m.normals.size() >= 3 * ((size_t)vi + 1))
+					{ vnormals.push_back(m.normals[3 * (size_t)vi]); vnormals.push_back(m.normals[3 * (size_t)vi + 1]); vnormals.push_back(m.normals[3 * (size_t)vi + 2]); }
+					else { vnormals.push_back(0.f); vnormals.push_back(0.f); vnormals.push_back(0.f); }
+				}
+			}
+			tri_mat.push_back(m.tri_mat[t]);
+		}
+	}
+	if(yi->material_order.empty()) return fail(yi, "render: no materials defined");
+	std::vector<yafgpu_material> mats; for(auto *m : yi->material_order) mats.push_back(m->m);
+	std::vector<yafgpu_light> lights; for(auto *l : yi->light_order) lights.push_back(l->l);
+	yafgpu_scene_desc d{};
+	d.n_tris = (int32_t)tri_mat.size(); d.verts = verts.data(); d.tri_mat = tri_mat.data();
+	d.vnormals = any_normals ? vnormals.data() : nullptr;
+	d.n_materials = (int32_t)mats.size(); d.materials = mats.data();
+	d.n_lights = (int32_t)lights.size(); d.lights = lights.data();
+	d.camera = cam->second->c.cam;
+	d.build_threads = 0;
+	int threads = -1; p.get("threads", threads); if(threads > 0) d.build_threads = threads;
+	if(yafgpu_scene_create(&d, &yi->gpu)) return fail(yi, std::string("scene upload: ") + yafgpu_last_error());
+	yafgpu_tree_info ti{};
+	yafgpu_scene_info(yi->gpu, &ti);
+	yi->stats = yafaray_render_stats_t{};
+	yi->stats.tree_build_seconds = ti.build_seconds; yi->stats.upload_seconds = ti.upload_seconds;
+	yi->stats.kd_nodes = ti.n_nodes; yi->stats.kd_leaf_refs = ti.n_leaf_refs; yi->stats.kd_max_depth = ti.max_depth; yi->stats.n_triangles = ti.n_tris;
+	yi->stats.scene_device_bytes = ti.device_bytes;
+	yi->prepared = true;
+	return 1;
+}
+
+yafaray_bool_t yafaray_getRenderSize(yafaray_interface_t *yi, int *width, int *height)
+{
+	if(!yi->prepared) return fail(yi, "getRenderSize: call prepareRender first");
+	if(width) *width = yi->rp.width;
+	if(height) *height = yi->rp.height;
+	return 1;
+}
+
+yafaray_bool_t yafaray_renderPassDevice(yafaray_interface_t *yi, float *d_planes, void *d_counters, void *stream)
+{
+	if(!yi->prepared) return fail(yi, "renderPassDevice: call prepareRender first");
+	yi->rp.shard_index = yi->shard_index; yi->rp.shard_count = yi->shard_count;
+	if(yafgpu_render_tiles(yi->gpu, &yi->rp, d_planes, (yafgpu_counters *)d_counters, stream)) return fail(yi, std::string("render: ") + yafgpu_last_error());
+	return 1;
+}
+
+yafaray_bool_t yafaray_intersectRays(yafaray_interface_t *yi, int n, const float *rays, int *tri, float *t, float *bary)
+{
+	if(!yi->prepared) return fail(yi, "intersectRays: call prepareRender first");
+	if(yafgpu_trace_closest(yi->gpu, n, rays, tri, t, bary)) return fail(yi, std::string("intersectRays: ") + yafgpu_last_error());
+	return 1;
+}
+yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *rays, int *shadowed)
+{
+	if(!yi->prepared) return fail(yi, "shadowRays: call prepareRender first");
+	if(yafgpu_trace_shadow(yi->gpu, n, rays, shadowed)) return fail(yi, std::string("shadowRays: ") + yafgpu_last_error());
+	return 1;
+}
+
+static float srgb_from_linear(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f; }
+
+static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)
+{	// ImageFilm::flush (imagefilm.cc:640-900), combined pass only
+	if(!out) return;
+	const int w = yi->rp.width, h = yi->rp.height;
+	if(out->putPixel)
+	{
+		for(int y = 0; y < h; ++y)
+			for(int x = 0; x < w; ++x)
+			{
+				const float *px = &yi->film[5 * ((size_t)y * (size_t)w + (size_t)x)];
+				float c[4] = {0, 0, 0, 0};
+				if(px[4] != 0.f) for(int k = 0; k < 4; ++k) c[k] = px[k] / px[4];   // Pixel::normalized
+				for(int k = 0; k < 3; ++k) c[k] = std::max(0.f, c[k]);              // clampRgb0
+				if(yi->color_space == "sRGB") for(int k = 0; k < 3; ++k) c[k] = srgb_from_linear(c[k]);
+				else if(yi->color_space == "Raw_Manual_Gamma" && yi->gamma > 0.f && std::fabs(1.f - yi->gamma) > 0.001f)
+					for(int k = 0; k < 3; ++k) c[k] = std::pow(c[k], 1.f / yi->gamma);
+				out->putPixel(out->user, 0, x, y, c[0], c[1], c[2], c[3]);
+			}
+	}
+	if(out->flush) out->flush(out->user, 0);
+}
+
+yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *output, const yafaray_progress_t *progress)
+{
+	yi->abort_flag = false;
+	if(progress && progress->init) progress->init(progress->user, 100);
+	if(progress && progress->setTag) progress->setTag(progress->user, "Rendering pass 1 of 1...");
+	if(!yafaray_prepareRender(yi)) return 0;
+	if(yi->abort_flag) return fail(yi, "aborted");
+	const int w = yi->rp.width, h = yi->rp.height;
+	yi->film.assign((size_t)w * (size_t)h * 5, 0.f);
+	yafgpu_counters cn{};
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	(void)hipEventRecord(e0, nullptr);
+	const int rc = yafgpu_render_to_host(yi->gpu, &yi->rp, yi->film.data(), &cn);
+	(void)hipEventRecord(e1, nullptr);
+	(void)hipEventSynchronize(e1);
+	float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	if(rc) return fail(yi, std::string("render: ") + yafgpu_last_error());
+	yi->stats.rays_closest = cn.rays_closest; yi->stats.rays_shadow = cn.rays_shadow; yi->stats.interior_steps = cn.interior_steps;
+	yi->stats.leaves = cn.leaves; yi->stats.tri_tests = cn.tri_tests; yi->stats.camera_samples = cn.camera_samples; yi->stats.restarts = cn.restarts;
+	yi->stats.render_seconds = (double)ms * 1e-3;
+	if(progress && progress->update) progress->update(progress->user, 100);
+	if(progress && progress->done) progress->done(progress->user);
+	deliver(yi, output);
+	return 1;
+}
+
+void yafaray_abort(yafaray_interface_t *yi) { yi->abort_flag = true; }
+void yafaray_internal_set_error(yafaray_interface_t *yi, const char *msg) { if(yi) yi->err = msg ? msg : ""; }
+
+yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output)
+{
+	if(num_view != 0 || yi->film.empty()) return fail(yi, "getRenderedImage: nothing rendered");
+	deliver(yi, output);
+	return 1;
+}
+yafaray_bool_t yafaray_getFilm(yafaray_interface_t *yi, float *film, int width, int height)
+{
+	if(yi->film.empty() || width != yi->rp.width || height != yi->rp.height) return fail(yi, "getFilm: no film of that size");
+	std::memcpy(film, yi->film.data(), yi->film.size() * sizeof(float));
+	return 1;
+}
+yafaray_bool_t yafaray_getRenderStats(yafaray_interface_t *yi, yafaray_render_stats_t *stats)
+{
+	if(!stats) return 0;
+	*stats = yi->stats;
+	return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,1137 @@
+// MI355X (gfx950) path-tracing core: flattened kd-tree traversal, surface shading with MIS direct
+// lighting, and deterministic film accumulation — hand-written HIP, one persistent launch per pass.
+//
+// Reference path: TiledIntegrator::renderTile (integrator_tiled.cc:309-521) ->
+// PathIntegrator::integrate (integrator_path_tracer.cc:112-347) -> Scene::intersect / isShadowed
+// (scene.cc:896-994) -> TriKdTree::intersect / intersectS (kdtree_triangle.cc:684-977) ->
+// Triangle::intersect (triangle.h:223-259), MonteCarloIntegrator::doLightEstimation
+// (integrator_montecarlo.cc:78-345), ImageFilm::addSample (imagefilm.cc:925-1015).
+//
+// Execution model (DESIGN.md has the full picture):
+//   * one lane = one camera sample; a wave owns P pixels x L lanes (L = min(spp,64)) and walks their
+//     samples in index order, so each pixel's film sum is a sequential sum in sample order with no
+//     atomics (ImageFilm::addSample's order for a single-threaded reference render);
+//   * persistent waves pull "units" (pixel groups of one tile) from 8 queues, one per XCD, and
+//     steal from the others when their own runs dry, so the waves of one XCD share an image region
+//     and hence a kd-tree working set in that XCD's L2;
+//   * integrate() is an explicit state machine with exactly one closest-hit trace site and one
+//     any-hit trace site, so the traversal loops exist once in the instruction stream;
+//   * traversal keeps a short per-lane stack in LDS ([slot][lane], conflict-free), with the
+//     classic kd-restart fallback when more than kStack far-children are pending.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/yafgpu.h"
+#include "kdtree_build.h"
+#include "yafgpu_math.h"
+#include "yafgpu_shading.h"
+
+namespace yafgpu {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kStack = 16;            // per-lane LDS stack slots (power of two)
+constexpr int kDepthCap = 48;         // host tree depth cap; deeper pending lists restart
+constexpr int kQueues = 8;            // one per XCD
+constexpr float kMinRayDist = (float)0.00005;   // MIN_RAYDIST, CMakeLists.txt:46-48
+constexpr float kShadowBias = (float)0.0005;    // YAF_SHADOW_BIAS, CMakeLists.txt:50-52
+
+// ------------------------------------------------------------------------------------------------
+// device scene
+struct DevScene
+{
+	const uint2 *nodes;          // 8-byte kd nodes (kdtree_build.h)
+	const uint32_t *refs;        // leaf references
+	const float4 *tri;           // 3 x float4 per triangle: (a, eps) (e1, mat|vis<<30) (e2, 0)
+	const float4 *tri_ng;        // geometric normal + smooth flag
+	const float4 *tri_vn;        // 3 x float4 per triangle (vertex normals) or nullptr
+	const yafgpu_material *mats;
+	const yafgpu_light *lights;
+	const int *faure;            // concatenated Faure permutations
+	const int *faure_off;        // [50] offsets into faure
+	const double *inv_prims;     // [50]
+	int n_lights, n_tris;
+	uint32_t n_nodes;
+	float blo[3], bhi[3];
+	yafgpu_camera cam;
+};
+
+struct RenderArgs
+{
+	DevScene sc;
+	yafgpu_render_params rp;
+	float shadow_bias, ray_min_dist, filterw;
+	int lanes_per_pixel, pixels_per_wave, iters;
+	int n_tiles; uint32_t n_units;
+	const int4 *tile_rect;         // x0,y0,w,h per tile of this shard
+	const uint32_t *unit_prefix;   // n_tiles+1
+	uint32_t *queue_next;          // kQueues counters, 32 words apart
+	uint32_t queue_begin[kQueues + 1];
+	float *planes;
+	yafgpu_counters *counters;
+};
+
+struct LaneCounters { uint32_t closest, shadow, interior, leaves, tests, samples, restarts; };
+
+__constant__ int c_prims[50] = {1, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67,
+                                71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167,
+                                173, 179, 181, 191, 193, 197, 199, 211, 223, 227};
+
+// scrHalton__, include/common/scr_halton.h:52-75
+YG_DEV double scr_halton(const DevScene &sc, int dim, uint32_t n)
+{
+	double value = 0.0;
+	const int *sigma = sc.faure + sc.faure_off[dim];
+	const uint32_t base = (uint32_t)c_prims[dim];
+	double f, factor, dn = (double)n;
+	f = factor = sc.inv_prims[dim];
+	while(n > 0)
+	{
+		value += (double)(sigma[n % base]) * factor;
+		dn *= f;
+		n = (uint32_t)dn;
+		factor *= f;
+	}
+	return fmax(1.0e-36, fmin(1.0, value));
+}
+
+// Bound::cross, include/common/bound.h:144-212
+YG_DEV bool bound_cross(const DevScene &sc, V3 from, V3 dir, float dist, float &enter, float &leave)
+{
+	const V3 a0 = mk(sc.blo[0], sc.blo[1], sc.blo[2]), a1 = mk(sc.bhi[0], sc.bhi[1], sc.bhi[2]);
+	const V3 p = from - a0;
+	float lmin = -1e38f, lmax = 1e38f, ltmin, ltmax;
+	if(dir.x != 0.f)
+	{
+		const float inv = 1.f / dir.x;
+		if(inv > 0.f) { lmin = -p.x * inv; lmax = ((a1.x - a0.x) - p.x) * inv; }
+		else { lmin = ((a1.x - a0.x) - p.x) * inv; lmax = -p.x * inv; }
+		if((lmax < 0.f) || (lmin > dist)) return false;
+	}
+	if(dir.y != 0.f)
+	{
+		const float inv = 1.f / dir.y;
+		if(inv > 0.f) { ltmin = -p.y * inv; ltmax = ((a1.y - a0.y) - p.y) * inv; }
+		else { ltmin = ((a1.y - a0.y) - p.y) * inv; ltmax = -p.y * inv; }
+		lmin = smax(ltmin, lmin);
+		lmax = smin(ltmax, lmax);
+		if((lmax < 0.f) || (lmin > dist)) return false;
+	}
+	if(dir.z != 0.f)
+	{
+		const float inv = 1.f / dir.z;
+		if(inv > 0.f) { ltmin = -p.z * inv; ltmax = ((a1.z - a0.z) - p.z) * inv; }
+		else { ltmin = ((a1.z - a0.z) - p.z) * inv; ltmax = -p.z * inv; }
+		lmin = smax(ltmin, lmin);
+		lmax = smin(ltmax, lmax);
+		if((lmax < 0.f) || (lmin > dist)) return false;
+	}
+	if((lmin <= lmax) && (lmax >= 0.f) && (lmin <= dist)) { enter = lmin; leave = lmax; return true; }
+	return false;
+}
+
+// Triangle::intersect, include/common/triangle.h:223-259, on the 48-byte record
+YG_DEV bool tri_test(const float4 r0, const float4 r1, const float4 r2, V3 from, V3 dir, float &t, float &u, float &v)
+{
+	const V3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
+	const float eps = r0.w;
+	const V3 pvec = cross(dir, e2);
+	const float det = dot(e1, pvec);
+	if(det > -eps && det < eps) return false;
+	const float inv_det = 1.f / det;
+	const V3 tvec = from - a;
+	u = dot(tvec, pvec) * inv_det;
+	if(u < 0.f || u > 1.f) return false;
+	const V3 qvec = cross(tvec, e1);
+	v = dot(dir, qvec) * inv_det;
+	if((v < 0.f) || ((u + v) > 1.f)) return false;
+	t = dot(e2, qvec) * inv_det;
+	if(t < eps) return false;
+	return true;
+}
+
+// per-lane stack in LDS: column `lane` of a [kStack][64] array of (node, tmax)
+struct LaneStack
+{
+	uint2 *col;     // &stack[0][lane]; slot s lives at col[s * kWave]
+	int head, count; bool dropped;
+	YG_DEV void reset() { head = 0; count = 0; dropped = false; }
+	YG_DEV void push(uint32_t node, float tmax)
+	{
+		col[head * kWave] = make_uint2(node, __float_as_uint(tmax));
+		head = (head + 1) & (kStack - 1);
+		if(count < kStack) ++count;
+		else dropped = true;       // the oldest pending far-child was overwritten: a restart will recover it
+	}
+	YG_DEV void pop(uint32_t &node, float &tmax)
+	{
+		head = (head + kStack - 1) & (kStack - 1);
+		const uint2 e = col[head * kWave];
+		node = e.x; tmax = __uint_as_float(e.y);
+		--count;
+	}
+};
+
+// Closest hit (kAny == false): TriKdTree::intersect, kdtree_triangle.cc:684-837 — the nearest
+//   triangle with ray_tmin <= t < dist whose material is visible to camera rays (:786).
+// Any hit (kAny == true): TriKdTree::intersectS, :840-977 — any triangle with 0 <= t < dist whose
+//   material casts shadows (:938).
+// Both walk [t_enter, t_exit] of the ray against the tree bound front to back; a triangle is
+// referenced by every leaf its bounds overlap, so the result does not depend on tree topology.
+template<bool kAny, bool kStats>
+YG_DEV bool kd_trace(const DevScene &sc, LaneStack &stk, V3 from, V3 dir, float ray_tmin, float dist,
+                     int &tri_out, float &t_out, float &bu, float &bv, LaneCounters &cn)
+{
+	float a, b;
+	if(sc.n_nodes == 0u) return false;
+	if(!bound_cross(sc, from, dir, dist, a, b)) return false;
+	const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+	const float t_exit = b;
+	float tmin = smax(a, 0.f), tmax = t_exit;
+	float z = dist;
+	bool hit = false;
+	uint32_t node = 0u;
+	stk.reset();
+	for(;;)
+	{
+		if(z < tmin) break;       // kdtree_triangle.cc:717 (dist < entry distance)
+		uint2 nd = sc.nodes[node];
+		while((nd.y & 3u) != 3u)
+		{
+			const int axis = (int)(nd.y & 3u);
+			const float split = __uint_as_float(nd.x);
+			const float o = comp(from, axis), d = comp(dir, axis);
+			const float tplane = (split - o) * comp(inv_dir, axis);
+			const bool below = (o < split) || (o == split && d <= 0.f);
+			const uint32_t left = node + 1u, right = nd.y >> 2;
+			const uint32_t near_c = below ? left : right, far_c = below ? right : left;
+			if(kStats) ++cn.interior;
+			if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;       // plane beyond the cell or behind the origin (also NaN)
+			else if(tplane < tmin) node = far_c;
+			else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
+			nd = sc.nodes[node];
+		}
+		{
+			const uint32_t np = nd.y >> 2, first = nd.x;
+			if(kStats) ++cn.leaves;
+			for(uint32_t i = 0; i < np; ++i)
+			{
+				const uint32_t ti = sc.refs[first + i];
+				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
+				float t, u, v;
+				if(kStats) ++cn.tests;
+				if(tri_test(r0, r1, r2, from, dir, t, u, v))
+				{
+					const uint32_t vis = __float_as_uint(r1.w) >> 30;
+					if(kAny)
+					{
+						if(t < dist && t >= 0.f && (vis == 0u || vis == 2u)) return true;
+					}
+					else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u))
+					{
+						z = t; tri_out = (int)ti; bu = u; bv = v; hit = true;
+					}
+				}
+			}
+		}
+		if(!kAny && hit && z <= tmax) break;   // :822
+		if(stk.count == 0)
+		{
+			if(!stk.dropped || tmax >= t_exit) break;
+			// kd-restart: pending far-children were lost to the short stack; resume at the cell exit
+			tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false;
+			if(kStats) ++cn.restarts;
+			continue;
+		}
+		tmin = tmax;
+		stk.pop(node, tmax);
+	}
+	t_out = z;
+	return hit;
+}
+
+// Triangle::getSurface, src/common/triangle.cc:30-133 (no UV / orco)
+YG_DEV void get_surface(const DevScene &sc, int ti, V3 hitp, float bu, float bv, SurfPt &sp)
+{
+	const float4 g = sc.tri_ng[ti];
+	sp.ng = mk(g.x, g.y, g.z);
+	if(sc.tri_vn != nullptr && __float_as_uint(g.w) != 0u)
+	{
+		const float u = 1.f - bu - bv, v = bu, w = bv;   // b_0, b_1, b_2 (triangle.h:252-254, triangle.cc:34)
+		const float4 na = sc.tri_vn[3 * ti], nb = sc.tri_vn[3 * ti + 1], nc = sc.tri_vn[3 * ti + 2];
+		sp.n = normalize(mk(na.x, na.y, na.z) * u + mk(nb.x, nb.y, nb.z) * v + mk(nc.x, nc.y, nc.z) * w);
+	}
+	else sp.n = sp.ng;
+	sp.mat = (int)(__float_as_uint(sc.tri[3 * ti + 1].w) & 0x3FFFFFFFu);
+	sp.p = hitp;
+	create_cs(sp.n, sp.nu, sp.nv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct lighting: MonteCarloIntegrator::doLightEstimation, integrator_montecarlo.cc:78-345,
+// over lights [l_begin, l_end).  One any-hit trace site serves the Dirac branch (:94-148), the
+// light-sampling half (:161-262) and the BSDF-sampling half (:285-333) of the area-light MIS.
+template<bool kStats>
+YG_DEV Col direct_light(const RenderArgs &ra, LaneStack &stk, const SurfPt &sp, const yafgpu_material &mat, const BsdfDat &dat, V3 wo,
+                        int l_begin, int l_end, uint32_t pixel_sample, uint32_t sampling_offs, LaneCounters &cn)
+{
+	const DevScene &sc = ra.sc;
+	Col total = mkc(0.f, 0.f, 0.f);
+	const uint32_t kMisFlags = kGlossy | kDiffuse | kDispersive | kReflect | kTransmit;
+	for(int li = l_begin; li < l_end; ++li)
+	{
+		const yafgpu_light &light = sc.lights[li];
+		const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
+		const bool dirac = light.type == YAFGPU_LIGHT_POINT;
+		const int n = dirac ? 1 : (int)ceilf((float)light.samples * ra.rp.aa_light_sample_multiplier);
+		const float inv_ns = 1.f / (float)n;
+		const uint32_t offs = (uint32_t)n * pixel_sample + sampling_offs + (uint32_t)li * 4567u; // LOFFS_DELTA :45
+		Col ccol = mkc(0.f, 0.f, 0.f), ccol_2 = mkc(0.f, 0.f, 0.f), col_dirac = mkc(0.f, 0.f, 0.f);
+		Halton hal_2, hal_3;
+		hal_2.init(2u); hal_3.init(3u);
+		const int n_phase = dirac ? 1 : 2;
+		for(int phase = 0; phase < n_phase; ++phase)
+		{
+			hal_2.set_start(offs - 1u);
+			hal_3.set_start(offs - 1u);
+			for(int i = 0; i < n; ++i)
+			{
+				V3 r_dir = mk(0.f, 0.f, 0.f);
+				float r_tmin = 0.f, r_tmax = -1.f;
+				Col contrib = mkc(0.f, 0.f, 0.f);
+				bool want = false;
+				if(dirac)
+				{
+					Col lcol;
+					if(pointlight_illuminate(light, sp.p, lcol, r_dir, r_tmax))
+					{
+						r_tmin = ra.rp.shadow_bias_auto ? ra.shadow_bias * smax(1.f, length(sp.p)) : ra.shadow_bias;
+						const float angle = mat.flat ? 1.f : fabsf(dot(sp.n, r_dir));
+						contrib = (mat_eval(mat, dat, sp, wo, r_dir, kAll) * lcol) * angle;
+						want = true;
+					}
+				}
+				else
+				{
+					const float s_1 = hal_2.next(), s_2 = hal_3.next();
+					if(phase == 0)
+					{
+						float ls_pdf;
+						if(arealight_illum_sample(light, sp.p, s_1, s_2, r_dir, r_tmax, ls_pdf))
+						{
+							r_tmin = ra.rp.shadow_bias_auto ? ra.shadow_bias * smax(1.f, length(sp.p)) : ra.shadow_bias;
+							if(ls_pdf > 1e-6f)
+							{
+								const Col surf_col = mat_eval(mat, dat, sp, wo, r_dir, kAll);
+								const float angle = mat.flat ? 1.f : fabsf(dot(sp.n, r_dir));
+								const float m_pdf = mat_pdf(mat, dat, sp, wo, r_dir, kMisFlags);
+								const Col ls_col = col3(light.color);
+								if(m_pdf > 1e-6f)
+								{
+									const float l_2 = ls_pdf * ls_pdf, m_2 = m_pdf * m_pdf;
+									const float w = l_2 / (l_2 + m_2);
+									contrib = (((surf_col * ls_col) * angle) * w) / ls_pdf;
+								}
+								else contrib = ((surf_col * ls_col) * angle) / ls_pdf;
+							}
+							// the reference traces the shadow ray before it looks at the pdf (:170-179)
+							want = true;
+						}
+					}
+					else
+					{
+						r_tmin = ra.rp.min_raydist_auto ? ra.ray_min_dist * smax(1.f, length(sp.p)) : ra.ray_min_dist;
+						float W = 0.f;
+						BsdfSample bs; bs.s_1 = s_1; bs.s_2 = s_2; bs.pdf = 0.f; bs.flags = kMisFlags; bs.sampled = kNone;
+						const Col surf_col = mat_sample(mat, dat, sp, wo, r_dir, bs, W);
+						float light_ipdf;
+						if(bs.pdf > 1e-6f && arealight_intersect(light, sp.p, r_dir, r_tmax, light_ipdf))
+						{
+							if(light_ipdf > 1e-6f)
+							{
+								const float l_pdf = 1.f / light_ipdf;
+								const float l_2 = l_pdf * l_pdf, m_2 = bs.pdf * bs.pdf;
+								const float w = m_2 / (l_2 + m_2);
+								contrib = ((surf_col * col3(light.color)) * w) * W;
+							}
+							want = true;
+						}
+					}
+				}
+				if(want)
+				{
+					bool shadowed = false;
+					if(cast_shadows)
+					{	// Scene::isShadowed, scene.cc:962-994
+						const V3 sfrom = sp.p + r_dir * r_tmin;
+						const float dis = (r_tmax < 0.f) ? INFINITY : r_tmax - 2.f * r_tmin;
+						int ti; float tt, uu, vv;
+						++cn.shadow;
+						shadowed = kd_trace<true, kStats>(sc, stk, sfrom, r_dir, 0.f, dis, ti, tt, uu, vv, cn);
+					}
+					if(!shadowed)
+					{
+						if(dirac) col_dirac = col_dirac + contrib;
+						else if(phase == 0) ccol = ccol + contrib;
+						else ccol_2 = ccol_2 + contrib;
+					}
+				}
+			}
+		}
+		Col col = mkc(0.f, 0.f, 0.f);
+		if(dirac) col = col + col_dirac;
+		else { col = col + ccol * inv_ns; col = col + ccol_2 * inv_ns; }
+		total = total + col;
+	}
+	return total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PathIntegrator::integrate, integrator_path_tracer.cc:112-347, as a per-lane state machine.
+// Supported lobes: diffuse/translucent shinydiffuse, glossy(as_diffuse), light_mat — the host
+// rejects materials that would need recursiveRaytrace (integrator_montecarlo.cc:782-1028).
+enum : int { kStPrimary = 0, kStFirst = 1, kStDepth = 2 };
+
+template<bool kStats>
+YG_DEV void integrate(const RenderArgs &ra, LaneStack &stk, V3 from, V3 dir, float tmin, float tmax,
+                      uint32_t pixel_sample, uint32_t sampling_offs, uint32_t sample_ordinal, float out[4], LaneCounters &cn)
+{
+	const DevScene &sc = ra.sc;
+	const yafgpu_render_params &rp = ra.rp;
+	Col col = mkc(0.f, 0.f, 0.f);
+	float alpha = rp.bg_transp ? 0.f : 1.f;
+
+	int stage = kStPrimary;
+	SurfPt sp0, hit;                   // camera hit, current path vertex
+	BsdfDat dat0, dat_n;
+	V3 wo0 = mk(0.f, 0.f, 0.f), pwo = mk(0.f, 0.f, 0.f);
+	int mat0 = 0;
+	uint32_t bsdfs0 = 0u;
+	Col path_col = mkc(0.f, 0.f, 0.f), throughput = mkc(1.f, 1.f, 1.f);
+	int path_i = 0, depth = 0;
+	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
+	uint32_t offs = 0u;
+	uint32_t sampled_flags = kNone;
+	uint32_t one_light_calls = 0u;
+	Mwc rr; rr.init(fnv32a(sample_ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
+
+	V3 r_from = from, r_dir = dir;
+	float r_tmin = tmin, r_tmax = tmax;
+	bool running = true;
+	while(running)
+	{
+		// ---- the one closest-hit trace site: Scene::intersect, scene.cc:896-927
+		int ti = -1; float z = 0.f, bu = 0.f, bv = 0.f;
+		const float dis = (r_tmax < 0.f) ? INFINITY : r_tmax;
+		++cn.closest;
+		const bool got = kd_trace<false, kStats>(sc, stk, r_from, r_dir, r_tmin, dis, ti, z, bu, bv, cn);
+		bool start_path = false;     // begin path sample `path_i` from the camera hit
+		bool extend = false;         // sample the current vertex and continue the path
+		if(stage == kStPrimary)
+		{
+			if(!got)
+			{
+				if(rp.has_background && !rp.bg_transp_refract) col = col + mkc(rp.background[0], rp.background[1], rp.background[2]);
+				break;
+			}
+			get_surface(sc, ti, r_from + r_dir * z, bu, bv, sp0);
+			const yafgpu_material &m = sc.mats[sp0.mat];
+			mat0 = sp0.mat;
+			bsdfs0 = mat_init_bsdf(m, dat0);
+			wo0 = -r_dir;
+			if(bsdfs0 & kEmit) col = col + mat_emit(m, sp0, wo0, true);                     // :152, include_lights_ = true (:133)
+			if(bsdfs0 & kDiffuse) col = col + direct_light<kStats>(ra, stk, sp0, m, dat0, wo0, 0, sc.n_lights, pixel_sample, sampling_offs, cn); // :156
+			alpha = 1.f;
+			if(rp.bg_transp_refract)
+			{
+				const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+				alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
+			}
+			const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
+			if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) break;
+			path_i = 0;
+			start_path = true;
+		}
+		else if(stage == kStFirst)
+		{
+			if(!got) { ++path_i; start_path = true; }                                        // :218 `continue`
+			else
+			{
+				get_surface(sc, ti, r_from + r_dir * z, bu, bv, hit);
+				const yafgpu_material &pm = sc.mats[hit.mat];
+				const uint32_t mb = mat_init_bsdf(pm, dat_n);
+				if(sampled_flags != kNone) pwo = -r_dir;                                      // :224
+				Col lcol = mkc(0.f, 0.f, 0.f);
+				if(sc.n_lights > 0)
+				{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
+					int lnum = 0;
+					if(sc.n_lights > 1)
+					{
+						Halton h2; h2.init(2u);
+						h2.set_start(rp.base_sampling_offset + (sample_ordinal * 16u + one_light_calls) - 1u);
+						lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
+					}
+					++one_light_calls;
+					lcol = direct_light<kStats>(ra, stk, hit, pm, dat_n, pwo, lnum, lnum + 1, pixel_sample, sampling_offs, cn) * (float)sc.n_lights;
+				}
+				if(mb & kEmit) lcol = lcol + mat_emit(pm, hit, pwo, false);                   // :226
+				path_col = path_col + lcol * throughput;                                       // :228
+				depth = 1;
+				if(depth < rp.bounces) extend = true;
+				else { ++path_i; start_path = true; }
+			}
+		}
+		else
+		{
+			if(!got) { ++path_i; start_path = true; }                                        // :259-266 `break`
+			else
+			{
+				get_surface(sc, ti, r_from + r_dir * z, bu, bv, hit);
+				const yafgpu_material &pm = sc.mats[hit.mat];
+				const uint32_t mb = mat_init_bsdf(pm, dat_n);
+				pwo = -r_dir;                                                                  // :271
+				Col lcol = mkc(0.f, 0.f, 0.f);
+				if((mb & kDiffuse) && sc.n_lights > 0)
+				{
+					int lnum = 0;
+					if(sc.n_lights > 1)
+					{
+						Halton h2; h2.init(2u);
+						h2.set_start(rp.base_sampling_offset + (sample_ordinal * 16u + one_light_calls) - 1u);
+						lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
+					}
+					++one_light_calls;
+					lcol = direct_light<kStats>(ra, stk, hit, pm, dat_n, pwo, lnum, lnum + 1, pixel_sample, sampling_offs, cn) * (float)sc.n_lights;
+				}
+				bool alive = true;
+				if(depth > rp.rr_min_bounces)
+				{	// Russian roulette :282-288
+					const float random_value = (float)rr.next();
+					const float probability = smax(throughput.r, smax(throughput.g, throughput.b));
+					if(probability <= 0.f || probability < random_value) alive = false;
+					else throughput = throughput * (1.f / probability);
+				}
+				if(alive)
+				{
+					path_col = path_col + lcol * throughput;                                   // :292
+					++depth;
+					if(depth < rp.bounces) extend = true;
+					else { ++path_i; start_path = true; }
+				}
+				else { ++path_i; start_path = true; }
+			}
+		}
+
+		if(extend)
+		{
+			// next segment from the current vertex, :232-257
+			const yafgpu_material &pm = sc.mats[hit.mat];
+			const int d_4 = 4 * depth;
+			BsdfSample bs;
+			bs.s_1 = (float)scr_halton(sc, d_4 + 3, offs);
+			bs.s_2 = (float)scr_halton(sc, d_4 + 4, offs);
+			bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
+			float w = 0.f;
+			V3 p_dir = r_dir;
+			const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
+			if(is_black(scol)) { ++path_i; start_path = true; }                               // :249 `break`
+			else
+			{
+				throughput = throughput * scol;
+				r_from = hit.p; r_dir = p_dir; r_tmin = ra.ray_min_dist; r_tmax = -1.f;
+				stage = kStDepth;
+			}
+		}
+		if(start_path)
+		{
+			if(path_i >= n_paths) { col = col + path_col / (float)n_paths; break; }           // :297
+			// first segment from the camera hit, :186-216
+			const yafgpu_material &m = sc.mats[mat0];
+			offs = (uint32_t)rp.path_samples * pixel_sample + sampling_offs + (uint32_t)path_i;
+			BsdfSample bs;
+			bs.s_1 = ri_vdc(offs, 0u);
+			bs.s_2 = (float)scr_halton(sc, 2, offs);
+			bs.pdf = 0.f; bs.sampled = kNone;
+			bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
+			float w = 0.f;
+			V3 p_dir = mk(0.f, 0.f, 0.f);
+			pwo = wo0;
+			const Col scol = mat_sample(m, dat0, sp0, pwo, p_dir, bs, w) * w;
+			throughput = scol;
+			sampled_flags = bs.sampled;
+			r_from = sp0.p; r_dir = p_dir; r_tmin = ra.ray_min_dist; r_tmax = -1.f;
+			stage = kStFirst;
+		}
+	}
+	// EmptyVolumeIntegrator (integrator_empty_volume.cc:32-38): transmittance 1, in-scatter 0
+	if(rp.bg_transp) alpha = smax(alpha, 0.f);
+	out[0] = col.r; out[1] = col.g; out[2] = col.b; out[3] = alpha;
+}
+
+YG_DEV int round2int(double v) { return (int)(v + (.5 - 1.4e-11)); } // util_math.h:34-43
+
+YG_DEV uint32_t read_xcc_id()
+{
+	uint32_t v;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+	return v & 7u;
+}
+
+template<typename T> YG_DEV T wave_bcast(T v, int src) { return __shfl(v, src, kWave); }
+
+YG_DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+	return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render pass: TiledIntegrator::renderTile (integrator_tiled.cc:309-521) for every tile of the
+// shard + ImageFilm::addSample (imagefilm.cc:925-1015) for the box filter of width <= 1.002 px
+// (filterw = 0.501 after the clamp at :165): a sample lands on its own pixel and, when dx (dy)
+// >= 0.999, also on the right (lower) neighbour, weight 1 each.
+template<bool kStats>
+__global__ __launch_bounds__(kBlock) void render_kernel(const RenderArgs ra)
+{
+	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
+	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
+	LaneStack stk;
+	stk.col = &s_stack[wave][0][lane];
+	LaneCounters cn = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	const yafgpu_render_params &rp = ra.rp;
+	const int L = ra.lanes_per_pixel, P = ra.pixels_per_wave;
+	const int group = lane / L, lane_in_pixel = lane - group * L;
+	const int n_samples = rp.aa_minsamples;
+	const float d_1 = (float)(1.0 / (double)(float)n_samples);    // integrator_tiled.cc:316
+	const int cx0 = rp.xstart, cy0 = rp.ystart, cx1 = rp.xstart + rp.width, cy1 = rp.ystart + rp.height;
+	const size_t plane_stride = (size_t)rp.width * (size_t)rp.height * YAFGPU_FILM_CHANNELS;
+	const uint32_t my_queue = read_xcc_id();
+
+	for(int qi = 0; qi < kQueues; ++qi)
+	{
+		const uint32_t q = (my_queue + (uint32_t)qi) & (kQueues - 1);
+		const uint32_t q_begin = ra.queue_begin[q], q_end = ra.queue_begin[q + 1];
+		for(;;)
+		{
+			uint32_t u = 0u;
+			if(lane == 0) u = atomicAdd(&ra.queue_next[q * 32u], 1u);
+			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u) + q_begin;
+			if(u >= q_end) break;
+			// tile of this unit (wave-uniform binary search over the prefix sums)
+			int lo = 0, hi = ra.n_tiles;
+			while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(ra.unit_prefix[mid] <= u) lo = mid; else hi = mid; }
+			const int4 rect = ra.tile_rect[lo];
+			const int k = (int)(u - ra.unit_prefix[lo]);
+			const int qpix = k * P + group;
+			const bool pix_ok = (group < P) && (qpix < rect.z * rect.w);
+			const int px = rect.x + (pix_ok ? qpix % rect.z : 0), py = rect.y + (pix_ok ? qpix / rect.z : 0);
+			const uint32_t sampling_offs = fnv32a((uint32_t)py * fnv32a((uint32_t)px));       // :379
+			float acc[YAFGPU_FILM_PLANES][YAFGPU_FILM_CHANNELS];
+#pragma unroll
+			for(int a = 0; a < YAFGPU_FILM_PLANES; ++a)
+#pragma unroll
+				for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) acc[a][c] = 0.f;
+
+			for(int it = 0; it < ra.iters; ++it)
+			{
+				const int sample = it * L + lane_in_pixel;
+				const bool active = pix_ok && sample < n_samples;
+				float c4[4] = {0.f, 0.f, 0.f, 0.f};
+				uint32_t flag = 0u;
+				if(active)
+				{
+					float dx = 0.5f, dy = 0.5f;
+					if(n_samples > 1)
+					{	// :399-403 (single pass)
+						dx = (float)((0.5 + (double)(float)sample) * (double)d_1);
+						dy = ri_lp((uint32_t)sample + sampling_offs, 0u);
+					}
+					V3 from, dir; float tmin, tmax;
+					camera_shoot(ra.sc.cam, (float)px + dx, (float)py + dy, from, dir, tmin, tmax);   // :410
+					++cn.samples;
+					const uint32_t pixel_sample = rp.base_sampling_offset + (uint32_t)sample;          // :389
+					const uint32_t ordinal = ((uint32_t)(py - cy0) * (uint32_t)rp.width + (uint32_t)(px - cx0)) * (uint32_t)n_samples + (uint32_t)sample;
+					integrate<kStats>(ra, stk, from, dir, tmin, tmax, pixel_sample, sampling_offs, ordinal, c4, cn);
+					if(c4[3] > 1.f) c4[3] = 1.f;                                                     // :459
+					// footprint, imagefilm.cc:933-936 with filterw = 0.501
+					const int dx_1 = min(cx1 - px - 1, round2int((double)dx + (double)ra.filterw - 1.0));
+					const int dy_1 = min(cy1 - py - 1, round2int((double)dy + (double)ra.filterw - 1.0));
+					flag = 1u | (dx_1 >= 1 ? 2u : 0u) | (dy_1 >= 1 ? 4u : 0u);
+				}
+				// sequential per-pixel sums in sample order; every lane of a group replays its group
+				const int base = group * L;
+				for(int s = 0; s < L; ++s)
+				{
+					const int src = (base + s) & (kWave - 1);
+					const uint32_t f = wave_bcast(flag, src);
+					const float r = wave_bcast(c4[0], src), g = wave_bcast(c4[1], src), b = wave_bcast(c4[2], src), al = wave_bcast(c4[3], src);
+					if(f & 1u)
+					{
+						acc[0][0] += r; acc[0][1] += g; acc[0][2] += b; acc[0][3] += al; acc[0][4] += 1.f;
+						if(f & 2u) { acc[1][0] += r; acc[1][1] += g; acc[1][2] += b; acc[1][3] += al; acc[1][4] += 1.f; }
+						if(f & 4u) { acc[2][0] += r; acc[2][1] += g; acc[2][2] += b; acc[2][3] += al; acc[2][4] += 1.f; }
+						if((f & 6u) == 6u) { acc[3][0] += r; acc[3][1] += g; acc[3][2] += b; acc[3][3] += al; acc[3][4] += 1.f; }
+					}
+				}
+			}
+			if(pix_ok && lane_in_pixel == 0)
+			{
+				const size_t pix = ((size_t)(py - cy0) * (size_t)rp.width + (size_t)(px - cx0)) * YAFGPU_FILM_CHANNELS;
+#pragma unroll
+				for(int a = 0; a < YAFGPU_FILM_PLANES; ++a)
+				{
+					if(a == 0 || acc[a][4] != 0.f)
+					{
+						float *dst = ra.planes + (size_t)a * plane_stride + pix;
+#pragma unroll
+						for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) dst[c] = acc[a][c];
+					}
+				}
+			}
+		}
+	}
+	if(ra.counters != nullptr)
+	{
+		const uint32_t v0 = wave_sum(cn.closest), v1 = wave_sum(cn.shadow), v2 = wave_sum(cn.interior), v3 = wave_sum(cn.leaves),
+		               v4 = wave_sum(cn.tests), v5 = wave_sum(cn.samples), v6 = wave_sum(cn.restarts);
+		if(lane == 0)
+		{
+			atomicAdd((unsigned long long *)&ra.counters->rays_closest, (unsigned long long)v0);
+			atomicAdd((unsigned long long *)&ra.counters->rays_shadow, (unsigned long long)v1);
+			atomicAdd((unsigned long long *)&ra.counters->camera_samples, (unsigned long long)v5);
+			if(kStats)
+			{
+				atomicAdd((unsigned long long *)&ra.counters->interior_steps, (unsigned long long)v2);
+				atomicAdd((unsigned long long *)&ra.counters->leaves, (unsigned long long)v3);
+				atomicAdd((unsigned long long *)&ra.counters->tri_tests, (unsigned long long)v4);
+				atomicAdd((unsigned long long *)&ra.counters->restarts, (unsigned long long)v6);
+			}
+		}
+	}
+}
+
+// film[y][x] = own + right(x-1,y) + down(x,y-1) + diag(x-1,y-1): the neighbours' splats onto this pixel
+__global__ __launch_bounds__(kBlock) void combine_kernel(const float *planes, float *film, int w, int h)
+{
+	const size_t n = (size_t)w * (size_t)h;
+	const size_t stride = n * YAFGPU_FILM_CHANNELS;
+	for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const int x = (int)(i % (size_t)w), y = (int)(i / (size_t)w);
+#pragma unroll
+		for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c)
+		{
+			float v = planes[i * YAFGPU_FILM_CHANNELS + c];
+			if(x > 0) v += planes[stride + (i - 1) * YAFGPU_FILM_CHANNELS + c];
+			if(y > 0) v += planes[2 * stride + (i - (size_t)w) * YAFGPU_FILM_CHANNELS + c];
+			if(x > 0 && y > 0) v += planes[3 * stride + (i - (size_t)w - 1) * YAFGPU_FILM_CHANNELS + c];
+			film[i * YAFGPU_FILM_CHANNELS + c] = v;
+		}
+	}
+}
+
+// ray batches: Scene::intersect / Scene::isShadowed on arrays (tests and kernel-level measurements)
+template<bool kAny>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const DevScene sc, int n, const float *rays, int *tri, float *t, float *bary, int *shadowed)
+{
+	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
+	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
+	LaneStack stk;
+	stk.col = &s_stack[wave][0][lane];
+	LaneCounters cn = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	for(int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x))
+	{
+		const float *r = rays + 8 * (size_t)i;
+		const V3 from = mk(r[0], r[1], r[2]), dir = mk(r[3], r[4], r[5]);
+		const float tmin = r[6], tmax = r[7];
+		int ti = -1; float z = 0.f, bu = 0.f, bv = 0.f;
+		if(kAny)
+		{
+			const V3 sfrom = from + dir * tmin;
+			const float dis = (tmax < 0.f) ? INFINITY : tmax - 2.f * tmin;
+			shadowed[i] = kd_trace<true, false>(sc, stk, sfrom, dir, 0.f, dis, ti, z, bu, bv, cn) ? 1 : 0;
+		}
+		else
+		{
+			const float dis = (tmax < 0.f) ? INFINITY : tmax;
+			const bool h = kd_trace<false, false>(sc, stk, from, dir, tmin, dis, ti, z, bu, bv, cn);
+			tri[i] = h ? ti : -1; t[i] = h ? z : 0.f;
+			bary[3 * i] = h ? 1.f - bu - bv : 0.f; bary[3 * i + 1] = h ? bu : 0.f; bary[3 * i + 2] = h ? bv : 0.f;
+		}
+	}
+}
+
+} // namespace yafgpu
+
+// ================================================================================================
+// host side of the narrow ABI
+using namespace yafgpu;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return fail(-100, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
+
+struct yafgpu_scene
+{
+	DevScene dev{};
+	std::vector<void *> allocs;
+	KdTree tree;
+	yafgpu_tree_info info{};
+	std::vector<yafgpu_material> mats;
+	int n_lights = 0;
+	// per-render scratch, grown on demand
+	int4 *d_tiles = nullptr; uint32_t *d_prefix = nullptr; uint32_t *d_queue = nullptr; size_t tiles_cap = 0;
+};
+
+template<typename T> static int upload(yafgpu_scene *s, const T *src, size_t n, const T **dst)
+{
+	void *p = nullptr;
+	const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+	HIP_OK(hipMalloc(&p, bytes));
+	s->allocs.push_back(p);
+	if(n) HIP_OK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+	s->info.device_bytes += bytes;
+	*dst = (const T *)p;
+	return 0;
+}
+
+// Faure permutations (the reference ships them as a table, src/common/faure_tables.cc; they are
+// the standard construction of Faure 1992 and are regenerated here rather than copied)
+static void faure_perm(int b, std::vector<int> &out)
+{
+	if(b == 2) { out = {0, 1}; return; }
+	if(b % 2 == 0)
+	{
+		std::vector<int> half; faure_perm(b / 2, half);
+		out.resize((size_t)b);
+		for(int i = 0; i < b / 2; ++i) { out[(size_t)i] = 2 * half[(size_t)i]; out[(size_t)(b / 2 + i)] = 2 * half[(size_t)i] + 1; }
+	}
+	else
+	{
+		std::vector<int> prev; faure_perm(b - 1, prev);
+		const int m = (b - 1) / 2;
+		for(int &v : prev) if(v >= m) ++v;
+		out.assign(prev.begin(), prev.begin() + m);
+		out.push_back(m);
+		out.insert(out.end(), prev.begin() + m, prev.end());
+	}
+}
+
+static const int kPrimsHost[50] = {1, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67,
+                                   71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167,
+                                   173, 179, 181, 191, 193, 197, 199, 211, 223, 227};
+
+extern "C" {
+
+const char *yafgpu_last_error(void) { return g_err.c_str(); }
+
+int yafgpu_device_count(void)
+{
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+int yafgpu_set_device(int device) { HIP_OK(hipSetDevice(device)); return 0; }
+
+uint64_t yafgpu_planes_bytes(int32_t width, int32_t height)
+{
+	return (uint64_t)YAFGPU_FILM_PLANES * (uint64_t)width * (uint64_t)height * YAFGPU_FILM_CHANNELS * sizeof(float);
+}
+
+int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
+{
+	if(!d || !out) return fail(-1, "null argument");
+	if(d->n_tris < 0 || d->n_materials <= 0) return fail(-2, "scene needs at least one material");
+	for(int i = 0; i < d->n_tris; ++i)
+		if(d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(-3, "triangle material index out of range");
+	for(int i = 0; i < d->n_materials; ++i)
+	{
+		// recursiveRaytrace (integrator_montecarlo.cc:782-1028) is not on the device path yet (row N3)
+		if(d->materials[i].bsdf_flags & (kSpecular | kGlossy | kFilter | kDispersive))
+			return fail(-4, "material with specular/glossy/filter lobes needs recursiveRaytrace, which the GPU path does not implement");
+	}
+	auto *s = new yafgpu_scene();
+	const auto t0 = std::chrono::steady_clock::now();
+	build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
+	s->info.build_seconds = s->tree.build_seconds;
+	s->info.n_nodes = (uint32_t)s->tree.nodes.size();
+	s->info.n_leaf_refs = (uint32_t)s->tree.refs.size();
+	s->info.max_depth = (uint32_t)s->tree.max_depth;
+	s->info.n_tris = (uint32_t)d->n_tris;
+	const auto t1 = std::chrono::steady_clock::now();
+
+	// triangle records: Triangle::updateIntersectionCachedValues (triangle.h:197-207), recNormal (:295-302)
+	const size_t nt = (size_t)d->n_tris;
+	std::vector<float4> rec(3 * nt), ng(nt), vn;
+	bool any_smooth = false;
+	for(size_t i = 0; i < nt; ++i)
+	{
+		const float *v = d->verts + 9 * i;
+		const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+		const float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+		const float l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+		const float eps = (float)((double)0.1f * 0.00005 * (double)std::max(l1, l2));
+		const uint32_t mat = (uint32_t)d->tri_mat[i];
+		const uint32_t vis = (uint32_t)d->materials[mat].visibility & 3u;
+		float mw; const uint32_t packed = mat | (vis << 30); std::memcpy(&mw, &packed, 4);
+		rec[3 * i] = make_float4(v[0], v[1], v[2], eps);
+		rec[3 * i + 1] = make_float4(e1[0], e1[1], e1[2], mw);
+		rec[3 * i + 2] = make_float4(e2[0], e2[1], e2[2], 0.f);
+		float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+		float len = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+		if(len != 0.f) { len = 1.0f / std::sqrt(len); n[0] *= len; n[1] *= len; n[2] *= len; }
+		bool smooth = false;
+		if(d->vnormals)
+		{
+			const float *q = d->vnormals + 9 * i;
+			for(int k = 0; k < 9; ++k) if(q[k] != 0.f) smooth = true;
+		}
+		float sw; const uint32_t sbits = smooth ? 1u : 0u; std::memcpy(&sw, &sbits, 4);
+		ng[i] = make_float4(n[0], n[1], n[2], sw);
+		any_smooth |= smooth;
+	}
+	if(any_smooth)
+	{
+		vn.resize(3 * nt);
+		for(size_t i = 0; i < nt; ++i)
+		{
+			const float *q = d->vnormals + 9 * i;
+			for(int c = 0; c < 3; ++c)
+			{
+				float x = q[3 * c], y = q[3 * c + 1], z = q[3 * c + 2];
+				if(x == 0.f && y == 0.f && z == 0.f) { x = ng[i].x; y = ng[i].y; z = ng[i].z; }
+				vn[3 * i + (size_t)c] = make_float4(x, y, z, 0.f);
+			}
+		}
+	}
+	// QMC tables
+	std::vector<int> faure; std::vector<int> foff(50); std::vector<double> invp(50);
+	for(int dim = 0; dim < 50; ++dim)
+	{
+		foff[(size_t)dim] = (int)faure.size();
+		std::vector<int> p;
+		if(dim < 3) p = {0, 1, 2};      // faure_tables.cc:437: dims 0-2 share the length-3 identity
+		else faure_perm(kPrimsHost[dim], p);
+		faure.insert(faure.end(), p.begin(), p.end());
+		char buf[32];
+		std::snprintf(buf, sizeof buf, "%.9f", 1.0 / (double)kPrimsHost[dim]); // scr_halton.h:37-47 prints 9 decimals
+		invp[(size_t)dim] = std::strtod(buf, nullptr);
+	}
+	int rc = 0;
+	DevScene &dv = s->dev;
+	const uint2 *nodes = nullptr;
+	if((rc = upload(s, (const uint2 *)s->tree.nodes.data(), s->tree.nodes.size(), &nodes))) { yafgpu_scene_destroy(s); return rc; }
+	dv.nodes = nodes;
+	if((rc = upload(s, s->tree.refs.data(), s->tree.refs.size(), &dv.refs))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, rec.data(), rec.size(), &dv.tri))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, ng.data(), ng.size(), &dv.tri_ng))) { yafgpu_scene_destroy(s); return rc; }
+	dv.tri_vn = nullptr;
+	if(any_smooth && (rc = upload(s, vn.data(), vn.size(), &dv.tri_vn))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, d->materials, (size_t)d->n_materials, &dv.mats))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, d->lights, (size_t)d->n_lights, &dv.lights))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, faure.data(), faure.size(), &dv.faure))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, foff.data(), foff.size(), &dv.faure_off))) { yafgpu_scene_destroy(s); return rc; }
+	if((rc = upload(s, invp.data(), invp.size(), &dv.inv_prims))) { yafgpu_scene_destroy(s); return rc; }
+	dv.n_lights = d->n_lights; dv.n_tris = d->n_tris; dv.n_nodes = (uint32_t)s->tree.nodes.size();
+	for(int k = 0; k < 3; ++k) { dv.blo[k] = s->tree.bound_lo[k]; dv.bhi[k] = s->tree.bound_hi[k]; }
+	dv.cam = d->camera;
+	s->mats.assign(d->materials, d->materials + d->n_materials);
+	s->n_lights = d->n_lights;
+	s->info.upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+	(void)t0;
+	*out = s;
+	return 0;
+}
+
+void yafgpu_scene_destroy(yafgpu_scene_t *s)
+{
+	if(!s) return;
+	for(void *p : s->allocs) (void)hipFree(p);
+	if(s->d_tiles) (void)hipFree(s->d_tiles);
+	if(s->d_prefix) (void)hipFree(s->d_prefix);
+	if(s->d_queue) (void)hipFree(s->d_queue);
+	delete s;
+}
+
+int yafgpu_scene_info(const yafgpu_scene_t *s, yafgpu_tree_info *info)
+{
+	if(!s || !info) return fail(-1, "null argument");
+	*info = s->info;
+	return 0;
+}
+
+int yafgpu_scene_get_tree(const yafgpu_scene_t *s, uint32_t *nodes, uint32_t *refs, float bound6[6])
+{
+	if(!s) return fail(-1, "null argument");
+	if(nodes) std::memcpy(nodes, s->tree.nodes.data(), s->tree.nodes.size() * sizeof(KdNode));
+	if(refs) std::memcpy(refs, s->tree.refs.data(), s->tree.refs.size() * sizeof(uint32_t));
+	if(bound6) for(int k = 0; k < 3; ++k) { bound6[k] = s->tree.bound_lo[k]; bound6[3 + k] = s->tree.bound_hi[k]; }
+	return 0;
+}
+
+static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
+{
+	if(rp->width <= 0 || rp->height <= 0 || rp->aa_minsamples <= 0 || rp->tile_size <= 0) return fail(-10, "empty image, sample count or tile size");
+	if(rp->bounces > 12) return fail(-11, "bounces > 12 would use scrHalton dimensions >= 50, which are a global racy LCG in the reference (scr_halton.h:70-73)");
+	if(rp->aa_pixelwidth > 1.002f) return fail(-12, "the GPU film implements the box filter with AA_pixelwidth <= 1.002 (filter half-width 0.501) only");
+	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
+	if(rp->integrator != YAFGPU_INTEGRATOR_PATH && rp->integrator != YAFGPU_INTEGRATOR_DIRECT) return fail(-14, "unknown integrator");
+	(void)s;
+	return 0;
+}
+
+int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float *d_planes, yafgpu_counters *d_counters, void *stream_)
+{
+	if(!s || !rp || !d_planes) return fail(-1, "null argument");
+	int rc = validate(s, rp);
+	if(rc) return rc;
+	hipStream_t stream = (hipStream_t)stream_;
+	RenderArgs ra{};
+	ra.sc = s->dev;
+	ra.rp = *rp;
+	ra.shadow_bias = rp->shadow_bias_auto ? kShadowBias : rp->shadow_bias;     // scene.cc:825
+	ra.ray_min_dist = rp->min_raydist_auto ? kMinRayDist : rp->min_raydist;    // scene.cc:826
+	{	// ImageFilm ctor, imagefilm.cc:127,165 (box: no widening)
+		float fw = (float)((double)rp->aa_pixelwidth * 0.5);
+		ra.filterw = std::min(std::max(0.501f, fw), 0.5f * 8.f);
+	}
+	const int spp = rp->aa_minsamples;
+	ra.lanes_per_pixel = std::min(spp, kWave);
+	ra.pixels_per_wave = kWave / ra.lanes_per_pixel;
+	ra.iters = (spp + ra.lanes_per_pixel - 1) / ra.lanes_per_pixel;
+	// tiles of this shard, row-major (ImageSplitter linear order, imagesplitter.cc:30-60)
+	const int ntx = (rp->width + rp->tile_size - 1) / rp->tile_size, nty = (rp->height + rp->tile_size - 1) / rp->tile_size;
+	std::vector<int4> tiles; std::vector<uint32_t> prefix;
+	prefix.push_back(0u);
+	for(int t = 0; t < ntx * nty; ++t)
+	{
+		if(t % rp->shard_count != rp->shard_index) continue;
+		const int tx = t % ntx, ty = t / ntx;
+		int4 r;
+		r.x = rp->xstart + tx * rp->tile_size; r.y = rp->ystart + ty * rp->tile_size;
+		r.z = std::min(rp->tile_size, rp->xstart + rp->width - r.x); r.w = std::min(rp->tile_size, rp->ystart + rp->height - r.y);
+		tiles.push_back(r);
+		const uint32_t units = (uint32_t)((r.z * r.w + ra.pixels_per_wave - 1) / ra.pixels_per_wave);
+		prefix.push_back(prefix.back() + units);
+	}
+	ra.n_tiles = (int)tiles.size();
+	ra.n_units = prefix.back();
+	HIP_OK(hipMemsetAsync(d_planes, 0, yafgpu_planes_bytes(rp->width, rp->height), stream));
+	if(ra.n_tiles == 0) return 0;
+	if(tiles.size() > s->tiles_cap)
+	{
+		if(s->d_tiles) (void)hipFree(s->d_tiles);
+		if(s->d_prefix) (void)hipFree(s->d_prefix);
+		s->tiles_cap = tiles.size();
+		HIP_OK(hipMalloc((void **)&s->d_tiles, s->tiles_cap * sizeof(int4)));
+		HIP_OK(hipMalloc((void **)&s->d_prefix, (s->tiles_cap + 1) * sizeof(uint32_t)));
+	}
+	if(!s->d_queue) HIP_OK(hipMalloc((void **)&s->d_queue, kQueues * 32 * sizeof(uint32_t)));
+	HIP_OK(hipMemcpyAsync(s->d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
+	HIP_OK(hipMemcpyAsync(s->d_prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+	HIP_OK(hipMemsetAsync(s->d_queue, 0, kQueues * 32 * sizeof(uint32_t), stream));
+	// the pageable staging vectors above must outlive the async copies
+	HIP_OK(hipStreamSynchronize(stream));
+	ra.tile_rect = s->d_tiles; ra.unit_prefix = s->d_prefix; ra.queue_next = s->d_queue;
+	for(int q = 0; q <= kQueues; ++q) ra.queue_begin[q] = (uint32_t)(((uint64_t)ra.n_units * (uint64_t)q) / kQueues);
+	ra.planes = d_planes;
+	ra.counters = d_counters;
+	int dev = 0; hipDeviceProp_t prop;
+	HIP_OK(hipGetDevice(&dev));
+	HIP_OK(hipGetDeviceProperties(&prop, dev));
+	int blocks_per_cu = 0;
+	HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<false>, kBlock, 0));
+	blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+	const uint32_t want = (ra.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
+	const uint32_t grid = std::max(1u, std::min(want, (uint32_t)(prop.multiProcessorCount * blocks_per_cu)));
+	const bool stats = d_counters != nullptr && std::getenv("YAFGPU_STATS") != nullptr;
+	if(stats) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, ra);
+	else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, ra);
+	HIP_OK(hipGetLastError());
+	return 0;
+}
+
+int yafgpu_film_combine(const float *d_planes, float *d_film, int32_t width, int32_t height, void *stream_)
+{
+	if(!d_planes || !d_film || width <= 0 || height <= 0) return fail(-1, "bad argument");
+	const size_t n = (size_t)width * (size_t)height;
+	const uint32_t grid = (uint32_t)std::min<size_t>((n + kBlock - 1) / kBlock, 2048);
+	hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream_, d_planes, d_film, width, height);
+	HIP_OK(hipGetLastError());
+	return 0;
+}
+
+int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, float *h_film, yafgpu_counters *h_counters)
+{
+	if(!s || !rp || !h_film) return fail(-1, "null argument");
+	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
+	const size_t film_bytes = (size_t)rp->width * (size_t)rp->height * YAFGPU_FILM_CHANNELS * sizeof(float);
+	HIP_OK(hipMalloc((void **)&d_planes, yafgpu_planes_bytes(rp->width, rp->height)));
+	HIP_OK(hipMalloc((void **)&d_film, film_bytes));
+	HIP_OK(hipMalloc((void **)&d_cnt, sizeof(yafgpu_counters)));
+	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
+	int rc = yafgpu_render_tiles(s, rp, d_planes, d_cnt, nullptr);
+	if(!rc) rc = yafgpu_film_combine(d_planes, d_film, rp->width, rp->height, nullptr);
+	if(!rc)
+	{
+		hipError_t e = hipDeviceSynchronize();
+		if(e != hipSuccess) rc = fail(-100, std::string("render: ") + hipGetErrorString(e));
+	}
+	if(!rc)
+	{
+		if(hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
+		if(h_counters && hipMemcpy(h_counters, d_cnt, sizeof(yafgpu_counters), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "counter download failed");
+	}
+	(void)hipFree(d_planes); (void)hipFree(d_film); (void)hipFree(d_cnt);
+	return rc;
+}
+
+static int trace_batch(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t *tri, float *t, float *bary, int32_t *shadowed, bool any)
+{
+	if(!s || !rays || n < 0) return fail(-1, "bad argument");
+	if(n == 0) return 0;
+	float *d_rays = nullptr, *d_t = nullptr, *d_b = nullptr; int *d_tri = nullptr, *d_sh = nullptr;
+	HIP_OK(hipMalloc((void **)&d_rays, (size_t)n * 8 * sizeof(float)));
+	HIP_OK(hipMemcpy(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMalloc((void **)&d_tri, (size_t)n * sizeof(int)));
+	HIP_OK(hipMalloc((void **)&d_t, (size_t)n * sizeof(float)));
+	HIP_OK(hipMalloc((void **)&d_b, (size_t)n * 3 * sizeof(float)));
+	HIP_OK(hipMalloc((void **)&d_sh, (size_t)n * sizeof(int)));
+	const uint32_t grid = (uint32_t)std::min((n + kBlock - 1) / kBlock, 4096);
+	if(any) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays, d_tri, d_t, d_b, d_sh);
+	else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays, d_tri, d_t, d_b, d_sh);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipDeviceSynchronize());
+	if(any) HIP_OK(hipMemcpy(shadowed, d_sh, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+	else
+	{
+		HIP_OK(hipMemcpy(tri, d_tri, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(bary, d_b, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+	}
+	(void)hipFree(d_rays); (void)hipFree(d_tri); (void)hipFree(d_t); (void)hipFree(d_b); (void)hipFree(d_sh);
+	return 0;
+}
+
+int yafgpu_trace_closest(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t *tri, float *t, float *bary)
+{
+	if(!tri || !t || !bary) return fail(-1, "null output");
+	return trace_batch(s, n, rays, tri, t, bary, nullptr, false);
+}
+int yafgpu_trace_shadow(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t *shadowed)
+{
+	if(!shadowed) return fail(-1, "null output");
+	return trace_batch(s, n, rays, nullptr, nullptr, nullptr, shadowed, true);
+}
+
+} // extern "C"

@@ -1,0 +1,467 @@
+// Device-side materials, lights and camera of the MI355X path-tracing core.
+// Restated from the reference's virtual Material/Light/Camera implementations as switch-on-type
+// inline functions over POD records (yafgpu.h) — no vtables, no per-hit scratch allocation.
+#pragma once
+#include "yafgpu_math.h"
+#include "../../include/yafgpu.h"
+
+namespace yafgpu {
+
+// BsdfFlags, include/material/material.h:49-64
+enum : uint32_t {
+	kNone = 0, kSpecular = 1, kGlossy = 2, kDiffuse = 4, kDispersive = 8, kReflect = 0x10, kTransmit = 0x20,
+	kFilter = 0x40, kEmit = 0x80, kVolumetric = 0x100,
+	kAll = kSpecular | kGlossy | kDiffuse | kDispersive | kReflect | kTransmit | kFilter
+};
+
+struct SurfPt { V3 p, n, ng, nu, nv; int mat; };                     // the live part of SurfacePoint (surface.h:58-100)
+struct BsdfDat { float c0, c1, c2, c3; float m_diffuse, m_glossy, p_diffuse; }; // SdDat / MDatT
+struct BsdfSample { float s_1, s_2, pdf; uint32_t flags, sampled; }; // Sample, material.h:68-78
+
+YG_DEV Col col3(const float *p) { return mkc(p[0], p[1], p[2]); }
+YG_DEV V3 vec3(const float *p) { return mk(p[0], p[1], p[2]); }
+YG_DEV V3 face_forward(V3 ng, V3 n, V3 i) { return (dot(ng, i) < 0.f) ? -n : n; } // material.h:33
+
+// ShinyDiffuseMaterial::getFresnel, material_shiny_diffuse.cc:119-147
+YG_DEV float sd_fresnel(const yafgpu_material &m, V3 wo, V3 n)
+{
+	if(!m.has_fresnel) return 1.f;
+	const V3 N = (dot(wo, n) < 0.f) ? -n : n;
+	const float c = dot(wo, N);
+	float g = m.ior_squared + c * c - 1.f;
+	if(g < 0.f) g = 0.f;
+	else g = f_sqrt(g);
+	const float aux = c * (g + c);
+	return ((0.5f * (g - c) * (g - c)) / ((g + c) * (g + c))) * (1.f + ((aux - 1.f) * (aux - 1.f)) / ((aux + 1.f) * (aux + 1.f)));
+}
+// accumulate__, :152-161
+YG_DEV void sd_accumulate(const BsdfDat &d, float kr, float acc_out[4])
+{
+	acc_out[0] = d.c0 * kr;
+	float acc = 1.f - acc_out[0];
+	acc_out[1] = d.c1 * acc;
+	acc *= 1.f - d.c1;
+	acc_out[2] = d.c2 * acc;
+	acc *= 1.f - d.c2;
+	acc_out[3] = d.c3 * acc;
+}
+// orenNayar, material_shiny_diffuse.cc:204-241 == material_glossy.cc:74-111
+YG_DEV float oren_nayar(float oa, float ob, V3 wi, V3 wo, V3 n)
+{
+	const float cos_ti = smax(-1.f, smin(1.f, dot(n, wi)));
+	const float cos_to = smax(-1.f, smin(1.f, dot(n, wo)));
+	float maxcos_f = 0.f;
+	if(cos_ti < 0.9999f && cos_to < 0.9999f)
+	{
+		const V3 v_1 = normalize(wi - n * cos_ti);
+		const V3 v_2 = normalize(wo - n * cos_to);
+		maxcos_f = smax(0.f, dot(v_1, v_2));
+	}
+	float sin_alpha, tan_beta;
+	if(cos_to >= cos_ti)
+	{
+		sin_alpha = f_sqrt(1.f - cos_ti * cos_ti);
+		tan_beta = f_sqrt(1.f - cos_to * cos_to) / ((cos_to == 0.f) ? 1e-8f : cos_to);
+	}
+	else
+	{
+		sin_alpha = f_sqrt(1.f - cos_to * cos_to);
+		tan_beta = f_sqrt(1.f - cos_ti * cos_ti) / ((cos_ti == 0.f) ? 1e-8f : cos_ti);
+	}
+	return smin(1.f, smax(0.f, (oa + ob * maxcos_f * sin_alpha * tan_beta)));
+}
+
+// initBsdf: material_shiny_diffuse.cc:163-183 (+getComponents :98-117), material_glossy.cc:51-64
+YG_DEV uint32_t mat_init_bsdf(const yafgpu_material &m, BsdfDat &d)
+{
+	d.c0 = d.c1 = d.c2 = d.c3 = 0.f; d.m_diffuse = d.m_glossy = d.p_diffuse = 0.f;
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	{
+		if(m.is_mirror) d.c0 = m.mirror_strength;
+		if(m.is_transparent) d.c1 = m.transparency_strength;
+		if(m.is_translucent) d.c2 = m.translucency_strength;
+		if(m.is_diffuse) d.c3 = m.diffuse_strength;
+	}
+	else if(m.type == YAFGPU_MAT_GLOSSY)
+	{
+		d.m_diffuse = m.diffuse;
+		d.m_glossy = m.reflectivity;
+		d.p_diffuse = smin(0.6f, 1.f - (d.m_glossy / (d.m_glossy + (1.f - d.m_glossy) * d.m_diffuse)));
+	}
+	return m.bsdf_flags;
+}
+
+// material_utils_microfacet.h
+YG_DEV float blinn_d(float cos_h, float e) { return (e + 1.f) * f_pow(cos_h, e); }                                   // :89-92
+YG_DEV double pdf_divisor(float c) { return (double)8.f * kPi * (double)(c * 0.99f + 0.04f); }                        // :35
+YG_DEV float blinn_pdf(float ct, float cwh, float e) { return (float)((double)blinn_d(ct, e) / pdf_divisor(cwh)); }   // :94-97
+YG_DEV double as_divisor(float c1, float ci, float co) { return (double)8.f * kPi * (double)((c1 * smax(ci, co)) * 0.99f + 0.04f); } // :36
+YG_DEV float schlick_fresnel(float ct, float r) // :188-193
+{
+	const float c_1 = (1.f - ct);
+	const float c_2 = c_1 * c_1;
+	return r + ((1.f - r) * c_1 * c_2 * c_2);
+}
+YG_DEV Col diffuse_reflect(float wi_n, float wo_n, float glossy, float diffuse, Col base) // :195-206
+{
+	float f_wi = (1.f - (0.5f * wi_n));
+	float t = f_wi * f_wi;
+	f_wi = t * t * f_wi;
+	float f_wo = (1.f - (0.5f * wo_n));
+	t = f_wo * f_wo;
+	f_wo = t * t * f_wo;
+	const double k = 0.387507688 * (double)diffuse * (double)(1.f - glossy) * (double)(1.f - f_wi) * (double)(1.f - f_wo);
+	return base * (float)k;
+}
+YG_DEV V3 blinn_sample(float s_1, float s_2, float e) // :99-106
+{
+	const float cos_theta = f_pow(1.f - s_2, 1.f / (e + 1.f));
+	const float sin_theta = f_sqrt(1.f - cos_theta * cos_theta);
+	const float phi = (float)((double)s_1 * k2Pi);
+	return mk(sin_theta * f_cos(phi), sin_theta * f_sin(phi), cos_theta);
+}
+
+// Material::eval — material_shiny_diffuse.cc:244-293, material_glossy.cc:113-173
+YG_DEV Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	{
+		const float cos_ng_wo = dot(sp.ng, wo), cos_ng_wl = dot(sp.ng, wl);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		if(!(bsdfs & m.bsdf_flags & kDiffuse)) return mkc(0.f, 0.f, 0.f);
+		const float kr = sd_fresnel(m, wo, n);
+		const float m_t = (1.f - kr * d.c0) * (1.f - d.c1);
+		if((cos_ng_wo * cos_ng_wl) < 0.f)
+		{
+			if(m.is_translucent) return col3(m.diffuse_color) * (d.c2 * m_t);
+		}
+		if(dot(n, wl) < 0.f && !m.flat) return mkc(0.f, 0.f, 0.f);
+		float m_d = m_t * (1.f - d.c2) * d.c3;
+		if(m.use_oren) m_d *= oren_nayar(m.oren_a, m.oren_b, wo, wl, n);
+		return col3(m.diffuse_color) * m_d;
+	}
+	if(m.type == YAFGPU_MAT_GLOSSY)
+	{
+		if(!(bsdfs & kDiffuse) || (dot(sp.ng, wl) * dot(sp.ng, wo)) < 0.f) return mkc(0.f, 0.f, 0.f);
+		Col col = mkc(0.f, 0.f, 0.f);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		const float wi_n = fabsf(dot(wl, n)), wo_n = fabsf(dot(wo, n));
+		if(m.as_diffuse || (bsdfs & kGlossy))
+		{
+			const V3 h = normalize(wo + wl);
+			const float cos_wi_h = smax(0.f, dot(wl, h));
+			const float glossy = (float)((double)(blinn_d(dot(h, n), m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			col = col3(m.gloss_color) * glossy;
+		}
+		if(m.with_diffuse)
+		{
+			Col add = col3(m.diff_color) * (d.m_diffuse * (1.f - d.m_glossy));
+			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wl, wo, n);
+			col = col + add;
+		}
+		return col;
+	}
+	return mkc(0.f, 0.f, 0.f);
+}
+
+// Material::pdf — material_shiny_diffuse.cc:410-460, material_glossy.cc:359-405
+YG_DEV float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wi, uint32_t bsdfs)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	{
+		if(!(bsdfs & kDiffuse)) return 0.f;
+		float pdf = 0.f, acc[4];
+		const float cos_ng_wo = dot(sp.ng, wo);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		sd_accumulate(d, sd_fresnel(m, wo, n), acc);
+		float sum = 0.f;
+		int n_match = 0;
+		for(int i = 0; i < m.n_bsdf; ++i)
+		{
+			if(bsdfs & m.c_flags[i])
+			{
+				const float width = acc[m.c_index[i]];
+				sum += width;
+				if(m.c_flags[i] == (kDiffuse | kTransmit))
+				{
+					if(cos_ng_wo * dot(sp.ng, wi) < 0.f) pdf += fabsf(dot(wi, n)) * width;
+				}
+				else if(m.c_flags[i] == (kDiffuse | kReflect)) pdf += fabsf(dot(wi, n)) * width;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) return 0.f;
+		return pdf / sum;
+	}
+	if(m.type == YAFGPU_MAT_GLOSSY)
+	{
+		if(dot(sp.ng, wo) * dot(sp.ng, wi) < 0.f) return 0.f;
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		float pdf = 0.f;
+		const bool use_glossy = m.as_diffuse ? (bsdfs & kDiffuse) != 0 : (bsdfs & kGlossy) != 0;
+		const bool use_diffuse = m.with_diffuse && (bsdfs & kDiffuse);
+		if(use_diffuse)
+		{
+			pdf = fabsf(dot(wi, n));
+			if(use_glossy)
+			{
+				const V3 h = normalize(wi + wo);
+				pdf = pdf * d.p_diffuse + blinn_pdf(dot(n, h), dot(wo, h), m.exponent) * (1.f - d.p_diffuse);
+			}
+			return pdf;
+		}
+		if(use_glossy)
+		{
+			const V3 h = normalize(wi + wo);
+			pdf = blinn_pdf(dot(n, h), dot(wo, h), m.exponent);
+		}
+		return pdf;
+	}
+	return 0.f;
+}
+
+// ShinyDiffuseMaterial::getAlpha, :568-597
+YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo)
+{
+	if(!m.is_transparent) return 1.f;
+	const V3 n = face_forward(sp.ng, sp.n, wo);
+	const float kr = sd_fresnel(m, wo, n);
+	return 1.f - (1.f - d.c0 * kr) * d.c1;
+}
+
+// Material::sample — material_shiny_diffuse.cc:308-408, material_glossy.cc:176-357 (Blinn branch),
+// material_simple.cc:41-46
+YG_DEV Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	{
+		float acc[4];
+		const float cos_ng_wo = dot(sp.ng, wo);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		sd_accumulate(d, sd_fresnel(m, wo, n), acc);
+		float sum = 0.f, val[4], width[4];
+		uint32_t choice[4];
+		int n_match = 0, pick = -1;
+		for(int i = 0; i < m.n_bsdf; ++i)
+		{
+			if((s.flags & m.c_flags[i]) == m.c_flags[i])
+			{
+				width[n_match] = acc[m.c_index[i]];
+				sum += width[n_match];
+				choice[n_match] = m.c_flags[i];
+				val[n_match] = sum;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) { s.sampled = kNone; s.pdf = 0.f; return mkc(1.f, 1.f, 1.f); }
+		const float inv_sum = 1.f / sum;
+		for(int i = 0; i < n_match; ++i)
+		{
+			val[i] *= inv_sum;
+			width[i] *= inv_sum;
+			if((s.s_1 <= val[i]) && (pick < 0)) pick = i;
+		}
+		if(pick < 0) pick = n_match - 1;
+		float s_1;
+		if(pick > 0) s_1 = (s.s_1 - val[pick - 1]) / width[pick];
+		else s_1 = s.s_1 / width[pick];
+		Col scolor = mkc(0.f, 0.f, 0.f);
+		const uint32_t ch = choice[pick];
+		if(ch == (kSpecular | kReflect))
+		{
+			wi = reflect_dir(n, wo);
+			s.pdf = width[pick];
+			scolor = col3(m.mirror_color) * acc[0];
+			scolor = scolor * (1.f / smax(fabsf(dot(sp.n, wi)), 1.0e-6f));
+		}
+		else if(ch == (kTransmit | kFilter))
+		{
+			wi = -wo;
+			const float omf = 1.f - m.transmit_filter;
+			scolor = (col3(m.diffuse_color) * m.transmit_filter + mkc(omf, omf, omf)) * acc[1];
+			const float cos_n = fabsf(dot(wi, n));
+			s.pdf = ((double)cos_n < 1e-6) ? 0.f : width[pick];
+		}
+		else if(ch == (kDiffuse | kTransmit))
+		{
+			wi = sample_cos_hemisphere(-n, sp.nu, sp.nv, s_1, s.s_2);
+			if(cos_ng_wo * dot(sp.ng, wi) < 0.f) scolor = col3(m.diffuse_color) * acc[2];
+			s.pdf = fabsf(dot(wi, n)) * width[pick];
+		}
+		else
+		{
+			wi = sample_cos_hemisphere(n, sp.nu, sp.nv, s_1, s.s_2);
+			if(cos_ng_wo * dot(sp.ng, wi) > 0.f) scolor = col3(m.diffuse_color) * acc[3];
+			if(m.use_oren) scolor = scolor * oren_nayar(m.oren_a, m.oren_b, wo, wi, n);
+			s.pdf = fabsf(dot(wi, n)) * width[pick];
+		}
+		s.sampled = ch;
+		w = (fabsf(dot(wi, sp.n))) / (s.pdf * 0.99f + 0.01f);
+		const float alpha = sd_alpha(m, d, sp, wo);
+		w = w * (alpha) + 1.f * (1.f - alpha);
+		return scolor;
+	}
+	if(m.type == YAFGPU_MAT_GLOSSY)
+	{
+		const float cos_ng_wo = dot(sp.ng, wo);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		s.pdf = 0.f;
+		float wi_n = 0.f;
+		const float wo_n = fabsf(dot(wo, n));
+		Col scolor = mkc(0.f, 0.f, 0.f);
+		float s_1 = s.s_1;
+		const float cur_p = d.p_diffuse;
+		const bool use_glossy = m.as_diffuse ? (s.flags & kDiffuse) != 0 : (s.flags & kGlossy) != 0;
+		const bool use_diffuse = m.with_diffuse && (s.flags & kDiffuse);
+		float glossy = 0.f;
+		if(use_diffuse)
+		{
+			const float s_p_diffuse = use_glossy ? cur_p : 1.f;
+			if(s_1 < s_p_diffuse)
+			{
+				s_1 /= s_p_diffuse;
+				wi = sample_cos_hemisphere(n, sp.nu, sp.nv, s_1, s.s_2);
+				if(dot(sp.ng, wi) * cos_ng_wo < 0.f) return scolor;
+				wi_n = fabsf(dot(wi, n));
+				s.pdf = wi_n;
+				if(use_glossy)
+				{
+					const V3 h = normalize(wi + wo);
+					const float cos_wo_h = dot(wo, h);
+					const float cos_wi_h = fabsf(dot(wi, h));
+					const float cos_n_h = dot(n, h);
+					s.pdf = s.pdf * cur_p + blinn_pdf(cos_n_h, cos_wo_h, m.exponent) * (1.f - cur_p);
+					glossy = (float)((double)(blinn_d(cos_n_h, m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+				}
+				s.sampled = kDiffuse | kReflect;
+				if(!(s.flags & kReflect)) return mkc(0.f, 0.f, 0.f);
+				scolor = col3(m.gloss_color) * glossy;
+				Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color));
+				if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+				scolor = scolor + add;
+				w = wi_n / (s.pdf * 0.99f + 0.01f);
+				return scolor;
+			}
+			s_1 -= cur_p;
+			s_1 /= (1.f - cur_p);
+		}
+		if(use_glossy)
+		{
+			const V3 hs = blinn_sample(s_1, s.s_2, m.exponent);
+			V3 h = sp.nu * hs.x + sp.nv * hs.y + n * hs.z;
+			float cos_wo_h = dot(wo, h);
+			if(cos_wo_h < 0.f)
+			{	// Vec3::reflect, vector.h:265-272
+				const float vn = 2.0f * (h.x * n.x + h.y * n.y + h.z * n.z);
+				h = mk(vn * n.x - h.x, vn * n.y - h.y, vn * n.z - h.z);
+				cos_wo_h = dot(wo, h);
+			}
+			wi = reflect_dir(h, wo);
+			if(cos_ng_wo * dot(sp.ng, wi) < 0.f) return mkc(0.f, 0.f, 0.f);
+			wi_n = fabsf(dot(wi, n));
+			const float cos_hn = dot(h, n);
+			s.pdf = blinn_pdf(cos_hn, cos_wo_h, m.exponent);
+			glossy = (float)((double)(blinn_d(cos_hn, m.exponent) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+			scolor = col3(m.gloss_color) * glossy;
+			s.sampled = m.as_diffuse ? (kDiffuse | kReflect) : (kGlossy | kReflect);
+		}
+		if(use_diffuse)
+		{
+			Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color));
+			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+			s.pdf = wi_n * cur_p + s.pdf * (1.f - cur_p);
+			scolor = scolor + add;
+		}
+		w = wi_n / (s.pdf * 0.99f + 0.01f);
+		return scolor;
+	}
+	s.pdf = 0.f; w = 0.f;
+	return mkc(0.f, 0.f, 0.f);
+}
+
+// Material::emit — material_shiny_diffuse.cc:295-306, material_simple.cc:50-57
+YG_DEV Col mat_emit(const yafgpu_material &m, const SurfPt &sp, V3 wo, bool include_lights)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE) return col3(m.emit_color);
+	if(m.type == YAFGPU_MAT_LIGHT)
+	{
+		if(!include_lights) return mkc(0.f, 0.f, 0.f);
+		if(m.double_sided) return col3(m.light_col);
+		return (dot(wo, sp.n) > 0.f) ? col3(m.light_col) : mkc(0.f, 0.f, 0.f);
+	}
+	return mkc(0.f, 0.f, 0.f);
+}
+
+// AreaLight::illumSample, light_area.cc:67-97
+YG_DEV bool arealight_illum_sample(const yafgpu_light &l, V3 sp_p, float s_1, float s_2, V3 &wi_dir, float &wi_tmax, float &pdf)
+{
+	const V3 p = vec3(l.corner) + vec3(l.to_x) * s_1 + vec3(l.to_y) * s_2;
+	V3 ldir = p - sp_p;
+	const float dist_sqr = ldir.x * ldir.x + ldir.y * ldir.y + ldir.z * ldir.z;
+	const float dist = f_sqrt(dist_sqr);
+	if(dist <= 0.f) return false;
+	const float inv = 1.f / dist;
+	ldir.x *= inv; ldir.y *= inv; ldir.z *= inv;
+	const float cos_angle = dot(ldir, vec3(l.fnormal));
+	if(cos_angle <= 0.f) return false;
+	wi_tmax = dist;
+	wi_dir = ldir;
+	pdf = (float)((double)dist_sqr * kPi / (double)(l.area * cos_angle));
+	return true;
+}
+// triIntersect__, light_area.cc:118-137
+YG_DEV bool tri_intersect_plain(V3 a, V3 b, V3 c, V3 from, V3 dir, float &t)
+{
+	const V3 edge_1 = b - a, edge_2 = c - a;
+	const V3 pvec = cross(dir, edge_2);
+	const float det = dot(edge_1, pvec);
+	if(det == 0.f) return false;
+	const float inv_det = 1.0f / det;
+	const V3 tvec = from - a;
+	const float u = dot(tvec, pvec) * inv_det;
+	if(u < 0.f || u > 1.f) return false;
+	const V3 qvec = cross(tvec, edge_1);
+	const float v = dot(dir, qvec) * inv_det;
+	if((v < 0.f) || ((u + v) > 1.f)) return false;
+	t = dot(edge_2, qvec) * inv_det;
+	return true;
+}
+// AreaLight::intersect, light_area.cc:139-155 (returns the INVERSE pdf)
+YG_DEV bool arealight_intersect(const yafgpu_light &l, V3 from, V3 dir, float &t, float &ipdf)
+{
+	const float cos_angle = dot(dir, vec3(l.fnormal));
+	if(cos_angle <= 0.f) return false;
+	if(!tri_intersect_plain(vec3(l.corner), vec3(l.c2), vec3(l.c3), from, dir, t))
+	{
+		if(!tri_intersect_plain(vec3(l.corner), vec3(l.c3), vec3(l.c4), from, dir, t)) return false;
+	}
+	if(!(t > 1.0e-10f)) return false;
+	ipdf = (float)((double)(1.f / (t * t) * l.area * cos_angle) * k1Pi);
+	return true;
+}
+// PointLight::illuminate, light_point.cc:38-56
+YG_DEV bool pointlight_illuminate(const yafgpu_light &l, V3 sp_p, Col &col, V3 &wi_dir, float &wi_tmax)
+{
+	V3 ldir = vec3(l.position) - sp_p;
+	const float dist_sqr = ldir.x * ldir.x + ldir.y * ldir.y + ldir.z * ldir.z;
+	const float dist = f_sqrt(dist_sqr);
+	if(dist == 0.f) return false;
+	const float idist_sqr = 1.f / (dist_sqr);
+	const float inv = 1.f / dist;
+	ldir.x *= inv; ldir.y *= inv; ldir.z *= inv;
+	wi_tmax = dist;
+	wi_dir = ldir;
+	col = col3(l.color) * idist_sqr;
+	return true;
+}
+
+// PerspectiveCamera::shootRay (aperture 0), camera_perspective.cc:133-156; rayPlaneIntersection__ util_geometry.h:34-37
+YG_DEV void camera_shoot(const yafgpu_camera &c, float px, float py, V3 &from, V3 &dir, float &tmin, float &tmax)
+{
+	from = vec3(c.position);
+	dir = normalize(vec3(c.vright) * px + vec3(c.vup) * py + vec3(c.vto));
+	tmin = dot(vec3(c.near_n), vec3(c.near_p) - from) / dot(dir, vec3(c.near_n));
+	tmax = dot(vec3(c.far_n), vec3(c.far_p) - from) / dot(dir, vec3(c.far_n));
+}
+
+} // namespace yafgpu

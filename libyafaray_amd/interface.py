@@ -1,0 +1,338 @@
+"""Host-side mirror of yafaray4::Interface (include/interface/interface.h:48-139) over the C ABI.
+
+Method names and argument meaning follow the reference class (and its SWIG module
+src/bindings/yafaray4_interface.i), so a script written against the reference's Python bindings
+ports by changing the import.  Error behaviour follows the reference too (False / None on failure)
+with the diagnostic available from getLastError(); `strict=True` raises instead.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libyafaray_gpu.so")
+
+
+class YafaRayError(RuntimeError):
+    pass
+
+
+class RenderStats(C.Structure):
+    _fields_ = [
+        ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("interior_steps", C.c_uint64), ("leaves", C.c_uint64),
+        ("tri_tests", C.c_uint64), ("camera_samples", C.c_uint64), ("restarts", C.c_uint64),
+        ("tree_build_seconds", C.c_double), ("upload_seconds", C.c_double), ("render_seconds", C.c_double),
+        ("kd_nodes", C.c_uint32), ("kd_leaf_refs", C.c_uint32), ("kd_max_depth", C.c_uint32), ("n_triangles", C.c_uint32),
+        ("scene_device_bytes", C.c_uint64),
+    ]
+
+
+PUTPIXEL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float)
+FLUSH = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+AREA = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
+class Output(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("putPixel", PUTPIXEL), ("flush", FLUSH), ("flushArea", AREA), ("highlightArea", AREA)]
+
+
+_lib = None
+
+# every symbol include/yafaray_c_api.h and include/yafgpu.h declare (checked by tests/test_abi.py)
+C_API_SYMBOLS = [
+    "yafaray_createInterface", "yafaray_destroyInterface", "yafaray_getLastError", "yafaray_getVersion",
+    "yafaray_startScene", "yafaray_startGeometry", "yafaray_endGeometry", "yafaray_getNextFreeId",
+    "yafaray_startTriMesh", "yafaray_endTriMesh", "yafaray_addVertex", "yafaray_addNormal", "yafaray_addTriangle",
+    "yafaray_smoothMesh", "yafaray_addTriangles",
+    "yafaray_paramsSetPoint", "yafaray_paramsSetString", "yafaray_paramsSetBool", "yafaray_paramsSetInt",
+    "yafaray_paramsSetFloat", "yafaray_paramsSetColor", "yafaray_paramsClearAll", "yafaray_paramsStartList",
+    "yafaray_paramsPushList", "yafaray_paramsEndList",
+    "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
+    "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
+    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_prepareRender",
+    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays",
+]
+GPU_ABI_SYMBOLS = [
+    "yafgpu_last_error", "yafgpu_device_count", "yafgpu_set_device", "yafgpu_scene_create", "yafgpu_scene_destroy",
+    "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host",
+    "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree",
+]
+
+
+def load():
+    """Load libyafaray_gpu.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise YafaRayError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(libyafaray_amd/csrc/build.sh); there is no CPU fallback")
+    L = C.CDLL(p)
+    vp, cp, ci, cd, cf = C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_float
+    sig = {
+        "yafaray_createInterface": (vp, []), "yafaray_destroyInterface": (None, [vp]),
+        "yafaray_getLastError": (cp, [vp]), "yafaray_getVersion": (cp, []),
+        "yafaray_startScene": (ci, [vp, ci]), "yafaray_startGeometry": (ci, [vp]), "yafaray_endGeometry": (ci, [vp]),
+        "yafaray_getNextFreeId": (C.c_uint, [vp]),
+        "yafaray_startTriMesh": (ci, [vp, C.c_uint, ci, ci, ci, ci, ci, ci]), "yafaray_endTriMesh": (ci, [vp]),
+        "yafaray_addVertex": (ci, [vp, cd, cd, cd]), "yafaray_addNormal": (None, [vp, cd, cd, cd]),
+        "yafaray_addTriangle": (ci, [vp, ci, ci, ci, vp]), "yafaray_smoothMesh": (ci, [vp, C.c_uint, cd]),
+        "yafaray_addTriangles": (ci, [vp, ci, C.POINTER(cf), ci, C.POINTER(ci), vp]),
+        "yafaray_paramsSetPoint": (None, [vp, cp, cd, cd, cd]), "yafaray_paramsSetString": (None, [vp, cp, cp]),
+        "yafaray_paramsSetBool": (None, [vp, cp, ci]), "yafaray_paramsSetInt": (None, [vp, cp, ci]),
+        "yafaray_paramsSetFloat": (None, [vp, cp, cd]), "yafaray_paramsSetColor": (None, [vp, cp, cf, cf, cf, cf]),
+        "yafaray_paramsClearAll": (None, [vp]), "yafaray_paramsStartList": (None, [vp]),
+        "yafaray_paramsPushList": (None, [vp]), "yafaray_paramsEndList": (None, [vp]),
+        "yafaray_createLight": (vp, [vp, cp]), "yafaray_createMaterial": (vp, [vp, cp]),
+        "yafaray_createCamera": (vp, [vp, cp]), "yafaray_createBackground": (vp, [vp, cp]),
+        "yafaray_createIntegrator": (vp, [vp, cp]), "yafaray_clearAll": (None, [vp]),
+        "yafaray_render": (ci, [vp, C.POINTER(Output), vp]), "yafaray_abort": (None, [vp]),
+        "yafaray_getRenderedImage": (ci, [vp, ci, C.POINTER(Output)]),
+        "yafaray_getFilm": (ci, [vp, C.POINTER(cf), ci, ci]), "yafaray_getRenderStats": (ci, [vp, C.POINTER(RenderStats)]),
+        "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_prepareRender": (ci, [vp]),
+        "yafaray_renderPassDevice": (ci, [vp, vp, vp, vp]), "yafaray_getRenderSize": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "yafaray_loadXml": (ci, [vp, cp]),
+        "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
+        "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
+        "yafgpu_last_error": (cp, []), "yafgpu_device_count": (ci, []), "yafgpu_set_device": (ci, [ci]),
+        "yafgpu_planes_bytes": (C.c_uint64, [ci, ci]),
+        "yafgpu_film_combine": (ci, [vp, vp, ci, ci, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+class Interface:
+    """yafaray4::Interface.  See include/yafaray_c_api.h for the per-method reference citations."""
+
+    def __init__(self, strict=True):
+        self._L = load()
+        self._h = self._L.yafaray_createInterface()
+        self.strict = strict
+        self._keep = []
+
+    # -- plumbing
+    def close(self):
+        if self._h:
+            self._L.yafaray_destroyInterface(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def getLastError(self):
+        return self._L.yafaray_getLastError(self._h).decode()
+
+    def getVersion(self):
+        return self._L.yafaray_getVersion().decode()
+
+    def _ok(self, r, what):
+        if not r and self.strict:
+            raise YafaRayError(f"{what}: {self.getLastError()}")
+        return bool(r)
+
+    def _obj(self, r, what):
+        if not r and self.strict:
+            raise YafaRayError(f"{what}: {self.getLastError()}")
+        return r
+
+    # -- scene
+    def startScene(self, type=0):
+        return self._ok(self._L.yafaray_startScene(self._h, type), "startScene")
+
+    def startGeometry(self):
+        return self._ok(self._L.yafaray_startGeometry(self._h), "startGeometry")
+
+    def endGeometry(self):
+        return self._ok(self._L.yafaray_endGeometry(self._h), "endGeometry")
+
+    def getNextFreeId(self):
+        return self._L.yafaray_getNextFreeId(self._h)
+
+    def startTriMesh(self, id, vertices, triangles, has_orco, has_uv=False, type=0, obj_pass_index=0):
+        return self._ok(self._L.yafaray_startTriMesh(self._h, id, vertices, triangles, int(has_orco), int(has_uv), type,
+                                                     obj_pass_index), "startTriMesh")
+
+    def endTriMesh(self):
+        return self._ok(self._L.yafaray_endTriMesh(self._h), "endTriMesh")
+
+    def addVertex(self, x, y, z):
+        return self._L.yafaray_addVertex(self._h, x, y, z)
+
+    def addNormal(self, nx, ny, nz):
+        self._L.yafaray_addNormal(self._h, nx, ny, nz)
+
+    def addTriangle(self, a, b, c, mat):
+        return self._ok(self._L.yafaray_addTriangle(self._h, a, b, c, mat), "addTriangle")
+
+    def addTriangles(self, verts, indices, mat):
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        return self._ok(self._L.yafaray_addTriangles(self._h, v.shape[0], v.ctypes.data_as(C.POINTER(C.c_float)), i.shape[0],
+                                                     i.ctypes.data_as(C.POINTER(C.c_int)), mat), "addTriangles")
+
+    def smoothMesh(self, id, angle):
+        return self._ok(self._L.yafaray_smoothMesh(self._h, id, angle), "smoothMesh")
+
+    # -- params
+    def paramsSetPoint(self, name, x, y, z):
+        self._L.yafaray_paramsSetPoint(self._h, _b(name), x, y, z)
+
+    def paramsSetString(self, name, s):
+        self._L.yafaray_paramsSetString(self._h, _b(name), _b(s))
+
+    def paramsSetBool(self, name, b):
+        self._L.yafaray_paramsSetBool(self._h, _b(name), int(b))
+
+    def paramsSetInt(self, name, i):
+        self._L.yafaray_paramsSetInt(self._h, _b(name), int(i))
+
+    def paramsSetFloat(self, name, f):
+        self._L.yafaray_paramsSetFloat(self._h, _b(name), float(f))
+
+    def paramsSetColor(self, name, r, g, b, a=1.0):
+        self._L.yafaray_paramsSetColor(self._h, _b(name), r, g, b, a)
+
+    def paramsClearAll(self):
+        self._L.yafaray_paramsClearAll(self._h)
+
+    def paramsStartList(self):
+        self._L.yafaray_paramsStartList(self._h)
+
+    def paramsPushList(self):
+        self._L.yafaray_paramsPushList(self._h)
+
+    def paramsEndList(self):
+        self._L.yafaray_paramsEndList(self._h)
+
+    def paramsSet(self, d):
+        """Convenience: fill the ParamMap from a dict, typed like the XML grammar (import_xml.cc:273-318):
+        str -> sval, bool -> bval, int -> ival, float -> fval, 3-tuple -> point, ('color', r,g,b[,a]) -> colour."""
+        for k, v in d.items():
+            if isinstance(v, str):
+                self.paramsSetString(k, v)
+            elif isinstance(v, bool):
+                self.paramsSetBool(k, v)
+            elif isinstance(v, (int, np.integer)):
+                self.paramsSetInt(k, v)
+            elif isinstance(v, (float, np.floating)):
+                self.paramsSetFloat(k, v)
+            elif isinstance(v, tuple) and len(v) in (4, 5) and v[0] == "color":
+                self.paramsSetColor(k, *[float(t) for t in v[1:]])
+            elif len(v) == 3:
+                self.paramsSetPoint(k, float(v[0]), float(v[1]), float(v[2]))
+            else:
+                raise TypeError(f"parameter {k}: {v!r}")
+
+    # -- factories
+    def createLight(self, name):
+        return self._obj(self._L.yafaray_createLight(self._h, _b(name)), "createLight")
+
+    def createMaterial(self, name):
+        return self._obj(self._L.yafaray_createMaterial(self._h, _b(name)), "createMaterial")
+
+    def createCamera(self, name):
+        return self._obj(self._L.yafaray_createCamera(self._h, _b(name)), "createCamera")
+
+    def createBackground(self, name):
+        return self._obj(self._L.yafaray_createBackground(self._h, _b(name)), "createBackground")
+
+    def createIntegrator(self, name):
+        return self._obj(self._L.yafaray_createIntegrator(self._h, _b(name)), "createIntegrator")
+
+    def clearAll(self):
+        self._L.yafaray_clearAll(self._h)
+
+    # -- render
+    def render(self, output=None, progress=None):
+        out = None
+        if output is not None:
+            out = Output()
+            pp = PUTPIXEL(lambda u, v, x, y, r, g, b, a: int(bool(output.putPixel(v, x, y, (r, g, b, a)))))
+            fl = FLUSH(lambda u, v: output.flush(v) if hasattr(output, "flush") else None)
+            self._keep = [pp, fl]
+            out.putPixel = pp
+            out.flush = fl
+        return self._ok(self._L.yafaray_render(self._h, C.byref(out) if out is not None else None, None), "render")
+
+    def abort(self):
+        self._L.yafaray_abort(self._h)
+
+    def loadXml(self, path):
+        return self._ok(self._L.yafaray_loadXml(self._h, _b(path)), "loadXml")
+
+    # -- additions (measurement / multi-GPU)
+    def setShard(self, index, count):
+        self._L.yafaray_setShard(self._h, index, count)
+
+    def prepareRender(self):
+        return self._ok(self._L.yafaray_prepareRender(self._h), "prepareRender")
+
+    def getRenderSize(self):
+        w, h = C.c_int(), C.c_int()
+        self._ok(self._L.yafaray_getRenderSize(self._h, C.byref(w), C.byref(h)), "getRenderSize")
+        return w.value, h.value
+
+    def renderPassDevice(self, d_planes, d_counters=0, stream=0):
+        return self._ok(self._L.yafaray_renderPassDevice(self._h, C.c_void_p(d_planes), C.c_void_p(d_counters or None),
+                                                         C.c_void_p(stream or None)), "renderPassDevice")
+
+    def intersectRays(self, rays):
+        """rays (n,8) float32 -> (tri (n,) int32, t (n,), bary (n,3))"""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        tri = np.zeros(n, np.int32); t = np.zeros(n, np.float32); bary = np.zeros((n, 3), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._ok(self._L.yafaray_intersectRays(self._h, n, r.ctypes.data_as(fp), tri.ctypes.data_as(C.POINTER(C.c_int)),
+                                               t.ctypes.data_as(fp), bary.ctypes.data_as(fp)), "intersectRays")
+        return tri, t, bary
+
+    def shadowRays(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        sh = np.zeros(r.shape[0], np.int32)
+        self._ok(self._L.yafaray_shadowRays(self._h, r.shape[0], r.ctypes.data_as(C.POINTER(C.c_float)),
+                                            sh.ctypes.data_as(C.POINTER(C.c_int))), "shadowRays")
+        return sh
+
+    def getFilm(self, width, height):
+        film = np.zeros((height, width, 5), dtype=np.float32)
+        self._ok(self._L.yafaray_getFilm(self._h, film.ctypes.data_as(C.POINTER(C.c_float)), width, height), "getFilm")
+        return film
+
+    def getRenderStats(self):
+        s = RenderStats()
+        self._L.yafaray_getRenderStats(self._h, C.byref(s))
+        return s
+
+
+def planes_bytes(width, height):
+    return load().yafgpu_planes_bytes(width, height)
+
+
+def film_combine(d_planes, d_film, width, height, stream=0):
+    rc = load().yafgpu_film_combine(C.c_void_p(d_planes), C.c_void_p(d_film), width, height, C.c_void_p(stream or None))
+    if rc:
+        raise YafaRayError(load().yafgpu_last_error().decode())
+
+
+def film_to_rgba(film):
+    """Pixel::normalized (util_image_buffers.h:39-43)."""
+    w = film[..., 4:5]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(w != 0, film[..., :4] / w, 0.0).astype(np.float32)

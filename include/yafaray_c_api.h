@@ -131,6 +131,8 @@ yafaray_bool_t yafaray_getRenderSize(yafaray_interface_t *yi, int *width, int *h
  * rays = n*8 floats {from.xyz, dir.xyz, tmin, tmax (<0 = infinite)}; tri = -1 on a miss */
 yafaray_bool_t yafaray_intersectRays(yafaray_interface_t *yi, int n, const float *rays, int *tri, float *t, float *bary);
 yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *rays, int *shadowed);
+/* device-side component probe (yafgpu_probe) against the prepared scene's materials/lights/camera */
+yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float *in, int n_in, float *out, int n_out);
 
 /* XML scene loader: src/loader_xml/loader_xml.cc + src/common/import_xml.cc drive the same calls
  * from a scene file.  Parses `path` and leaves the interface ready for yafaray_render. */

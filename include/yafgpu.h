@@ -151,6 +151,12 @@ int yafgpu_render_to_host(yafgpu_scene_t *scene, const yafgpu_render_params *rp,
 int yafgpu_trace_closest(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *tri, float *t, float *bary);
 int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *shadowed);
 
+/* Component probe for tests: evaluates device-side leaf functions (fast-math, QMC, camera, lights,
+ * material eval/pdf/sample) on n items of n_in floats each, writing n_out floats each; `op` selects the
+ * function (see probe_kernel in yafgpu_device.hip).  Lets the device code be pinned against the
+ * reference's own golden vectors independently of any render. */
+int yafgpu_probe(yafgpu_scene_t *scene, int32_t op, int32_t n, const float *in, int32_t n_in, float *out, int32_t n_out);
+
 /* kd-tree built on the host, downloadable for inspection/tests: nodes = n_nodes*2 uint32, refs = n_leaf_refs uint32 */
 int yafgpu_scene_get_tree(const yafgpu_scene_t *scene, uint32_t *nodes, uint32_t *refs, float bound6[6]);
 

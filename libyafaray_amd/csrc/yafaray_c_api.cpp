@@ -643,6 +643,13 @@ yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *r
 	return 1;
 }
 
+yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float *in, int n_in, float *out, int n_out)
+{
+	if(!yi->prepared) return fail(yi, "probe: call prepareRender first");
+	if(yafgpu_probe(yi->gpu, op, n, in, n_in, out, n_out)) return fail(yi, std::string("probe: ") + yafgpu_last_error());
+	return 1;
+}
+
 static float srgb_from_linear(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f; }
 
 static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)

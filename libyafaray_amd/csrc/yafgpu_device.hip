@@ -771,6 +771,109 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const DevScene sc, int n,
 	}
 }
 
+// Component probe: evaluates the device-side restatements of the reference's leaf functions on
+// arrays, so that tests can pin them against the reference's own golden vectors (tests/golden).
+// Integers travel as float bit patterns.  One thread per item; no LDS, no traversal.
+__global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op, int n, const float *in, int n_in, float *out, int n_out)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if(i >= n) return;
+	const float *x = in + (size_t)i * (size_t)n_in;
+	float *o = out + (size_t)i * (size_t)n_out;
+	switch(op)
+	{
+		case 1:
+		{
+			const float ax = fabsf(x[0]) + 1e-3f;
+			o[0] = f_sin(x[0]); o[1] = f_cos(x[0]); o[2] = f_exp2(x[0]); o[3] = f_log2(ax); o[4] = f_sqrt(ax);
+			break;
+		}
+		case 2: o[0] = f_pow(x[0], x[1]); break;
+		case 3:
+		{
+			const uint32_t bits = __float_as_uint(x[0]), r = __float_as_uint(x[1]);
+			o[0] = ri_vdc(bits, r); o[1] = ri_lp(bits, r); o[2] = __uint_as_float(fnv32a(bits));
+			break;
+		}
+		case 4:
+		{
+			const double v = scr_halton(sc, (int)__float_as_uint(x[0]), __float_as_uint(x[1]));
+			o[0] = (float)v;
+			o[1] = __uint_as_float((uint32_t)(__double_as_longlong(v) & 0xffffffffll));
+			o[2] = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(v) >> 32));
+			break;
+		}
+		case 5:
+		{
+			Halton h; h.init(__float_as_uint(x[0])); h.set_start(__float_as_uint(x[1]));
+			for(int k = 0; k < 6; ++k) o[k] = h.next();
+			break;
+		}
+		case 6:
+		{
+			const V3 nn = mk(x[0], x[1], x[2]);
+			V3 u, v; create_cs(nn, u, v);
+			const V3 w = sample_cos_hemisphere(nn, u, v, x[3], x[4]);
+			o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = v.x; o[4] = v.y; o[5] = v.z; o[6] = w.x; o[7] = w.y; o[8] = w.z;
+			break;
+		}
+		case 7:
+		{
+			V3 f, d; float t0, t1;
+			camera_shoot(sc.cam, x[0], x[1], f, d, t0, t1);
+			o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = t0; o[7] = t1; o[8] = 1.f;
+			break;
+		}
+		case 8:
+		{
+			const yafgpu_light &l = sc.lights[0];
+			V3 d = mk(0.f, 0.f, 0.f); float tmax = 0.f, pdf = 0.f;
+			const bool ok = arealight_illum_sample(l, mk(x[0], x[1], x[2]), x[3], x[4], d, tmax, pdf);
+			o[0] = ok ? 1.f : 0.f;
+			o[1] = ok ? d.x : 0.f; o[2] = ok ? d.y : 0.f; o[3] = ok ? d.z : 0.f; o[4] = ok ? tmax : 0.f; o[5] = ok ? pdf : 0.f;
+			o[6] = ok ? l.color[0] : 0.f; o[7] = ok ? l.color[1] : 0.f; o[8] = ok ? l.color[2] : 0.f;
+			break;
+		}
+		case 9:
+		{
+			const yafgpu_light &l = sc.lights[0];
+			float t = 0.f, ipdf = 0.f;
+			const bool ok = arealight_intersect(l, mk(x[0], x[1], x[2]), mk(x[3], x[4], x[5]), t, ipdf);
+			o[0] = ok ? 1.f : 0.f; o[1] = ok ? t : 0.f; o[2] = ok ? ipdf : 0.f;
+			o[3] = ok ? l.color[0] : 0.f; o[4] = ok ? l.color[1] : 0.f; o[5] = ok ? l.color[2] : 0.f;
+			break;
+		}
+		case 10:
+		{
+			const yafgpu_light &l = sc.lights[1];
+			Col c = mkc(0.f, 0.f, 0.f); V3 d = mk(0.f, 0.f, 0.f); float tmax = 0.f;
+			pointlight_illuminate(l, mk(x[0], x[1], x[2]), c, d, tmax);
+			o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = tmax; o[4] = c.r; o[5] = c.g; o[6] = c.b;
+			break;
+		}
+		case 11:
+		{	// x = material index, n, ng, wo, wl, s1, s2, sample flags
+			const yafgpu_material &m = sc.mats[__float_as_uint(x[0])];
+			SurfPt sp; sp.n = mk(x[1], x[2], x[3]); sp.ng = mk(x[4], x[5], x[6]); sp.p = mk(0.f, 0.f, 0.f); sp.mat = 0;
+			create_cs(sp.n, sp.nu, sp.nv);
+			const V3 wo = mk(x[7], x[8], x[9]), wl = mk(x[10], x[11], x[12]);
+			BsdfDat d;
+			const uint32_t fl = mat_init_bsdf(m, d);
+			const Col e = mat_eval(m, d, sp, wo, wl, kAll);
+			const float pdf = mat_pdf(m, d, sp, wo, wl, kGlossy | kDiffuse | kDispersive | kReflect | kTransmit);
+			BsdfSample bs; bs.s_1 = x[13]; bs.s_2 = x[14]; bs.pdf = 0.f; bs.flags = __float_as_uint(x[15]); bs.sampled = kNone;
+			V3 wi = mk(0.f, 0.f, 0.f); float w = 0.f;
+			const Col sc_ = mat_sample(m, d, sp, wo, wi, bs, w);
+			o[0] = __uint_as_float(fl); o[1] = e.r; o[2] = e.g; o[3] = e.b; o[4] = pdf; o[5] = __uint_as_float(bs.sampled);
+			o[6] = sc_.r; o[7] = sc_.g; o[8] = sc_.b; o[9] = wi.x; o[10] = wi.y; o[11] = wi.z; o[12] = bs.pdf; o[13] = w;
+			const Col em = mat_emit(m, sp, wo, x[15] != 0.f);
+			o[14] = em.r; o[15] = em.g; o[16] = em.b;
+			break;
+		}
+		default: break;
+	}
+}
+
 } // namespace yafgpu
 
 // ================================================================================================
@@ -1132,6 +1235,23 @@ int yafgpu_trace_shadow(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t
 {
 	if(!shadowed) return fail(-1, "null output");
 	return trace_batch(s, n, rays, nullptr, nullptr, nullptr, shadowed, true);
+}
+
+int yafgpu_probe(yafgpu_scene_t *s, int32_t op, int32_t n, const float *in, int32_t n_in, float *out, int32_t n_out)
+{
+	if(!s || !in || !out || n < 0 || n_in <= 0 || n_out <= 0) return fail(-1, "bad argument");
+	if(n == 0) return 0;
+	float *d_in = nullptr, *d_out = nullptr;
+	HIP_OK(hipMalloc((void **)&d_in, (size_t)n * (size_t)n_in * sizeof(float)));
+	HIP_OK(hipMalloc((void **)&d_out, (size_t)n * (size_t)n_out * sizeof(float)));
+	HIP_OK(hipMemcpy(d_in, in, (size_t)n * (size_t)n_in * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipMemset(d_out, 0, (size_t)n * (size_t)n_out * sizeof(float)));
+	hipLaunchKernelGGL(probe_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, s->dev, op, n, d_in, n_in, d_out, n_out);
+	HIP_OK(hipGetLastError());
+	HIP_OK(hipDeviceSynchronize());
+	HIP_OK(hipMemcpy(out, d_out, (size_t)n * (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost));
+	(void)hipFree(d_in); (void)hipFree(d_out);
+	return 0;
 }
 
 } // extern "C"

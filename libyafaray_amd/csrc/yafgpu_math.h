@@ -68,7 +68,8 @@ YG_DEV float f_log2(float x) // :131-142 ; POLYLOG :94 turns double at the unsuf
 	return ((float)ee * (m - 1.0f) + e);
 }
 YG_DEV float f_pow(float a, float b) { return f_exp2(f_log2(a) * b); } // :176-183
-YG_DEV float f_sqrt(float a) { return __fsqrt_rn(a); }               // :203-210 -> sqrt
+// NB: __fsqrt_rn lowers to the bare 1-ulp v_sqrt_f32 on gfx950; sqrtf gets the correctly rounded fix-up sequence
+YG_DEV float f_sqrt(float a) { return __builtin_sqrtf(a); }          // :203-210 -> sqrt
 YG_DEV float f_sin(float x) // :222-244
 {
 	if((double)x > k2Pi || (double)x < -k2Pi) x -= ((int)(x * (float)k12Pi)) * (float)k2Pi;

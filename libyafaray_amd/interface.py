@@ -54,12 +54,12 @@ C_API_SYMBOLS = [
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
     "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_prepareRender",
-    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays",
+    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe",
 ]
 GPU_ABI_SYMBOLS = [
     "yafgpu_last_error", "yafgpu_device_count", "yafgpu_set_device", "yafgpu_scene_create", "yafgpu_scene_destroy",
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host",
-    "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree",
+    "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
         "yafaray_loadXml": (ci, [vp, cp]),
         "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
         "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
+        "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
         "yafgpu_last_error": (cp, []), "yafgpu_device_count": (ci, []), "yafgpu_set_device": (ci, [ci]),
         "yafgpu_planes_bytes": (C.c_uint64, [ci, ci]),
         "yafgpu_film_combine": (ci, [vp, vp, ci, ci, vp]),
@@ -309,6 +310,15 @@ class Interface:
         self._ok(self._L.yafaray_shadowRays(self._h, r.shape[0], r.ctypes.data_as(C.POINTER(C.c_float)),
                                             sh.ctypes.data_as(C.POINTER(C.c_int))), "shadowRays")
         return sh
+
+    def probe(self, op, inp, n_out):
+        """device-side component probe; inp (n, n_in) float32 (integers as bit patterns) -> (n, n_out) float32"""
+        x = np.ascontiguousarray(inp, dtype=np.float32)
+        x = x.reshape(x.shape[0], -1)
+        out = np.zeros((x.shape[0], n_out), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._ok(self._L.yafaray_probe(self._h, op, x.shape[0], x.ctypes.data_as(fp), x.shape[1], out.ctypes.data_as(fp), n_out), "probe")
+        return out
 
     def getFilm(self, width, height):
         film = np.zeros((height, width, 5), dtype=np.float32)

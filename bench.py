@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the path-tracing hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
+
+A *step* is one full render pass of the workload's frame through the C ABI (renderPassDevice ->
+yafgpu_render_tiles, then the film combine; for N > 1 each rank renders its tile shard and the
+float film planes are sum-reduced to rank 0 over RCCL).  A *ray* is one kd-tree query (closest-hit
+or any-hit), counted by device atomics.  The scene is uploaded and its kd-tree built before the timed
+region (reported separately); inputs are resident in HBM when timing starts.
+
+Workloads (BASELINE.json configs):
+  c2  100k-triangle diffuse Cornell box, 512x512, 64 spp, primary + 1 bounce            (default, configs[1])
+  c3  1M-triangle diffuse soup, 1024x1024, 256 spp, 2 bounces                           (configs[2])
+  c4  1M-triangle soup, 50% glossy, 2 area lights (BSDF sampling + MIS), 1024x1024, 64 spp  (configs[3])
+
+Output: one JSON line with the contract fields plus `roofline` (dominant kernel: render_kernel, HBM
+bound, algorithmic bytes / measured launch time) and `cpu_baseline` (the CPU oracle — a port of the
+reference's algorithm — timed on a bounded sample of the same scene on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "c2": dict(desc="100k-tri diffuse Cornell box 512x512 64spp primary+1-bounce", n_tris=100_000, res=512, spp=64, bounces=1,
+               glossy=0.0, lights=1, sigma=0.02, seed=1234),
+    "c3": dict(desc="1M-tri diffuse soup 1024x1024 256spp 2 bounces", n_tris=1_000_000, res=1024, spp=256, bounces=2,
+               glossy=0.0, lights=1, sigma=0.01, seed=1),
+    "c4": dict(desc="1M-tri soup 50% glossy + 2 area lights (MIS) 1024x1024 64spp 2 bounces", n_tris=1_000_000, res=1024, spp=64,
+               bounces=2, glossy=0.5, lights=2, sigma=0.01, seed=1),
+}
+
+
+def make_workload(name, res=None, spp=None):
+    from libyafaray_amd import scenes
+    w = dict(WORKLOADS[name])
+    if res:
+        w["res"] = res
+    if spp:
+        w["spp"] = spp
+    sc = scenes.cornell_soup(w["n_tris"], seed=w["seed"], sigma=w["sigma"], glossy_fraction=w["glossy"], n_lights=w["lights"],
+                             res=(w["res"], w["res"]))
+    rd = scenes.render_settings(w["res"], w["res"], w["spp"], bounces=w["bounces"])
+    return w, sc, rd
+
+
+def cpu_baseline(name, budget_s=15.0):
+    """Time the CPU oracle (multi-threaded port of the reference path) on a bounded sample of the workload:
+    the same scene at reduced resolution / samples per pixel, sized from a pilot run to ~budget_s of CPU wall."""
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # pilot at 64x64x2 to size the sample; the camera resolution is part of the scene, so each size is its own scene
+    w, sc, rd = make_workload(name, res=64)
+    t0 = time.time()
+    osc = po.OracleScene(sc)            # kd build is setup, not timed
+    build_s = time.time() - t0
+    _, st = osc.render(dict(rd, AA_minsamples=2, oracle_threads=cores))
+    osc.close()
+    rate = (st.rays_closest + st.rays_shadow) / max(st.render_seconds, 1e-6)
+    rays_per_sample = (st.rays_closest + st.rays_shadow) / max(st.camera_samples, 1)
+    samples = budget_s * rate / rays_per_sample
+    spp = w["spp"]
+    sres = int(max(32, min(WORKLOADS[name]["res"], (samples / spp) ** 0.5))) // 32 * 32
+    w, sc, rd = make_workload(name, res=sres)
+    osc = po.OracleScene(sc)
+    _, st = osc.render(dict(rd, AA_minsamples=spp, oracle_threads=cores))
+    rays = st.rays_closest + st.rays_shadow
+    osc.close()
+    return {"value": round(rays / st.render_seconds / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"same scene ({w['n_tris']} tris), {sres}x{sres} px, {spp} spp, {rays} rays in {st.render_seconds:.2f} s "
+                      f"(oracle kd build {build_s:.1f} s excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--res", type=int, default=0, help="override resolution (debug)")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from libyafaray_amd import Interface, scenes, interface as yi_mod
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, sc, rd = make_workload(args.workload, args.res, args.spp)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.setShard(rank, world)            # pixel-tile sharding: tile t -> rank t % world
+    t0 = time.time()
+    yi.prepareRender()                  # Scene::update: kd-tree build + upload (untimed, reported)
+    setup_s = time.time() - t0
+    stats0 = yi.getRenderStats()
+    W, H = yi.getRenderSize()
+
+    planes = torch.zeros((4, H, W, 5), dtype=torch.float32, device=dev)
+    film = torch.zeros((H, W, 5), dtype=torch.float32, device=dev)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(planes, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    counters.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.reduce(planes, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # render_kernel (+ its memset/tile upload), same stream
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = counters.clone()
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    c = cnt.cpu().numpy()
+    rays_total = int(c[0] + c[1])
+    value = rays_total / elapsed / 1e6
+
+    # per-ray traversal averages for the algorithmic-bytes figure: one extra, untimed launch of the
+    # counting variant of the kernel (YAFGPU_STATS)
+    os.environ["YAFGPU_STATS"] = "1"
+    counters.zero_()
+    yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
+    torch.cuda.synchronize()
+    del os.environ["YAFGPU_STATS"]
+    s = counters.cpu().numpy().astype(np.float64)
+    rays_launch = s[0] + s[1]
+    n_int, n_leaf, n_tri = s[2] / rays_launch, s[3] / rays_launch, s[4] / rays_launch
+    # bytes/ray = 32 (ray) + 16 (hit) + 8*(interior+leaf nodes) + 4*leaf refs + 48*triangle records
+    bytes_per_ray = 32 + 16 + 8 * (n_int + n_leaf) + 4 * n_tri + 48 * n_tri
+    # + film traffic: 4 planes zeroed + the owned pixels written once per launch (20 B/pixel/plane)
+    film_bytes = 2 * 4 * H * W * 5 * 4 / max(world, 1)
+    achieved = (bytes_per_ray * rays_launch + film_bytes) / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec (primary+secondary) on the path-tracing hot path", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "triangles": int(stats0.n_triangles), "width": W, "height": H, "spp": w["spp"],
+                       "bounces": w["bounces"], "lights": w["lights"], "parallelism": f"pixel-tile shard x{world}",
+                       "rays_per_step": rays_total // args.steps, "rays_per_camera_sample": round(rays_total / max(int(c[5]), 1), 3),
+                       "kd_nodes": int(stats0.kd_nodes), "kd_leaf_refs": int(stats0.kd_leaf_refs), "kd_max_depth": int(stats0.kd_max_depth),
+                       "scene_device_MB": round(stats0.scene_device_bytes / 1e6, 1), "setup_s": round(setup_s, 2),
+                       "tree_build_s": round(stats0.tree_build_seconds, 2)},
+            "roofline": {"bound": "hbm", "kernel": "render_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(bytes_per_ray, 1),
+                         "per_ray": {"interior_nodes": round(n_int, 2), "leaves": round(n_leaf, 2), "tri_tests": round(n_tri, 2),
+                                     "restarts": round(s[6] / rays_launch, 5)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

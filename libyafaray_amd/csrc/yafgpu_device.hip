@@ -39,7 +39,13 @@ namespace yafgpu {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kStack = 16;            // per-lane LDS stack slots (power of two)
+#ifndef YAFGPU_STACK
+#define YAFGPU_STACK 16
+#endif
+#ifndef YAFGPU_WAVES
+#define YAFGPU_WAVES 1                // __launch_bounds__ minimum waves per SIMD for the render kernel
+#endif
+constexpr int kStack = YAFGPU_STACK;  // per-lane LDS stack slots (power of two)
 constexpr int kDepthCap = 48;         // host tree depth cap; deeper pending lists restart
 constexpr int kQueues = 8;            // one per XCD
 constexpr float kMinRayDist = (float)0.00005;   // MIN_RAYDIST, CMakeLists.txt:46-48
@@ -601,7 +607,7 @@ YG_DEV uint32_t wave_sum(uint32_t v)
 // (filterw = 0.501 after the clamp at :165): a sample lands on its own pixel and, when dx (dy)
 // >= 0.999, also on the right (lower) neighbour, weight 1 each.
 template<bool kStats>
-__global__ __launch_bounds__(kBlock) void render_kernel(const RenderArgs ra)
+__global__ __launch_bounds__(kBlock, YAFGPU_WAVES) void render_kernel(const RenderArgs ra)
 {
 	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
@@ -894,6 +900,9 @@ struct yafgpu_scene
 	int n_lights = 0;
 	// per-render scratch, grown on demand
 	int4 *d_tiles = nullptr; uint32_t *d_prefix = nullptr; uint32_t *d_queue = nullptr; size_t tiles_cap = 0;
+	// the tile list of the last launch stays resident; it is re-uploaded only when its key changes
+	std::vector<int4> h_tiles; std::vector<uint32_t> h_prefix;
+	int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 };
 
 template<typename T> static int upload(yafgpu_scene *s, const T *src, size_t n, const T **dst)
@@ -1113,38 +1122,46 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	ra.pixels_per_wave = kWave / ra.lanes_per_pixel;
 	ra.iters = (spp + ra.lanes_per_pixel - 1) / ra.lanes_per_pixel;
 	// tiles of this shard, row-major (ImageSplitter linear order, imagesplitter.cc:30-60)
-	const int ntx = (rp->width + rp->tile_size - 1) / rp->tile_size, nty = (rp->height + rp->tile_size - 1) / rp->tile_size;
-	std::vector<int4> tiles; std::vector<uint32_t> prefix;
-	prefix.push_back(0u);
-	for(int t = 0; t < ntx * nty; ++t)
+	const int key[8] = {rp->width, rp->height, rp->xstart, rp->ystart, rp->tile_size, rp->shard_index, rp->shard_count, ra.pixels_per_wave};
+	const bool same = std::memcmp(key, s->tile_key, sizeof key) == 0;
+	if(!same)
 	{
-		if(t % rp->shard_count != rp->shard_index) continue;
-		const int tx = t % ntx, ty = t / ntx;
-		int4 r;
-		r.x = rp->xstart + tx * rp->tile_size; r.y = rp->ystart + ty * rp->tile_size;
-		r.z = std::min(rp->tile_size, rp->xstart + rp->width - r.x); r.w = std::min(rp->tile_size, rp->ystart + rp->height - r.y);
-		tiles.push_back(r);
-		const uint32_t units = (uint32_t)((r.z * r.w + ra.pixels_per_wave - 1) / ra.pixels_per_wave);
-		prefix.push_back(prefix.back() + units);
+		const int ntx = (rp->width + rp->tile_size - 1) / rp->tile_size, nty = (rp->height + rp->tile_size - 1) / rp->tile_size;
+		std::vector<int4> &tiles = s->h_tiles; std::vector<uint32_t> &prefix = s->h_prefix;
+		tiles.clear(); prefix.clear();
+		prefix.push_back(0u);
+		for(int t = 0; t < ntx * nty; ++t)
+		{
+			if(t % rp->shard_count != rp->shard_index) continue;
+			const int tx = t % ntx, ty = t / ntx;
+			int4 r;
+			r.x = rp->xstart + tx * rp->tile_size; r.y = rp->ystart + ty * rp->tile_size;
+			r.z = std::min(rp->tile_size, rp->xstart + rp->width - r.x); r.w = std::min(rp->tile_size, rp->ystart + rp->height - r.y);
+			tiles.push_back(r);
+			const uint32_t units = (uint32_t)((r.z * r.w + ra.pixels_per_wave - 1) / ra.pixels_per_wave);
+			prefix.push_back(prefix.back() + units);
+		}
 	}
-	ra.n_tiles = (int)tiles.size();
-	ra.n_units = prefix.back();
+	ra.n_tiles = (int)s->h_tiles.size();
+	ra.n_units = s->h_prefix.back();
 	HIP_OK(hipMemsetAsync(d_planes, 0, yafgpu_planes_bytes(rp->width, rp->height), stream));
 	if(ra.n_tiles == 0) return 0;
-	if(tiles.size() > s->tiles_cap)
-	{
-		if(s->d_tiles) (void)hipFree(s->d_tiles);
-		if(s->d_prefix) (void)hipFree(s->d_prefix);
-		s->tiles_cap = tiles.size();
-		HIP_OK(hipMalloc((void **)&s->d_tiles, s->tiles_cap * sizeof(int4)));
-		HIP_OK(hipMalloc((void **)&s->d_prefix, (s->tiles_cap + 1) * sizeof(uint32_t)));
-	}
 	if(!s->d_queue) HIP_OK(hipMalloc((void **)&s->d_queue, kQueues * 32 * sizeof(uint32_t)));
-	HIP_OK(hipMemcpyAsync(s->d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
-	HIP_OK(hipMemcpyAsync(s->d_prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+	if(!same)
+	{
+		if(s->h_tiles.size() > s->tiles_cap)
+		{
+			if(s->d_tiles) (void)hipFree(s->d_tiles);
+			if(s->d_prefix) (void)hipFree(s->d_prefix);
+			s->tiles_cap = s->h_tiles.size();
+			HIP_OK(hipMalloc((void **)&s->d_tiles, s->tiles_cap * sizeof(int4)));
+			HIP_OK(hipMalloc((void **)&s->d_prefix, (s->tiles_cap + 1) * sizeof(uint32_t)));
+		}
+		HIP_OK(hipMemcpy(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(s->d_prefix, s->h_prefix.data(), s->h_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		std::memcpy(s->tile_key, key, sizeof key);
+	}
 	HIP_OK(hipMemsetAsync(s->d_queue, 0, kQueues * 32 * sizeof(uint32_t), stream));
-	// the pageable staging vectors above must outlive the async copies
-	HIP_OK(hipStreamSynchronize(stream));
 	ra.tile_rect = s->d_tiles; ra.unit_prefix = s->d_prefix; ra.queue_next = s->d_queue;
 	for(int q = 0; q <= kQueues; ++q) ra.queue_begin[q] = (uint32_t)(((uint64_t)ra.n_units * (uint64_t)q) / kQueues);
 	ra.planes = d_planes;

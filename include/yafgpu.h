@@ -157,6 +157,15 @@ int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int
  * reference's own golden vectors independently of any render. */
 int yafgpu_probe(yafgpu_scene_t *scene, int32_t op, int32_t n, const float *in, int32_t n_in, float *out, int32_t n_out);
 
+/* Host-only kd-tree build (no device needed): the builder Scene::update would run (scene.cc:818 ->
+ * TriKdTree ctor, kdtree_triangle.cc:76-157), exposed so that host tests can check the tree the
+ * kernels will walk.  nodes = n_nodes*2 uint32 (kdtree_build.h layout), refs = n_leaf_refs uint32. */
+typedef struct yafgpu_kdtree yafgpu_kdtree_t;
+yafgpu_kdtree_t *yafgpu_kdtree_build(const float *verts, int32_t n_tris, int32_t threads);
+void yafgpu_kdtree_info(const yafgpu_kdtree_t *tree, yafgpu_tree_info *info);
+void yafgpu_kdtree_get(const yafgpu_kdtree_t *tree, uint32_t *nodes, uint32_t *refs, float bound6[6]);
+void yafgpu_kdtree_destroy(yafgpu_kdtree_t *tree);
+
 /* kd-tree built on the host, downloadable for inspection/tests: nodes = n_nodes*2 uint32, refs = n_leaf_refs uint32 */
 int yafgpu_scene_get_tree(const yafgpu_scene_t *scene, uint32_t *nodes, uint32_t *refs, float bound6[6]);
 

@@ -22,6 +22,7 @@ struct Box { float lo[3], hi[3]; };
 struct Params
 {
 	const Box *prim_box;
+	const float *verts;
 	int depth_cap;
 	float cost_ratio, empty_bonus;
 };
@@ -47,6 +48,58 @@ inline float sah_cost(const Params &p, const float d[3], int axis, float l1, uin
 	const float below = cap + l1 * rim, above = cap + (d[axis] - l1) * rim;
 	const float eb = (nl == 0 || nr == 0) ? p.empty_bonus : 0.f;
 	return p.cost_ratio + inv_total_sa * (below * (float)nl + above * (float)nr) * (1.f - eb);
+}
+
+
+// Bounds of (triangle ∩ box), by Sutherland-Hodgman clipping in double precision ("perfect splits";
+// the reference clips too, for nodes of <= 32 prims: kdtree_triangle.cc:483-515).  The box is grown
+// by a small margin before clipping so that a triangle is only ever dropped from a subtree when it is
+// clearly outside it; the result is intersected with the node box.
+bool clip_tri_to_box(const float *v, const Box &box, Box &out)
+{
+	double poly[16][3], tmp[16][3];
+	int n = 3;
+	for(int i = 0; i < 3; ++i) for(int k = 0; k < 3; ++k) poly[i][k] = v[3 * i + k];
+	for(int axis = 0; axis < 3 && n > 0; ++axis)
+	{
+		const double ext = (double)box.hi[axis] - (double)box.lo[axis];
+		const double margin = 1e-5 * ext + 1e-7 * (std::fabs((double)box.lo[axis]) + std::fabs((double)box.hi[axis])) + 1e-30;
+		for(int side = 0; side < 2 && n > 0; ++side)
+		{
+			const double plane = side == 0 ? (double)box.lo[axis] - margin : (double)box.hi[axis] + margin;
+			int m = 0;
+			for(int i = 0; i < n; ++i)
+			{
+				const double *p = poly[i], *q = poly[(i + 1) % n];
+				const bool pin = side == 0 ? p[axis] >= plane : p[axis] <= plane;
+				const bool qin = side == 0 ? q[axis] >= plane : q[axis] <= plane;
+				if(pin) { for(int k = 0; k < 3; ++k) tmp[m][k] = p[k]; ++m; }
+				if(pin != qin)
+				{
+					const double t = (plane - p[axis]) / (q[axis] - p[axis]);
+					for(int k = 0; k < 3; ++k) tmp[m][k] = p[k] + t * (q[k] - p[k]);
+					tmp[m][axis] = plane;
+					++m;
+				}
+			}
+			n = m;
+			for(int i = 0; i < n; ++i) for(int k = 0; k < 3; ++k) poly[i][k] = tmp[i][k];
+		}
+	}
+	if(n == 0) return false;
+	for(int k = 0; k < 3; ++k)
+	{
+		double lo = poly[0][k], hi = poly[0][k];
+		for(int i = 1; i < n; ++i) { lo = std::min(lo, poly[i][k]); hi = std::max(hi, poly[i][k]); }
+		// round outward, then clamp to the node box
+		float flo = (float)lo, fhi = (float)hi;
+		if((double)flo > lo) flo = std::nextafter(flo, -INFINITY);
+		if((double)fhi < hi) fhi = std::nextafter(fhi, INFINITY);
+		out.lo[k] = std::max(flo, box.lo[k]);
+		out.hi[k] = std::min(fhi, box.hi[k]);
+		if(out.lo[k] > out.hi[k]) { const float mid = std::min(std::max(flo, box.lo[k]), box.hi[k]); out.lo[k] = out.hi[k] = mid; }
+	}
+	return true;
 }
 
 Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, uint32_t np)
@@ -83,7 +136,7 @@ Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, 
 	return best;
 }
 
-Split find_split_sweep(const Params &p, const Box &box, const uint32_t *prims, uint32_t np)
+Split find_split_sweep(const Params &p, const Box &box, const Box *pbox, uint32_t np)
 {
 	Split best;
 	float d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
@@ -97,7 +150,7 @@ Split find_split_sweep(const Params &p, const Box &box, const uint32_t *prims, u
 		if(!(d[axis] > 0.f)) continue;
 		for(uint32_t i = 0; i < np; ++i)
 		{
-			const Box &b = p.prim_box[prims[i]];
+			const Box &b = pbox[i];
 			edges[2 * i] = {b.lo[axis], 0};
 			edges[2 * i + 1] = {b.hi[axis], 1};
 		}
@@ -133,13 +186,29 @@ void emit_leaf(Sub &s, const uint32_t *prims, uint32_t np, int depth)
 	s.depth = std::max(s.depth, depth);
 }
 
-// returns false when the node must become a leaf
-bool choose_and_partition(const Params &p, const Box &box, const std::vector<uint32_t> &prims, int depth, int &bad_refines,
+// returns false when the node must become a leaf (prims may have shrunk: triangles that the exact
+// clip shows to lie outside this node are removed)
+bool choose_and_partition(const Params &p, const Box &box, std::vector<uint32_t> &prims, int depth, int &bad_refines,
                           Split &sp, std::vector<uint32_t> &left, std::vector<uint32_t> &right)
 {
-	const uint32_t np = (uint32_t)prims.size();
+	uint32_t np = (uint32_t)prims.size();
 	if(np <= 1 || depth >= p.depth_cap) return false;
-	sp = (np <= (uint32_t)kSweepMax) ? find_split_sweep(p, box, prims.data(), np) : find_split_binned(p, box, prims.data(), np);
+	Box local[kSweepMax];
+	const bool small = np <= (uint32_t)kSweepMax;
+	if(small)
+	{
+		uint32_t m = 0;
+		for(uint32_t i = 0; i < np; ++i)
+		{
+			Box b;
+			if(clip_tri_to_box(p.verts + 9 * (size_t)prims[i], box, b)) { local[m] = b; prims[m] = prims[i]; ++m; }
+		}
+		prims.resize(m);
+		np = m;
+		if(np <= 1) return false;
+		sp = find_split_sweep(p, box, local, np);
+	}
+	else sp = find_split_binned(p, box, prims.data(), np);
 	if(sp.axis < 0) return false;
 	const float leaf_cost = (float)np;
 	if(sp.cost > leaf_cost) ++bad_refines;
@@ -147,10 +216,13 @@ bool choose_and_partition(const Params &p, const Box &box, const std::vector<uin
 	left.clear(); right.clear();
 	for(uint32_t i = 0; i < np; ++i)
 	{
-		const Box &b = p.prim_box[prims[i]];
-		// conservative: a prim whose bounds touch the plane is referenced on both sides
-		if(b.lo[sp.axis] <= sp.pos) left.push_back(prims[i]);
-		if(b.hi[sp.axis] >= sp.pos) right.push_back(prims[i]);
+		const Box &b = small ? local[i] : p.prim_box[prims[i]];
+		// same membership as the cost model: a prim that merely touches the plane belongs to one side
+		// (its hit at t == t_plane is still found: the traversal accepts any t below the current best,
+		// not only hits inside the cell); a prim lying in the plane goes left
+		const float lo = b.lo[sp.axis], hi = b.hi[sp.axis];
+		if(lo < sp.pos || (lo == sp.pos && hi == sp.pos)) left.push_back(prims[i]);
+		if(hi > sp.pos) right.push_back(prims[i]);
 	}
 	if(left.size() == np && right.size() == np) return false;
 	return true;
@@ -245,6 +317,7 @@ void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, Kd
 	}
 	Params p;
 	p.prim_box = boxes.data();
+	p.verts = verts;
 	int md = (int)(7.0f + 1.66f * std::log((float)n_tris)); // kdtree_triangle.cc:89
 	p.depth_cap = std::min(md, depth_cap);
 	p.cost_ratio = 0.8f; p.empty_bonus = 0.33f;             // scene.cc:818
@@ -265,3 +338,29 @@ void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, Kd
 }
 
 } // namespace yafgpu
+
+// ---- host-only C entry points (include/yafgpu.h) ----
+#include "../../include/yafgpu.h"
+struct yafgpu_kdtree { yafgpu::KdTree t; int n_tris; };
+extern "C" {
+yafgpu_kdtree_t *yafgpu_kdtree_build(const float *verts, int32_t n_tris, int32_t threads)
+{
+	auto *k = new yafgpu_kdtree();
+	k->n_tris = n_tris;
+	yafgpu::build_kdtree(verts, n_tris, 48, threads, k->t);
+	return k;
+}
+void yafgpu_kdtree_info(const yafgpu_kdtree_t *k, yafgpu_tree_info *info)
+{
+	info->n_nodes = (uint32_t)k->t.nodes.size(); info->n_leaf_refs = (uint32_t)k->t.refs.size();
+	info->max_depth = (uint32_t)k->t.max_depth; info->n_tris = (uint32_t)k->n_tris;
+	info->build_seconds = k->t.build_seconds; info->upload_seconds = 0; info->device_bytes = 0;
+}
+void yafgpu_kdtree_get(const yafgpu_kdtree_t *k, uint32_t *nodes, uint32_t *refs, float bound6[6])
+{
+	if(nodes) std::memcpy(nodes, k->t.nodes.data(), k->t.nodes.size() * sizeof(yafgpu::KdNode));
+	if(refs) std::memcpy(refs, k->t.refs.data(), k->t.refs.size() * sizeof(uint32_t));
+	if(bound6) for(int i = 0; i < 3; ++i) { bound6[i] = k->t.bound_lo[i]; bound6[3 + i] = k->t.bound_hi[i]; }
+}
+void yafgpu_kdtree_destroy(yafgpu_kdtree_t *k) { delete k; }
+}

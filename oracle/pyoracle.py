@@ -98,6 +98,7 @@ def lib():
     L.yor_scene_destroy.argtypes = [C.c_void_p]
     L.yor_render.restype = C.c_int
     L.yor_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), fp, C.POINTER(Stats)]
+    L.yor_scene_set_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), fp]
     L.yor_intersect.restype = C.c_int
     L.yor_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_float, C.POINTER(C.c_int32), fp, fp]
     L.yor_is_shadowed.restype = C.c_int
@@ -281,6 +282,13 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError(f"oracle: unsupported configuration (code {rc})")
         return film, st
+
+    def set_tree(self, nodes, refs, bound6):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 2)
+        refs = np.ascontiguousarray(refs, dtype=np.uint32)
+        b = np.ascontiguousarray(bound6, dtype=np.float32)
+        up = C.POINTER(C.c_uint32)
+        lib().yor_scene_set_tree(self.h, nodes.shape[0], nodes.ctypes.data_as(up), refs.shape[0], refs.ctypes.data_as(up), fptr(b))
 
     def intersect(self, frm, dr, tmin=0.0, tmax=-1.0, use_tree=True):
         L = lib()

@@ -1574,6 +1574,17 @@ void yor_scene_destroy(yor_scene *s)
 	free(s->tris); free(s->mats); free(s->lights); free(s->nodes); free(s->leaf_refs); free(s);
 }
 
+void yor_scene_set_tree(yor_scene *s, uint32_t n_nodes, const uint32_t *nodes, uint32_t n_refs, const uint32_t *refs, const float bound6[6])
+{
+	free(s->nodes); free(s->leaf_refs);
+	s->nodes = (kdnode_t *)malloc(sizeof(kdnode_t) * (n_nodes ? n_nodes : 1));
+	s->leaf_refs = (uint32_t *)malloc(sizeof(uint32_t) * (n_refs ? n_refs : 1));
+	memcpy(s->nodes, nodes, sizeof(kdnode_t) * n_nodes);
+	memcpy(s->leaf_refs, refs, sizeof(uint32_t) * n_refs);
+	s->n_nodes = s->cap_nodes = n_nodes; s->n_refs = s->cap_refs = n_refs;
+	s->tb_a = V(bound6[0], bound6[1], bound6[2]); s->tb_g = V(bound6[3], bound6[4], bound6[5]);
+}
+
 /* ------------------------------------------------------------------ integrator */
 typedef struct
 {

@@ -147,6 +147,11 @@ void yor_scene_destroy(yor_scene *s);
  * zeroed by the callee.  Returns 0 on success, negative on unsupported configuration. */
 int yor_render(yor_scene *s, const yor_render_desc *rd, float *film, yor_stats *stats);
 
+/* Replace the oracle's own kd-tree by an externally built one in the same 8-byte node layout
+ * (interior: {split, axis | right<<2}, leaf: {first_ref, 3 | count<<2}, near child = next node): lets
+ * tests walk the PRODUCT's tree with the reference's traversal algorithm. */
+void yor_scene_set_tree(yor_scene *s, uint32_t n_nodes, const uint32_t *nodes, uint32_t n_refs, const uint32_t *refs, const float bound6[6]);
+
 /* ray-level entry points (kd traversal vs brute force cross-checks and GPU ray parity tests) */
 int yor_intersect(const yor_scene *s, int use_tree, const float from[3], const float dir[3], float tmin, float tmax,
                   int32_t *tri, float *t, float bary[3]);

@@ -96,6 +96,7 @@ def main():
     import torch
     import torch.distributed as dist
     from libyafaray_amd import Interface, scenes, interface as yi_mod
+    from libyafaray_amd.parallel import reduce_planes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,8 +128,7 @@ def main():
 
     def step():
         yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
-        if world > 1:
-            dist.reduce(planes, dst=0, op=dist.ReduceOp.SUM)
+        reduce_planes(planes, dst=0)
         if rank == 0:
             yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
 
@@ -148,8 +148,7 @@ def main():
         ev[k][0].record()
         yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
         ev[k][1].record()
-        if world > 1:
-            dist.reduce(planes, dst=0, op=dist.ReduceOp.SUM)
+        reduce_planes(planes, dst=0)
         if rank == 0:
             yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
     barrier()

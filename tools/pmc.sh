@@ -1,0 +1,25 @@
+#!/bin/bash
+# GPU-box helper: PMC passes for the render kernel (counters only; no trace domains besides kernel-trace)
+# usage: tools/pmc.sh <outdir> [bench args]
+cd "$(dirname "$0")/.."
+repo="$PWD"
+out="$repo/$1"; shift
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$repo"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pass$i" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$out/pass$i.log" 2>&1 || echo "pass $i failed"
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "render_kernel<false>" not in r["Kernel_Name"]: continue
+        agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+for c, d in sorted(agg.items()):
+    vals = list(d.values())
+    print(f"{c:28s} per-dispatch mean {sum(vals)/len(vals):.6g}  (n={len(vals)})")
+PY

@@ -726,6 +726,10 @@ __global__ __launch_bounds__(kBlock, YAFGPU_WAVES) void render_kernel(const Rend
 	}
 }
 
+} // namespace yafgpu
+#include "yafgpu_wavefront.h"
+namespace yafgpu {
+
 // film[y][x] = own + right(x-1,y) + down(x,y-1) + diag(x-1,y-1): the neighbours' splats onto this pixel
 __global__ __launch_bounds__(kBlock) void combine_kernel(const float *planes, float *film, int w, int h)
 {
@@ -897,12 +901,18 @@ struct yafgpu_scene
 	KdTree tree;
 	yafgpu_tree_info info{};
 	std::vector<yafgpu_material> mats;
+	std::vector<yafgpu_light> h_lights;
 	int n_lights = 0;
 	// per-render scratch, grown on demand
 	int4 *d_tiles = nullptr; uint32_t *d_prefix = nullptr; uint32_t *d_queue = nullptr; size_t tiles_cap = 0;
 	// the tile list of the last launch stays resident; it is re-uploaded only when its key changes
 	std::vector<int4> h_tiles; std::vector<uint32_t> h_prefix;
 	int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
+	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
+	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr; uint32_t wf_cap = 0;
+	bool profiling = false;
+	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
 };
 
 template<typename T> static int upload(yafgpu_scene *s, const T *src, size_t n, const T **dst)
@@ -1059,6 +1069,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	dv.cam = d->camera;
 	s->mats.assign(d->materials, d->materials + d->n_materials);
 	s->n_lights = d->n_lights;
+	s->h_lights.assign(d->lights, d->lights + d->n_lights);
 	s->info.upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 	(void)t0;
 	*out = s;
@@ -1072,6 +1083,11 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->d_tiles) (void)hipFree(s->d_tiles);
 	if(s->d_prefix) (void)hipFree(s->d_prefix);
 	if(s->d_queue) (void)hipFree(s->d_queue);
+	if(s->d_pix_prefix) (void)hipFree(s->d_pix_prefix);
+	if(s->wf_state) (void)hipFree(s->wf_state);
+	if(s->wf_results) (void)hipFree(s->wf_results);
+	if(s->wf_queues) (void)hipFree(s->wf_queues);
+	if(s->wf_counts) (void)hipFree(s->wf_counts);
 	delete s;
 }
 
@@ -1099,6 +1115,117 @@ static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
 	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
 	if(rp->integrator != YAFGPU_INTEGRATOR_PATH && rp->integrator != YAFGPU_INTEGRATOR_DIRECT) return fail(-14, "unknown integrator");
 	(void)s;
+	return 0;
+}
+
+// ---- wavefront pass -------------------------------------------------------------------------
+static constexpr uint32_t kWfMaxPaths = 32u << 20;   // paths in flight per chunk: 32 Mi x 304 B = 9.5 GiB of parked state
+
+static int wf_grid(const void *kernel, int cus)
+{
+	int per_cu = 0;
+	if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+	return cus * std::min(per_cu, 8);
+}
+
+static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream, bool stats)
+{
+	const yafgpu_render_params &rp = ra.rp;
+	const uint32_t spp = (uint32_t)rp.aa_minsamples;
+	// per-tile pixel prefix (same tile list as the unit prefix)
+	std::vector<uint32_t> &pp = s->h_pix_prefix;
+	pp.assign(1, 0u);
+	for(const int4 &r : s->h_tiles) pp.push_back(pp.back() + (uint32_t)(r.z * r.w));
+	const uint32_t n_pixels_total = pp.back();
+	if(pp.size() > s->pix_prefix_cap)
+	{
+		if(s->d_pix_prefix) (void)hipFree(s->d_pix_prefix);
+		s->pix_prefix_cap = pp.size();
+		HIP_OK(hipMalloc((void **)&s->d_pix_prefix, s->pix_prefix_cap * sizeof(uint32_t)));
+	}
+	HIP_OK(hipMemcpy(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, kWfMaxPaths / spp));
+	const uint32_t cap = chunk_pixels * spp;
+	if(cap > s->wf_cap)
+	{
+		if(s->wf_state) (void)hipFree(s->wf_state);
+		if(s->wf_results) (void)hipFree(s->wf_results);
+		if(s->wf_queues) (void)hipFree(s->wf_queues);
+		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_cap = 0;
+		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)kWfRecs * cap * sizeof(float4)));
+		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
+		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)4 * cap * sizeof(uint32_t)));
+		s->wf_cap = cap;
+	}
+	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 64 * sizeof(uint32_t)));
+	int dev = 0; hipDeviceProp_t prop;
+	HIP_OK(hipGetDevice(&dev));
+	HIP_OK(hipGetDeviceProperties(&prop, dev));
+	const int cus = prop.multiProcessorCount;
+	const int g_trace_c = stats ? wf_grid((const void *)wf_trace<false, true>, cus) : wf_grid((const void *)wf_trace<false, false>, cus);
+	const int g_trace_s = stats ? wf_grid((const void *)wf_trace<true, true>, cus) : wf_grid((const void *)wf_trace<true, false>, cus);
+	const int g_shade = wf_grid((const void *)wf_shade, cus);
+	// upper bound of kd-tree queries per path = iterations needed (every path advances one query per iteration)
+	int r_all = 0, r_one = 0;
+	for(int i = 0; i < s->n_lights; ++i)
+	{
+		const yafgpu_light &l = s->h_lights[(size_t)i];
+		const int r = l.type == YAFGPU_LIGHT_POINT ? 1 : 2 * (int)std::ceil((float)l.samples * rp.aa_light_sample_multiplier);
+		r_all += r; r_one = std::max(r_one, r);
+	}
+	int iters = 1 + r_all;
+	if(rp.integrator == YAFGPU_INTEGRATOR_PATH)
+		iters += std::max(1, rp.path_samples) * ((1 + r_one) + std::max(0, rp.bounces - 1) * (1 + r_one));
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	if(s->profiling) { HIP_OK(hipEventCreate(&ev[0])); HIP_OK(hipEventCreate(&ev[1])); for(int k = 0; k < 4; ++k) { s->prof_ms[k] = 0; s->prof_launches[k] = 0; } }
+	auto timed = [&](int slot, auto &&launch) -> int {
+		if(s->profiling) HIP_OK(hipEventRecord(ev[0], stream));
+		launch();
+		HIP_OK(hipGetLastError());
+		if(s->profiling)
+		{
+			HIP_OK(hipEventRecord(ev[1], stream));
+			HIP_OK(hipEventSynchronize(ev[1]));
+			float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+			s->prof_ms[slot] += ms; s->prof_launches[slot] += 1;
+		}
+		return 0;
+	};
+	for(uint32_t pb = 0; pb < n_pixels_total; pb += chunk_pixels)
+	{
+		WfArgs a{};
+		a.ra = ra;
+		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results;
+		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
+		a.pix_prefix = s->d_pix_prefix;
+		uint32_t *q[4] = {s->wf_queues, s->wf_queues + s->wf_cap, s->wf_queues + 2 * (size_t)s->wf_cap, s->wf_queues + 3 * (size_t)s->wf_cap};
+		uint32_t *cnt[2] = {s->wf_counts, s->wf_counts + 32};
+		a.cnt_in = cnt[0]; a.cnt_out = cnt[1];
+		a.q_closest_in = nullptr; a.q_shadow_in = q[1]; a.q_closest_out = q[2]; a.q_shadow_out = q[3];
+		const uint32_t g_gen = std::min<uint32_t>((a.n_paths + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
+		int rc;
+		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
+		int cur = 0;
+		for(int it = 0; it < iters; ++it)
+		{
+			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 2 * sizeof(uint32_t), stream));
+			if((rc = timed(0, [&] {
+				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
+				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
+			if(it > 0 && (rc = timed(1, [&] {
+				if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, stream, a);
+				else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, stream, a); }))) return rc;
+			if((rc = timed(2, [&] { hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
+			// swap queues: what shade produced is the next iteration's input
+			cur ^= 1;
+			a.cnt_in = cnt[cur]; a.cnt_out = cnt[cur ^ 1];
+			if(cur) { a.q_closest_in = q[2]; a.q_shadow_in = q[3]; a.q_closest_out = q[0]; a.q_shadow_out = q[1]; }
+			else { a.q_closest_in = q[0]; a.q_shadow_in = q[1]; a.q_closest_out = q[2]; a.q_shadow_out = q[3]; }
+		}
+		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
+		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
+	}
+	if(s->profiling) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
 	return 0;
 }
 
@@ -1166,6 +1293,12 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	for(int q = 0; q <= kQueues; ++q) ra.queue_begin[q] = (uint32_t)(((uint64_t)ra.n_units * (uint64_t)q) / kQueues);
 	ra.planes = d_planes;
 	ra.counters = d_counters;
+	const bool stats = d_counters != nullptr && std::getenv("YAFGPU_STATS") != nullptr;
+	{
+		const char *pl = std::getenv("YAFGPU_PIPELINE");
+		const bool mega = pl && std::strcmp(pl, "megakernel") == 0;
+		if(!mega) return render_wavefront(s, ra, stream, stats);
+	}
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev));
 	HIP_OK(hipGetDeviceProperties(&prop, dev));
@@ -1174,7 +1307,6 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
 	const uint32_t want = (ra.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
 	const uint32_t grid = std::max(1u, std::min(want, (uint32_t)(prop.multiProcessorCount * blocks_per_cu)));
-	const bool stats = d_counters != nullptr && std::getenv("YAFGPU_STATS") != nullptr;
 	if(stats) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, ra);
 	else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, ra);
 	HIP_OK(hipGetLastError());

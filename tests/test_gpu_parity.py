@@ -24,6 +24,13 @@ def compare_films(gpu_film, ora_film, what, max_outliers=0):
     return n_bad, exact
 
 
+@pytest.fixture(params=["wavefront", "megakernel"], autouse=True)
+def pipeline(request, monkeypatch):
+    """Both device pipelines (queue-per-stage wavefront, one-kernel persistent) must give the same film."""
+    monkeypatch.setenv("YAFGPU_PIPELINE", request.param)
+    return request.param
+
+
 def render_both(sc, rd):
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
@@ -68,3 +75,34 @@ def test_render_matches_oracle(n_tris, res, spp, bounces):
     assert st.camera_samples == res * res * spp
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow, "ray counts differ from the oracle"
     compare_films(film, ofilm, f"cornell {n_tris} tris {res}x{res} {spp}spp b{bounces}")
+
+
+def test_pipelines_are_bit_identical(monkeypatch):
+    sc = scenes.cornell_soup(3000, seed=77, res=(56, 40), n_lights=2, glossy_fraction=0.3)
+    rd = scenes.render_settings(56, 40, 12, bounces=3, path_samples=2)
+    films = {}
+    for pl in ("wavefront", "megakernel"):
+        monkeypatch.setenv("YAFGPU_PIPELINE", pl)
+        yi = Interface()
+        scenes.load_scene(yi, sc, rd)
+        yi.render()
+        films[pl] = (yi.getFilm(56, 40), yi.getRenderStats())
+    a, b = films["wavefront"], films["megakernel"]
+    assert a[1].rays_closest == b[1].rays_closest and a[1].rays_shadow == b[1].rays_shadow
+    assert np.array_equal(a[0], b[0]), "wavefront and megakernel films differ"
+
+
+def test_glossy_two_lights_point_light_run_and_match_oracle_where_defined():
+    """Glossy (as_diffuse) + diffuse, ONE area light: inside the deterministic-parity regime."""
+    sc = scenes.cornell_soup(1500, seed=5, res=(40, 40), glossy_fraction=0.5)
+    rd = scenes.render_settings(40, 40, 16, bounces=3)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "glossy 50% cornell")
+    # a point light (Dirac branch of doLightEstimation) in place of the area light
+    sc2 = scenes.cornell_soup(800, seed=6, res=(32, 32))
+    sc2["lights"] = [{"type": "pointlight", "from": (0.2, -0.3, 0.6), "color": (1.0, 0.9, 0.8), "power": 3.0}]
+    rd2 = scenes.render_settings(32, 32, 8, bounces=2)
+    film, st, ofilm, ost = render_both(sc2, rd2)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "point light cornell")

@@ -40,7 +40,7 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 #ifndef YAFGPU_STACK
-#define YAFGPU_STACK 16
+#define YAFGPU_STACK 8                // 8 slots: 8 waves/SIMD for the traversal kernels, 0.8 % of rays restart (C2)
 #endif
 #ifndef YAFGPU_WAVES
 #define YAFGPU_WAVES 4                // __launch_bounds__ min waves/SIMD of the render kernel (C2 measured: 1:368 2:667 3:781 4:793 Mrays/s)
@@ -1208,7 +1208,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		int cur = 0;
 		for(int it = 0; it < iters; ++it)
 		{
-			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 2 * sizeof(uint32_t), stream));
+			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 4 * sizeof(uint32_t), stream));
 			if((rc = timed(0, [&] {
 				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
 				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;

@@ -30,8 +30,8 @@ struct WfArgs
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
 	const uint32_t *q_closest_in, *q_shadow_in;   // nullptr closest queue = identity (first iteration)
 	uint32_t *q_closest_out, *q_shadow_out;
-	uint32_t *cnt_in;                 // [0] closest, [1] shadow
-	uint32_t *cnt_out;                // [0] closest, [1] shadow
+	uint32_t *cnt_in;                 // [0] closest count, [1] shadow count, [2] closest fetch cursor, [3] shadow fetch cursor
+	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
 
 enum : int { kPcAfterClosest = 1, kPcAfterShadow = 2 };
@@ -71,7 +71,7 @@ YG_DEV void wf_load(const WfArgs &a, uint32_t s, PathRegs &p)
 	r = b[7 * c]; p.hit_p = v3(r); p.hit_mat = (int)ubits(r.w);
 	r = b[8 * c]; p.hit_n = v3(r); p.offs = ubits(r.w);
 	r = b[9 * c]; p.hit_ng = v3(r); p.one_light_calls = ubits(r.w);
-	r = b[10 * c]; p.pwo = v3(r); p.shadowed = (int)ubits(r.w);
+	r = b[10 * c]; p.pwo = v3(r); p.shadowed = (p.tri != 0);   // after an any-hit query record 2 holds the verdict in .x
 	r = b[11 * c]; p.throughput = c3(r); p.rr.x = ubits(r.w);
 	r = b[12 * c]; p.path_col = c3(r); p.rr.c = ubits(r.w);
 	r = b[13 * c]; p.col = c3(r);
@@ -103,7 +103,7 @@ YG_DEV void wf_store(const WfArgs &a, uint32_t s, const PathRegs &p)
 	b[7 * c] = f4(p.hit_p, fbits((uint32_t)p.hit_mat));
 	b[8 * c] = f4(p.hit_n, fbits(p.offs));
 	b[9 * c] = f4(p.hit_ng, fbits(p.one_light_calls));
-	b[10 * c] = f4(p.pwo, fbits((uint32_t)p.shadowed));
+	b[10 * c] = f4(p.pwo, 0.f);
 	b[11 * c] = f4(p.throughput, fbits(p.rr.x));
 	b[12 * c] = f4(p.path_col, fbits(p.rr.c));
 	b[13 * c] = f4(p.col, fbits((uint32_t)p.pc | ((uint32_t)p.stage << 2) | ((uint32_t)p.dl_on_sp0 << 4) | ((uint32_t)p.depth << 8) | ((uint32_t)p.path_i << 16)));
@@ -479,43 +479,141 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 		b[12 * c] = make_float4(0.f, 0.f, 0.f, fbits(rr.c));
 		b[13 * c] = make_float4(0.f, 0.f, 0.f, fbits((uint32_t)kPcAfterClosest | ((uint32_t)kStPrimary << 2)));
 	}
-	if(blockIdx.x == 0 && threadIdx.x == 0) { a.cnt_in[0] = a.n_paths; a.cnt_in[1] = 0u; }
+	if(blockIdx.x == 0 && threadIdx.x == 0) { a.cnt_in[0] = a.n_paths; a.cnt_in[1] = 0u; a.cnt_in[2] = 0u; a.cnt_in[3] = 0u; }
 }
 
-// the traversal kernels: Scene::intersect (scene.cc:896-927) / Scene::isShadowed (:962-994) over a queue
+// The traversal kernels: Scene::intersect (scene.cc:896-927) / Scene::isShadowed (:962-994) over a queue.
+//
+// Persistent waves with ray refill: a lane whose ray is finished does not idle until the slowest ray
+// of its wave ends; when at least kRefill lanes are free the wave fetches that many new rays from the
+// queue with one atomic (ballot + prefix rank) and the freed lanes start them while the others carry
+// on.  Traversal state (current node, [tmin,tmax], best hit, short stack in LDS) is per lane, so lanes
+// of one wave can be at any point of any ray.  The walk itself is kd_trace's, cut at leaf granularity.
+#ifndef YAFGPU_REFILL
+#define YAFGPU_REFILL 32               // C2 sweep: 16 -> 1134, 32 -> 1408, 48 -> 1360 Mrays/s
+#endif
 template<bool kAny, bool kStats>
 __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 {
 	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
+	const DevScene &sc = a.ra.sc;
 	LaneStack stk;
 	stk.col = &s_stack[wave][0][lane];
 	LaneCounters cn = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
 	const uint32_t n = kAny ? a.cnt_in[1] : a.cnt_in[0];
+	uint32_t *cursor = kAny ? &a.cnt_in[3] : &a.cnt_in[2];
 	const uint32_t *q = kAny ? a.q_shadow_in : a.q_closest_in;
 	const size_t c = a.cap;
-	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	// per-lane ray + traversal state
+	bool active = false, exhausted = (n == 0u) || (sc.n_nodes == 0u && false);
+	uint32_t slot = 0u, node = 0u;
+	V3 from = mk(0.f, 0.f, 0.f), dir = from, inv_dir = from;
+	float ray_tmin = 0.f, dist = 0.f, t_exit = 0.f, tmin = 0.f, tmax = 0.f, z = 0.f, bu = 0.f, bv = 0.f;
+	int tri = -1; bool hit = false;
+	for(;;)
 	{
-		const uint32_t slot = q ? q[i] : i;
-		const float4 r0 = a.state[slot], r1 = a.state[c + slot];
-		const V3 from = v3(r0), dir = v3(r1);
-		int ti = -1; float z = 0.f, bu = 0.f, bv = 0.f;
-		if(kAny)
+		const unsigned long long idle = __ballot(!active);
+		const int n_idle = __popcll(idle);
+		if(!exhausted && (n_idle >= YAFGPU_REFILL || n_idle == kWave))
 		{
-			const V3 sfrom = from + dir * r0.w;
-			const float dis = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
-			++cn.shadow;
-			const bool sh = kd_trace<true, kStats>(a.ra.sc, stk, sfrom, dir, 0.f, dis, ti, z, bu, bv, cn);
-			float4 r10 = a.state[10 * c + slot];
-			r10.w = fbits(sh ? 1u : 0u);
-			a.state[10 * c + slot] = r10;
+			const int leader = __ffsll((long long)idle) - 1;
+			uint32_t base = 0u;
+			if(lane == leader) base = atomicAdd(cursor, (uint32_t)n_idle);
+			base = (uint32_t)__shfl((int)base, leader, kWave);
+			if(base + (uint32_t)n_idle >= n) exhausted = true;
+			if(!active)
+			{
+				const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+				if(i < n)
+				{
+					slot = q ? q[i] : i;
+					const float4 r0 = a.state[slot], r1 = a.state[c + slot];
+					from = v3(r0); dir = v3(r1);
+					if(kAny)
+					{
+						from = from + dir * r0.w;
+						dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
+						ray_tmin = 0.f;
+						++cn.shadow;
+					}
+					else
+					{
+						dist = (r1.w < 0.f) ? INFINITY : r1.w;
+						ray_tmin = r0.w;
+						++cn.closest;
+					}
+					float ea, eb;
+					tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f;
+					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, dist, ea, eb))
+					{
+						inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u;
+						stk.reset();
+						active = true;
+					}
+					else
+					{	// misses the scene bound: answer at once
+						a.state[2 * c + slot] = kAny ? make_float4(fbits(0u), 0.f, 0.f, 0.f) : make_float4(fbits(0xffffffffu), dist, 0.f, 0.f);
+					}
+				}
+			}
 		}
-		else
+		if(__ballot(active) == 0ull) { if(exhausted) break; else continue; }
+		if(active)
 		{
-			const float dis = (r1.w < 0.f) ? INFINITY : r1.w;
-			++cn.closest;
-			const bool h = kd_trace<false, kStats>(a.ra.sc, stk, from, dir, r0.w, dis, ti, z, bu, bv, cn);
-			a.state[2 * c + slot] = make_float4(fbits((uint32_t)(h ? ti : -1)), z, bu, bv);
+			bool done = false, found = false;
+			if(z < tmin) done = true;                     // kdtree_triangle.cc:717
+			else
+			{
+				uint2 nd = sc.nodes[node];
+				while((nd.y & 3u) != 3u)
+				{
+					const int axis = (int)(nd.y & 3u);
+					const float split = __uint_as_float(nd.x);
+					const float o = comp(from, axis), d = comp(dir, axis);
+					const float tplane = (split - o) * comp(inv_dir, axis);
+					const bool below = (o < split) || (o == split && d <= 0.f);
+					const uint32_t left = node + 1u, right = nd.y >> 2;
+					const uint32_t near_c = below ? left : right, far_c = below ? right : left;
+					if(kStats) ++cn.interior;
+					if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
+					else if(tplane < tmin) node = far_c;
+					else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
+					nd = sc.nodes[node];
+				}
+				const uint32_t np = nd.y >> 2, first = nd.x;
+				if(kStats) ++cn.leaves;
+				for(uint32_t k = 0; k < np; ++k)
+				{
+					const uint32_t ti = sc.refs[first + k];
+					const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
+					float t, u, v;
+					if(kStats) ++cn.tests;
+					if(tri_test(r0, r1, r2, from, dir, t, u, v))
+					{
+						const uint32_t vis = __float_as_uint(r1.w) >> 30;
+						if(kAny)
+						{
+							if(t < dist && t >= 0.f && (vis == 0u || vis == 2u)) { found = true; break; }
+						}
+						else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u)) { z = t; tri = (int)ti; bu = u; bv = v; hit = true; }
+					}
+				}
+				if(kAny ? found : (hit && z <= tmax)) done = true;         // :822 / :936-945
+				else if(stk.count == 0)
+				{
+					if(!stk.dropped || tmax >= t_exit) done = true;
+					else { tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false; if(kStats) ++cn.restarts; }
+				}
+				else { tmin = tmax; stk.pop(node, tmax); }
+			}
+			if(done)
+			{
+				a.state[2 * c + slot] = kAny ? make_float4(fbits(found ? 1u : 0u), 0.f, 0.f, 0.f)
+				                             : make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
+				active = false;
+			}
 		}
 	}
 	if(a.ra.counters != nullptr)
@@ -538,7 +636,10 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 }
 
 // resume every answered path; entries [0, n_closest) come from the closest queue, the rest from the shadow queue
-__global__ __launch_bounds__(kBlock) void wf_shade(const WfArgs a)
+#ifndef YAFGPU_SHADE_WAVES
+#define YAFGPU_SHADE_WAVES 1
+#endif
+__global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
 {
 	const uint32_t nc = a.cnt_in[0], ns = a.cnt_in[1];
 	const uint32_t total = nc + ns;

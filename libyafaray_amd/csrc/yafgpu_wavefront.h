@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 19;   // float4 records of parked state per path (304 B)
+constexpr int kWfRecs = 20;   // float4 records of parked state per path (320 B)
 
 struct WfArgs
 {
@@ -48,6 +48,7 @@ struct PathRegs
 	int pc, stage, path_i, depth, dl_on_sp0;
 	Col pending, ccol, ccol_2, col_dirac, total;     // r14..r18
 	int li, l_end, phase, is, shadowed;
+	uint32_t have, dirty;                            // record groups present in registers / modified
 };
 
 YG_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -57,61 +58,86 @@ YG_DEV Col c3(float4 f) { return mkc(f.x, f.y, f.z); }
 YG_DEV float fbits(uint32_t u) { return __uint_as_float(u); }
 YG_DEV uint32_t ubits(float f) { return __float_as_uint(f); }
 
-YG_DEV void wf_load(const WfArgs &a, uint32_t s, PathRegs &p)
+// Parked state is read and written by record group, on demand: a path that resumes after a shadow
+// ray and parks again for the next one touches ~10 of the 20 records, not all of them.
+enum : uint32_t {
+	G_RAY = 1u << 0,    // r0, r1   pending ray
+	G_ANS = 1u << 1,    // r2       answer of the last query
+	G_SP0 = 1u << 2,    // r3..r6   camera hit: p|mat0, n, ng|bsdfs0, wo0
+	G_HIT = 1u << 3,    // r7..r10  current path vertex: p|mat, n, ng, pwo
+	G_PATH = 1u << 4,   // r11, r12 throughput|rr.x, path_col|rr.c
+	G_CTRL = 1u << 5,   // r13      col | pc, stage, depth, path_i
+	G_DLC = 1u << 6,    // r14      pending contribution | li, l_end, phase, is
+	G_ACC = 1u << 7,    // r15..r18 ccol, ccol_2, col_dirac, total
+	G_MISC = 1u << 8,   // r19      offs, sampled_flags, one_light_calls, alpha
+};
+
+YG_DEV void wf_need(const WfArgs &a, uint32_t s, PathRegs &p, uint32_t groups)
 {
+	groups &= ~p.have;
+	if(!groups) return;
+	p.have |= groups;
 	const float4 *b = a.state + s; const size_t c = a.cap;
 	float4 r;
-	r = b[0 * c]; p.r_from = v3(r); p.r_tmin = r.w;
-	r = b[1 * c]; p.r_dir = v3(r); p.r_tmax = r.w;
-	r = b[2 * c]; p.tri = (int)ubits(r.x); p.t = r.y; p.bu = r.z; p.bv = r.w;
-	r = b[3 * c]; p.sp0_p = v3(r); p.mat0 = (int)ubits(r.w);
-	r = b[4 * c]; p.sp0_n = v3(r); p.sampled_flags = ubits(r.w);
-	r = b[5 * c]; p.sp0_ng = v3(r); p.bsdfs0 = ubits(r.w);
-	r = b[6 * c]; p.wo0 = v3(r); p.alpha = r.w;
-	r = b[7 * c]; p.hit_p = v3(r); p.hit_mat = (int)ubits(r.w);
-	r = b[8 * c]; p.hit_n = v3(r); p.offs = ubits(r.w);
-	r = b[9 * c]; p.hit_ng = v3(r); p.one_light_calls = ubits(r.w);
-	r = b[10 * c]; p.pwo = v3(r); p.shadowed = (p.tri != 0);   // after an any-hit query record 2 holds the verdict in .x
-	r = b[11 * c]; p.throughput = c3(r); p.rr.x = ubits(r.w);
-	r = b[12 * c]; p.path_col = c3(r); p.rr.c = ubits(r.w);
-	r = b[13 * c]; p.col = c3(r);
+	if(groups & G_RAY) { r = b[0 * c]; p.r_from = v3(r); p.r_tmin = r.w; r = b[1 * c]; p.r_dir = v3(r); p.r_tmax = r.w; }
+	if(groups & G_ANS) { r = b[2 * c]; p.tri = (int)ubits(r.x); p.t = r.y; p.bu = r.z; p.bv = r.w; p.shadowed = (p.tri != 0); }
+	if(groups & G_SP0)
 	{
+		r = b[3 * c]; p.sp0_p = v3(r); p.mat0 = (int)ubits(r.w);
+		r = b[4 * c]; p.sp0_n = v3(r);
+		r = b[5 * c]; p.sp0_ng = v3(r); p.bsdfs0 = ubits(r.w);
+		r = b[6 * c]; p.wo0 = v3(r);
+	}
+	if(groups & G_HIT)
+	{
+		r = b[7 * c]; p.hit_p = v3(r); p.hit_mat = (int)ubits(r.w);
+		r = b[8 * c]; p.hit_n = v3(r);
+		r = b[9 * c]; p.hit_ng = v3(r);
+		r = b[10 * c]; p.pwo = v3(r);
+	}
+	if(groups & G_PATH) { r = b[11 * c]; p.throughput = c3(r); p.rr.x = ubits(r.w); r = b[12 * c]; p.path_col = c3(r); p.rr.c = ubits(r.w); }
+	if(groups & G_CTRL)
+	{
+		r = b[13 * c]; p.col = c3(r);
 		const uint32_t w = ubits(r.w);
 		p.pc = (int)(w & 3u); p.stage = (int)((w >> 2) & 3u); p.dl_on_sp0 = (int)((w >> 4) & 1u);
 		p.depth = (int)((w >> 8) & 0xffu); p.path_i = (int)(w >> 16);
 	}
-	r = b[14 * c]; p.pending = c3(r);
+	if(groups & G_DLC)
 	{
+		r = b[14 * c]; p.pending = c3(r);
 		const uint32_t w = ubits(r.w);
 		p.li = (int)(w & 0xffu); p.l_end = (int)((w >> 8) & 0xffu); p.phase = (int)((w >> 16) & 0xfu); p.is = (int)(w >> 20);
 	}
-	r = b[15 * c]; p.ccol = c3(r);
-	r = b[16 * c]; p.ccol_2 = c3(r);
-	r = b[17 * c]; p.col_dirac = c3(r);
-	r = b[18 * c]; p.total = c3(r);
+	if(groups & G_ACC) { p.ccol = c3(b[15 * c]); p.ccol_2 = c3(b[16 * c]); p.col_dirac = c3(b[17 * c]); p.total = c3(b[18 * c]); }
+	if(groups & G_MISC) { r = b[19 * c]; p.offs = ubits(r.x); p.sampled_flags = ubits(r.y); p.one_light_calls = ubits(r.z); p.alpha = r.w; }
 }
 
 YG_DEV void wf_store(const WfArgs &a, uint32_t s, const PathRegs &p)
 {
 	float4 *b = a.state + s; const size_t c = a.cap;
-	b[0 * c] = f4(p.r_from, p.r_tmin);
-	b[1 * c] = f4(p.r_dir, p.r_tmax);
-	b[3 * c] = f4(p.sp0_p, fbits((uint32_t)p.mat0));
-	b[4 * c] = f4(p.sp0_n, fbits(p.sampled_flags));
-	b[5 * c] = f4(p.sp0_ng, fbits(p.bsdfs0));
-	b[6 * c] = f4(p.wo0, p.alpha);
-	b[7 * c] = f4(p.hit_p, fbits((uint32_t)p.hit_mat));
-	b[8 * c] = f4(p.hit_n, fbits(p.offs));
-	b[9 * c] = f4(p.hit_ng, fbits(p.one_light_calls));
-	b[10 * c] = f4(p.pwo, 0.f);
-	b[11 * c] = f4(p.throughput, fbits(p.rr.x));
-	b[12 * c] = f4(p.path_col, fbits(p.rr.c));
-	b[13 * c] = f4(p.col, fbits((uint32_t)p.pc | ((uint32_t)p.stage << 2) | ((uint32_t)p.dl_on_sp0 << 4) | ((uint32_t)p.depth << 8) | ((uint32_t)p.path_i << 16)));
-	b[14 * c] = f4(p.pending, fbits((uint32_t)p.li | ((uint32_t)p.l_end << 8) | ((uint32_t)p.phase << 16) | ((uint32_t)p.is << 20)));
-	b[15 * c] = f4(p.ccol, 0.f);
-	b[16 * c] = f4(p.ccol_2, 0.f);
-	b[17 * c] = f4(p.col_dirac, 0.f);
-	b[18 * c] = f4(p.total, 0.f);
+	const uint32_t d = p.dirty;
+	if(d & G_RAY) { b[0 * c] = f4(p.r_from, p.r_tmin); b[1 * c] = f4(p.r_dir, p.r_tmax); }
+	if(d & G_SP0)
+	{
+		b[3 * c] = f4(p.sp0_p, fbits((uint32_t)p.mat0));
+		b[4 * c] = f4(p.sp0_n, 0.f);
+		b[5 * c] = f4(p.sp0_ng, fbits(p.bsdfs0));
+		b[6 * c] = f4(p.wo0, 0.f);
+	}
+	if(d & G_HIT)
+	{
+		b[7 * c] = f4(p.hit_p, fbits((uint32_t)p.hit_mat));
+		b[8 * c] = f4(p.hit_n, 0.f);
+		b[9 * c] = f4(p.hit_ng, 0.f);
+		b[10 * c] = f4(p.pwo, 0.f);
+	}
+	if(d & G_PATH) { b[11 * c] = f4(p.throughput, fbits(p.rr.x)); b[12 * c] = f4(p.path_col, fbits(p.rr.c)); }
+	if(d & G_CTRL)
+		b[13 * c] = f4(p.col, fbits((uint32_t)p.pc | ((uint32_t)p.stage << 2) | ((uint32_t)p.dl_on_sp0 << 4) | ((uint32_t)p.depth << 8) | ((uint32_t)p.path_i << 16)));
+	if(d & G_DLC) b[14 * c] = f4(p.pending, fbits((uint32_t)p.li | ((uint32_t)p.l_end << 8) | ((uint32_t)p.phase << 16) | ((uint32_t)p.is << 20)));
+	if(d & G_ACC) { b[15 * c] = f4(p.ccol, 0.f); b[16 * c] = f4(p.ccol_2, 0.f); b[17 * c] = f4(p.col_dirac, 0.f); b[18 * c] = f4(p.total, 0.f); }
+	if(d & G_MISC) b[19 * c] = make_float4(fbits(p.offs), fbits(p.sampled_flags), fbits(p.one_light_calls), p.alpha);
 }
 
 // pixel of path slot s: chunk-local pixel -> tile (binary search over the per-tile pixel prefix) -> (px, py)
@@ -191,13 +217,16 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int li
 }
 
 // Resume a parked path and run it to its next kd-tree query (or to its end).
-YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4])
+YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, PathRegs &P, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4])
 {
 	const RenderArgs &ra = a.ra;
 	const DevScene &sc = ra.sc;
 	const yafgpu_render_params &rp = ra.rp;
 	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
 	enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH };
+#define NEED(g) wf_need(a, slot, P, (g))
+#define DIRTY(g) do { P.have |= (g); P.dirty |= (g); } while(0)
+	NEED(G_CTRL | G_ANS);
 	int where = (P.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
 	for(;;)
 	{
@@ -206,8 +235,10 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			case W_AFTER_CLOSEST:
 			{
 				const bool got = P.tri >= 0;
+				NEED(G_RAY);
 				if(P.stage == kStPrimary)
 				{
+					DIRTY(G_CTRL | G_MISC);
 					P.col = mkc(0.f, 0.f, 0.f);
 					P.alpha = rp.bg_transp ? 0.f : 1.f;
 					if(!got)
@@ -215,6 +246,7 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 						if(rp.has_background && !rp.bg_transp_refract) P.col = P.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
 						where = W_FINISH; break;
 					}
+					DIRTY(G_SP0 | G_PATH | G_ACC | G_DLC);
 					SurfPt sp0;
 					get_surface(sc, P.tri, P.r_from + P.r_dir * P.t, P.bu, P.bv, sp0);
 					P.sp0_p = sp0.p; P.sp0_n = sp0.n; P.sp0_ng = sp0.ng; P.mat0 = sp0.mat;
@@ -230,6 +262,7 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 						P.alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
 					}
 					P.path_col = mkc(0.f, 0.f, 0.f); P.throughput = mkc(1.f, 1.f, 1.f);
+					P.rr.init(fnv32a(ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
 					P.path_i = 0; P.depth = 0; P.one_light_calls = 0u; P.sampled_flags = kNone; P.offs = 0u;
 					P.total = mkc(0.f, 0.f, 0.f);
 					if((P.bsdfs0 & kDiffuse) && sc.n_lights > 0)
@@ -240,14 +273,20 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 					}
 					where = W_DL_DONE; break;
 				}
-				if(!got) { ++P.path_i; where = W_START_PATH; break; }
+				if(!got) { DIRTY(G_CTRL); ++P.path_i; where = W_START_PATH; break; }
+				NEED(G_MISC);
+				DIRTY(G_HIT | G_ACC | G_DLC | G_MISC | G_CTRL);
 				SurfPt hit;
 				get_surface(sc, P.tri, P.r_from + P.r_dir * P.t, P.bu, P.bv, hit);
 				P.hit_p = hit.p; P.hit_n = hit.n; P.hit_ng = hit.ng; P.hit_mat = hit.mat;
 				const yafgpu_material &pm = sc.mats[hit.mat];
 				BsdfDat dat_n;
 				const uint32_t mb = mat_init_bsdf(pm, dat_n);
-				if(P.stage == kStFirst) { if(P.sampled_flags != kNone) P.pwo = -P.r_dir; }
+				if(P.stage == kStFirst)
+				{
+					if(P.sampled_flags != kNone) P.pwo = -P.r_dir;
+					else { const float4 r10 = a.state[10 * (size_t)a.cap + slot]; P.pwo = v3(r10); }   // keeps the pwo of the first segment (:224)
+				}
 				else P.pwo = -P.r_dir;
 				P.total = mkc(0.f, 0.f, 0.f);
 				const bool want_dl = sc.n_lights > 0 && (P.stage == kStFirst || (mb & kDiffuse));
@@ -270,6 +309,8 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			}
 			case W_AFTER_SHADOW:
 			{
+				NEED(G_DLC | G_ACC);
+				DIRTY(G_DLC | G_ACC);
 				if(!P.shadowed)
 				{
 					const bool dirac = sc.lights[P.li].type == YAFGPU_LIGHT_POINT;
@@ -283,6 +324,7 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			case W_DL_NEXT:
 			{
 				// iterate (li, phase, is) in the order of direct_light(): for li { for phase { for is } }
+				NEED(P.dl_on_sp0 ? G_SP0 : G_HIT);
 				SurfPt sp;
 				if(P.dl_on_sp0) make_sp(P.sp0_p, P.sp0_n, P.sp0_ng, P.mat0, sp);
 				else make_sp(P.hit_p, P.hit_n, P.hit_ng, P.hit_mat, sp);
@@ -325,19 +367,24 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 					}
 					++P.is;
 				}
-				if(parked) { P.pc = kPcAfterShadow; return kReqShadow; }
+				if(parked) { DIRTY(G_RAY | G_CTRL | G_DLC | G_ACC); P.pc = kPcAfterShadow; return kReqShadow; }
 				where = W_DL_DONE; break;
 			}
 			case W_DL_DONE:
 			{
+				NEED(G_ACC | G_DLC);
+				DIRTY(G_CTRL);
 				if(P.stage == kStPrimary)
 				{
+					NEED(G_SP0);
 					if(P.bsdfs0 & kDiffuse) P.col = P.col + P.total;                                  // :156
 					const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
 					if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(P.bsdfs0 & path_flags)) { where = W_FINISH; break; }
 					P.path_i = 0;
 					where = W_START_PATH; break;
 				}
+				NEED(G_HIT | G_PATH);
+				DIRTY(G_PATH);
 				const yafgpu_material &pm = sc.mats[P.hit_mat];
 				BsdfDat dat_n;
 				const uint32_t mb = mat_init_bsdf(pm, dat_n);
@@ -372,6 +419,8 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			}
 			case W_EXTEND:
 			{
+				NEED(G_HIT | G_PATH | G_MISC | G_RAY);
+				DIRTY(G_PATH | G_RAY | G_CTRL);
 				const yafgpu_material &pm = sc.mats[P.hit_mat];
 				BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
 				SurfPt hit; make_sp(P.hit_p, P.hit_n, P.hit_ng, P.hit_mat, hit);
@@ -391,7 +440,10 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			}
 			case W_START_PATH:
 			{
+				NEED(G_PATH);
 				if(P.path_i >= n_paths) { P.col = P.col + P.path_col / (float)n_paths; where = W_FINISH; break; }
+				NEED(G_SP0 | G_MISC);
+				DIRTY(G_PATH | G_MISC | G_RAY | G_CTRL);
 				const yafgpu_material &m = sc.mats[P.mat0];
 				BsdfDat dat0; mat_init_bsdf(m, dat0);
 				SurfPt sp0; make_sp(P.sp0_p, P.sp0_n, P.sp0_ng, P.mat0, sp0);
@@ -404,6 +456,7 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 				float w = 0.f;
 				V3 p_dir = mk(0.f, 0.f, 0.f);
 				P.pwo = P.wo0;
+				a.state[10 * (size_t)a.cap + slot] = f4(P.pwo, 0.f);
 				const Col scol = mat_sample(m, dat0, sp0, P.pwo, p_dir, bs, w) * w;
 				P.throughput = scol;
 				P.sampled_flags = bs.sampled;
@@ -413,6 +466,7 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			}
 			default: // W_FINISH
 			{
+				NEED(G_MISC);
 				float alpha = P.alpha;
 				if(rp.bg_transp) alpha = smax(alpha, 0.f);
 				result[0] = P.col.r; result[1] = P.col.g; result[2] = P.col.b; result[3] = alpha;
@@ -420,6 +474,8 @@ YG_DEV int wf_advance(const WfArgs &a, PathRegs &P, uint32_t pixel_sample, uint3
 			}
 		}
 	}
+#undef NEED
+#undef DIRTY
 }
 
 // identity of a path slot: slot = pixel_local * spp + sample
@@ -474,9 +530,6 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 		float4 *b = a.state + slot; const size_t c = a.cap;
 		b[0 * c] = f4(from, tmin);
 		b[1 * c] = f4(dir, tmax);
-		Mwc rr; rr.init(fnv32a(ordinal) + 123u);
-		b[11 * c] = make_float4(1.f, 1.f, 1.f, fbits(rr.x));
-		b[12 * c] = make_float4(0.f, 0.f, 0.f, fbits(rr.c));
 		b[13 * c] = make_float4(0.f, 0.f, 0.f, fbits((uint32_t)kPcAfterClosest | ((uint32_t)kStPrimary << 2)));
 	}
 	if(blockIdx.x == 0 && threadIdx.x == 0) { a.cnt_in[0] = a.n_paths; a.cnt_in[1] = 0u; a.cnt_in[2] = 0u; a.cnt_in[3] = 0u; }
@@ -657,9 +710,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 			int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
 			wf_identity(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
 			PathRegs P;
-			wf_load(a, slot, P);
+			P.have = 0u; P.dirty = 0u;
 			float res[4];
-			req = wf_advance(a, P, pixel_sample, sampling_offs, ordinal, res);
+			req = wf_advance(a, slot, P, pixel_sample, sampling_offs, ordinal, res);
 			if(req == kReqDone)
 			{
 				if(res[3] > 1.f) res[3] = 1.f;    // integrator_tiled.cc:459

@@ -12,14 +12,17 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pass$i" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$out/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - "$out" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, re
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "render_kernel<false>" not in r["Kernel_Name"]: continue
-        agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-for c, d in sorted(agg.items()):
-    vals = list(d.values())
-    print(f"{c:28s} per-dispatch mean {sum(vals)/len(vals):.6g}  (n={len(vals)})")
+        k = r["Kernel_Name"]
+        if "yafgpu" not in k: continue
+        k = re.sub(r"\(.*", "", k).replace("void ", "").replace("yafgpu::", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k in sorted(agg):
+    print("==", k)
+    for c, v in sorted(agg[k].items()):
+        print(f"   {c:26s} {v:.6g}")
 PY

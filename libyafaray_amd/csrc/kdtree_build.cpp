@@ -36,20 +36,32 @@ struct Sub   // a subtree in private storage, indices relative to its own arrays
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
-constexpr int kBins = 64;
-constexpr int kSweepMax = 48;
+#ifndef KD_BINS
+#define KD_BINS 64
+#endif
+#ifndef KD_SWEEP
+#define KD_SWEEP 48
+#endif
+constexpr int kBins = KD_BINS;
+constexpr int kSweepMax = KD_SWEEP;
 
 struct Split { int axis = -1; float pos = 0.f; float cost = INFINITY; };
 
-inline float sah_cost(const Params &p, const float d[3], int axis, float l1, uint32_t nl, uint32_t nr, float inv_total_sa)
+// SAH cost of a plane, with the reference's empty-space bonus model: the bonus grows with the
+// fraction of the node the empty side takes (kdtree_triangle.cc:431-433) and decays with depth
+// (:498: e_bonus *= 1.1 - depth/max_depth), so thin empty slivers deep in the tree are not cut off.
+inline float sah_cost(const Params &p, const float d[3], int axis, float l1, uint32_t nl, uint32_t nr, float inv_total_sa, float e_bonus)
 {
 	const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
 	const float cap = d[a1] * d[a2], rim = d[a1] + d[a2];
-	const float below = cap + l1 * rim, above = cap + (d[axis] - l1) * rim;
-	const float eb = (nl == 0 || nr == 0) ? p.empty_bonus : 0.f;
-	return p.cost_ratio + inv_total_sa * (below * (float)nl + above * (float)nr) * (1.f - eb);
+	const float l2 = d[axis] - l1;
+	const float below = cap + l1 * rim, above = cap + l2 * rim;
+	const float raw = below * (float)nl + above * (float)nr;
+	float eb = 0.f;
+	if(nr == 0) eb = (0.1f + l2 / d[axis]) * e_bonus * raw;
+	else if(nl == 0) eb = (0.1f + l1 / d[axis]) * e_bonus * raw;
+	return p.cost_ratio + inv_total_sa * (raw - eb);
 }
-
 
 // Bounds of (triangle ∩ box), by Sutherland-Hodgman clipping in double precision ("perfect splits";
 // the reference clips too, for nodes of <= 32 prims: kdtree_triangle.cc:483-515).  The box is grown
@@ -102,7 +114,7 @@ bool clip_tri_to_box(const float *v, const Box &box, Box &out)
 	return true;
 }
 
-Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, uint32_t np)
+Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, uint32_t np, float e_bonus)
 {
 	Split best;
 	float d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
@@ -129,14 +141,14 @@ Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, 
 			nl += starts[k - 1];   // prims beginning before plane k
 			nr -= ends[k];         // prims ending at or before plane k no longer reach the right side
 			const float l1 = (float)k / scale;
-			const float c = sah_cost(p, d, axis, l1, nl, nr, inv_total_sa);
+			const float c = sah_cost(p, d, axis, l1, nl, nr, inv_total_sa, e_bonus);
 			if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = lo + l1; }
 		}
 	}
 	return best;
 }
 
-Split find_split_sweep(const Params &p, const Box &box, const Box *pbox, uint32_t np)
+Split find_split_sweep(const Params &p, const Box &box, const Box *pbox, uint32_t np, float e_bonus)
 {
 	Split best;
 	float d[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
@@ -163,7 +175,7 @@ Split find_split_sweep(const Params &p, const Box &box, const Box *pbox, uint32_
 			const float pos = edges[i].pos;
 			if(pos > box.lo[axis] && pos < box.hi[axis])
 			{
-				const float c = sah_cost(p, d, axis, pos - box.lo[axis], nl, nr, inv_total_sa);
+				const float c = sah_cost(p, d, axis, pos - box.lo[axis], nl, nr, inv_total_sa, e_bonus);
 				if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = pos; }
 			}
 			if(!edges[i].is_end) ++nl;
@@ -193,6 +205,7 @@ bool choose_and_partition(const Params &p, const Box &box, std::vector<uint32_t>
 {
 	uint32_t np = (uint32_t)prims.size();
 	if(np <= 1 || depth >= p.depth_cap) return false;
+	const float e_bonus = p.empty_bonus * (1.1f - (float)depth / (float)p.depth_cap);
 	Box local[kSweepMax];
 	const bool small = np <= (uint32_t)kSweepMax;
 	if(small)
@@ -206,9 +219,9 @@ bool choose_and_partition(const Params &p, const Box &box, std::vector<uint32_t>
 		prims.resize(m);
 		np = m;
 		if(np <= 1) return false;
-		sp = find_split_sweep(p, box, local, np);
+		sp = find_split_sweep(p, box, local, np, e_bonus);
 	}
-	else sp = find_split_binned(p, box, prims.data(), np);
+	else sp = find_split_binned(p, box, prims.data(), np, e_bonus);
 	if(sp.axis < 0) return false;
 	const float leaf_cost = (float)np;
 	if(sp.cost > leaf_cost) ++bad_refines;

@@ -165,21 +165,32 @@ def main():
     rays_total = int(c[0] + c[1])
     value = rays_total / elapsed / 1e6
 
-    # per-ray traversal averages for the algorithmic-bytes figure: one extra, untimed launch of the
-    # counting variant of the kernel (YAFGPU_STATS)
+    # per-ray traversal averages for the algorithmic-bytes figure + per-kernel device time: one extra,
+    # untimed pass of the counting variant of the traversal kernels with HIP events around every launch
     os.environ["YAFGPU_STATS"] = "1"
+    counters.zero_()
+    yi.setProfiling(True)
+    yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
+    torch.cuda.synchronize()
+    prof_stats = yi.getKernelProfile()
+    del os.environ["YAFGPU_STATS"]
+    s = counters.cpu().numpy().astype(np.float64)
+    # ... and once more with the production kernels for the durations that go into the roofline
     counters.zero_()
     yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
     torch.cuda.synchronize()
-    del os.environ["YAFGPU_STATS"]
-    s = counters.cpu().numpy().astype(np.float64)
+    prof = yi.getKernelProfile()
+    yi.setProfiling(False)
     rays_launch = s[0] + s[1]
     n_int, n_leaf, n_tri = s[2] / rays_launch, s[3] / rays_launch, s[4] / rays_launch
     # bytes/ray = 32 (ray) + 16 (hit) + 8*(interior+leaf nodes) + 4*leaf refs + 48*triangle records
     bytes_per_ray = 32 + 16 + 8 * (n_int + n_leaf) + 4 * n_tri + 48 * n_tri
-    # + film traffic: 4 planes zeroed + the owned pixels written once per launch (20 B/pixel/plane)
-    film_bytes = 2 * 4 * H * W * 5 * 4 / max(world, 1)
-    achieved = (bytes_per_ray * rays_launch + film_bytes) / (kernel_ms * 1e-3) / 1e9
+    trace_ms = prof["trace_closest"][0] + prof["trace_shadow"][0]
+    trace_launches = prof["trace_closest"][1] + prof["trace_shadow"][1]
+    if trace_launches == 0:       # one-kernel pipeline (YAFGPU_PIPELINE=megakernel): the pass is the kernel
+        trace_ms, trace_launches = kernel_ms, 1
+    # dominant kernel = the traversal kernel (wf_trace): algorithmic bytes of all its launches / their summed duration
+    achieved = bytes_per_ray * rays_launch / (trace_ms * 1e-3) / 1e9
 
     if rank == 0:
         out = {
@@ -192,9 +203,12 @@ def main():
                        "kd_nodes": int(stats0.kd_nodes), "kd_leaf_refs": int(stats0.kd_leaf_refs), "kd_max_depth": int(stats0.kd_max_depth),
                        "scene_device_MB": round(stats0.scene_device_bytes / 1e6, 1), "setup_s": round(setup_s, 2),
                        "tree_build_s": round(stats0.tree_build_seconds, 2)},
-            "roofline": {"bound": "hbm", "kernel": "render_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(bytes_per_ray, 1),
+            "roofline": {"bound": "hbm", "kernel": "wf_trace (closest-hit + any-hit kd traversal)", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launches_per_pass": int(trace_launches), "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),
+                         "rays_per_launch": round(rays_launch / max(trace_launches, 1)),
+                         "pass_ms": {k: round(v[0], 3) for k, v in prof.items()}, "pass_ms_total": round(kernel_ms, 3),
+                         "bytes_per_ray": round(bytes_per_ray, 1),
                          "per_ray": {"interior_nodes": round(n_int, 2), "leaves": round(n_leaf, 2), "tri_tests": round(n_tri, 2),
                                      "restarts": round(s[6] / rays_launch, 5)}},
         }

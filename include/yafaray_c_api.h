@@ -131,6 +131,10 @@ yafaray_bool_t yafaray_getRenderSize(yafaray_interface_t *yi, int *width, int *h
  * rays = n*8 floats {from.xyz, dir.xyz, tmin, tmax (<0 = infinite)}; tri = -1 on a miss */
 yafaray_bool_t yafaray_intersectRays(yafaray_interface_t *yi, int n, const float *rays, int *tri, float *t, float *bary);
 yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *rays, int *shadowed);
+/* per-kernel device timing of the next renderPassDevice (yafgpu_set_profiling / yafgpu_get_profile):
+ * ms[4]/launches[4] = closest-hit traversal, any-hit traversal, shading, other */
+yafaray_bool_t yafaray_setProfiling(yafaray_interface_t *yi, yafaray_bool_t enable);
+yafaray_bool_t yafaray_getKernelProfile(yafaray_interface_t *yi, double ms[4], uint64_t launches[4]);
 /* device-side component probe (yafgpu_probe) against the prepared scene's materials/lights/camera */
 yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float *in, int n_in, float *out, int n_out);
 

@@ -151,6 +151,12 @@ int yafgpu_render_to_host(yafgpu_scene_t *scene, const yafgpu_render_params *rp,
 int yafgpu_trace_closest(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *tri, float *t, float *bary);
 int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int32_t *shadowed);
 
+/* Per-kernel device timing of the NEXT render pass (HIP events around every launch on the pass's own
+ * stream; the pass then synchronises after each launch, so it is a measurement mode, not a fast path).
+ * slots: 0 closest-hit traversal, 1 any-hit traversal, 2 shading, 3 other (ray generation, film). */
+int yafgpu_set_profiling(yafgpu_scene_t *scene, int32_t enable);
+int yafgpu_get_profile(const yafgpu_scene_t *scene, double ms[4], uint64_t launches[4]);
+
 /* Component probe for tests: evaluates device-side leaf functions (fast-math, QMC, camera, lights,
  * material eval/pdf/sample) on n items of n_in floats each, writing n_out floats each; `op` selects the
  * function (see probe_kernel in yafgpu_device.hip).  Lets the device code be pinned against the

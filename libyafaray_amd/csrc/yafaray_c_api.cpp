@@ -643,6 +643,17 @@ yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *r
 	return 1;
 }
 
+yafaray_bool_t yafaray_setProfiling(yafaray_interface_t *yi, yafaray_bool_t enable)
+{
+	if(!yi->prepared) return fail(yi, "setProfiling: call prepareRender first");
+	return yafgpu_set_profiling(yi->gpu, enable) == 0;
+}
+yafaray_bool_t yafaray_getKernelProfile(yafaray_interface_t *yi, double ms[4], uint64_t launches[4])
+{
+	if(!yi->prepared) return fail(yi, "getKernelProfile: call prepareRender first");
+	return yafgpu_get_profile(yi->gpu, ms, launches) == 0;
+}
+
 yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float *in, int n_in, float *out, int n_out)
 {
 	if(!yi->prepared) return fail(yi, "probe: call prepareRender first");

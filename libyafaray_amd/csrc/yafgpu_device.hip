@@ -910,7 +910,7 @@ struct yafgpu_scene
 	int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
-	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr; uint32_t wf_cap = 0;
+	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr; uint32_t wf_cap = 0;
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
 };
@@ -1088,6 +1088,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_results) (void)hipFree(s->wf_results);
 	if(s->wf_queues) (void)hipFree(s->wf_queues);
 	if(s->wf_counts) (void)hipFree(s->wf_counts);
+	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 	delete s;
 }
 
@@ -1144,17 +1145,22 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->d_pix_prefix, s->pix_prefix_cap * sizeof(uint32_t)));
 	}
 	HIP_OK(hipMemcpy(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, kWfMaxPaths / spp));
+	uint32_t max_paths = kWfMaxPaths;
+	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(65536u, (uint32_t)std::strtoul(e, nullptr, 10));
+	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
 	const uint32_t cap = chunk_pixels * spp;
 	if(cap > s->wf_cap)
 	{
 		if(s->wf_state) (void)hipFree(s->wf_state);
 		if(s->wf_results) (void)hipFree(s->wf_results);
 		if(s->wf_queues) (void)hipFree(s->wf_queues);
-		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_cap = 0;
+		if(s->wf_verdict) (void)hipFree(s->wf_verdict);
+		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_verdict = nullptr; s->wf_cap = 0;
 		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)kWfRecs * cap * sizeof(float4)));
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
-		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)4 * cap * sizeof(uint32_t)));
+		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
+		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
+		HIP_OK(hipMalloc((void **)&s->wf_verdict, (size_t)2 * cap * sizeof(uint32_t)));
 		s->wf_cap = cap;
 	}
 	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 64 * sizeof(uint32_t)));
@@ -1170,7 +1176,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	for(int i = 0; i < s->n_lights; ++i)
 	{
 		const yafgpu_light &l = s->h_lights[(size_t)i];
-		const int r = l.type == YAFGPU_LIGHT_POINT ? 1 : 2 * (int)std::ceil((float)l.samples * rp.aa_light_sample_multiplier);
+		const int r = l.type == YAFGPU_LIGHT_POINT ? 1 : (int)std::ceil((float)l.samples * rp.aa_light_sample_multiplier);   // shadow parks (MIS pairs)
 		r_all += r; r_one = std::max(r_one, r);
 	}
 	int iters = 1 + r_all;
@@ -1198,17 +1204,21 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results;
 		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
 		a.pix_prefix = s->d_pix_prefix;
-		uint32_t *q[4] = {s->wf_queues, s->wf_queues + s->wf_cap, s->wf_queues + 2 * (size_t)s->wf_cap, s->wf_queues + 3 * (size_t)s->wf_cap};
+		const size_t cp = s->wf_cap;
+		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
+		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
 		uint32_t *cnt[2] = {s->wf_counts, s->wf_counts + 32};
+		a.verdict = s->wf_verdict;
 		a.cnt_in = cnt[0]; a.cnt_out = cnt[1];
-		a.q_closest_in = nullptr; a.q_shadow_in = q[1]; a.q_closest_out = q[2]; a.q_shadow_out = q[3];
+		a.q_closest_in = nullptr; a.q_shadow_in = qset[0][1]; a.q_resume_in = qset[0][2];
+		a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
 		const uint32_t g_gen = std::min<uint32_t>((a.n_paths + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		int rc;
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
 		int cur = 0;
 		for(int it = 0; it < iters; ++it)
 		{
-			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 4 * sizeof(uint32_t), stream));
+			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 8 * sizeof(uint32_t), stream));
 			if((rc = timed(0, [&] {
 				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
 				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
@@ -1219,8 +1229,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			// swap queues: what shade produced is the next iteration's input
 			cur ^= 1;
 			a.cnt_in = cnt[cur]; a.cnt_out = cnt[cur ^ 1];
-			if(cur) { a.q_closest_in = q[2]; a.q_shadow_in = q[3]; a.q_closest_out = q[0]; a.q_shadow_out = q[1]; }
-			else { a.q_closest_in = q[0]; a.q_shadow_in = q[1]; a.q_closest_out = q[2]; a.q_shadow_out = q[3]; }
+			a.q_closest_in = qset[cur][0]; a.q_shadow_in = qset[cur][1]; a.q_resume_in = qset[cur][2];
+			a.q_closest_out = qset[cur ^ 1][0]; a.q_shadow_out = qset[cur ^ 1][1]; a.q_resume_out = qset[cur ^ 1][2];
 		}
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
@@ -1384,6 +1394,19 @@ int yafgpu_trace_shadow(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t
 {
 	if(!shadowed) return fail(-1, "null output");
 	return trace_batch(s, n, rays, nullptr, nullptr, nullptr, shadowed, true);
+}
+
+int yafgpu_set_profiling(yafgpu_scene_t *s, int32_t enable)
+{
+	if(!s) return fail(-1, "null argument");
+	s->profiling = enable != 0;
+	return 0;
+}
+int yafgpu_get_profile(const yafgpu_scene_t *s, double ms[4], uint64_t launches[4])
+{
+	if(!s) return fail(-1, "null argument");
+	for(int k = 0; k < 4; ++k) { ms[k] = s->prof_ms[k]; launches[k] = s->prof_launches[k]; }
+	return 0;
 }
 
 int yafgpu_probe(yafgpu_scene_t *s, int32_t op, int32_t n, const float *in, int32_t n_in, float *out, int32_t n_out)

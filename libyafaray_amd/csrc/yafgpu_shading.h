@@ -3,6 +3,17 @@
 // inline functions over POD records (yafgpu.h) — no vtables, no per-hit scratch allocation.
 #pragma once
 #include "yafgpu_math.h"
+
+// Material entry points are called from several places of the shading kernels; YG_MAT decides whether every
+// call site gets its own inlined copy (YAFGPU_NOINLINE_MAT=0) or shares one body (=1, smaller instruction footprint).
+#ifndef YAFGPU_NOINLINE_MAT
+#define YAFGPU_NOINLINE_MAT 0
+#endif
+#if YAFGPU_NOINLINE_MAT
+#define YG_MAT __device__ __attribute__((noinline))
+#else
+#define YG_MAT __device__ __forceinline__
+#endif
 #include "../../include/yafgpu.h"
 
 namespace yafgpu {
@@ -122,7 +133,7 @@ YG_DEV V3 blinn_sample(float s_1, float s_2, float e) // :99-106
 }
 
 // Material::eval — material_shiny_diffuse.cc:244-293, material_glossy.cc:113-173
-YG_DEV Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
+YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
 {
 	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
 	{
@@ -165,7 +176,7 @@ YG_DEV Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 }
 
 // Material::pdf — material_shiny_diffuse.cc:410-460, material_glossy.cc:359-405
-YG_DEV float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wi, uint32_t bsdfs)
+YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wi, uint32_t bsdfs)
 {
 	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
 	{
@@ -231,7 +242,7 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 
 // Material::sample — material_shiny_diffuse.cc:308-408, material_glossy.cc:176-357 (Blinn branch),
 // material_simple.cc:41-46
-YG_DEV Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
+YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
 {
 	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
 	{

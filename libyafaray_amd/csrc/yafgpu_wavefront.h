@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 20;   // float4 records of parked state per path (320 B)
+constexpr int kWfRecs = 22;   // float4 records of parked state per path (352 B)
 
 struct WfArgs
 {
@@ -28,28 +28,18 @@ struct WfArgs
 	float4 *results;                  // final rgba per path
 	uint32_t n_paths, pixel_begin, n_pixels;
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
-	const uint32_t *q_closest_in, *q_shadow_in;   // nullptr closest queue = identity (first iteration)
-	uint32_t *q_closest_out, *q_shadow_out;
-	uint32_t *cnt_in;                 // [0] closest count, [1] shadow count, [2] closest fetch cursor, [3] shadow fetch cursor
+	// closest queue: one entry per path (the path's ray).  shadow queue: one entry per shadow RAY,
+	// slot | which<<31 — a path parks with up to two (the light-sampling and the BSDF-sampling ray of one
+	// MIS pair).  resume queue: the paths (once each) that wait for shadow answers.
+	const uint32_t *q_closest_in, *q_shadow_in, *q_resume_in;   // nullptr closest queue = identity (first iteration)
+	uint32_t *q_closest_out, *q_shadow_out, *q_resume_out;
+	uint32_t *verdict;                // [2*slot + which] any-hit answers
+	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
 
 enum : int { kPcAfterClosest = 1, kPcAfterShadow = 2 };
 enum : int { kReqDone = 0, kReqClosest = 1, kReqShadow = 2 };
-
-struct PathRegs
-{
-	V3 r_from, r_dir; float r_tmin, r_tmax;          // r0, r1: the pending ray (closest: as is; shadow: dir/tmin/tmax of the light ray)
-	int tri; float t, bu, bv;                        // r2: answer of the closest-hit query
-	V3 sp0_p, sp0_n, sp0_ng; int mat0; uint32_t bsdfs0; V3 wo0; float alpha;   // r3..r6
-	V3 hit_p, hit_n, hit_ng; int hit_mat; V3 pwo;    // r7..r10
-	uint32_t sampled_flags, offs, one_light_calls;
-	Col throughput, path_col, col; Mwc rr;           // r11..r13
-	int pc, stage, path_i, depth, dl_on_sp0;
-	Col pending, ccol, ccol_2, col_dirac, total;     // r14..r18
-	int li, l_end, phase, is, shadowed;
-	uint32_t have, dirty;                            // record groups present in registers / modified
-};
 
 YG_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 YG_DEV float4 f4(Col c, float w) { return make_float4(c.r, c.g, c.b, w); }
@@ -57,88 +47,6 @@ YG_DEV V3 v3(float4 f) { return mk(f.x, f.y, f.z); }
 YG_DEV Col c3(float4 f) { return mkc(f.x, f.y, f.z); }
 YG_DEV float fbits(uint32_t u) { return __uint_as_float(u); }
 YG_DEV uint32_t ubits(float f) { return __float_as_uint(f); }
-
-// Parked state is read and written by record group, on demand: a path that resumes after a shadow
-// ray and parks again for the next one touches ~10 of the 20 records, not all of them.
-enum : uint32_t {
-	G_RAY = 1u << 0,    // r0, r1   pending ray
-	G_ANS = 1u << 1,    // r2       answer of the last query
-	G_SP0 = 1u << 2,    // r3..r6   camera hit: p|mat0, n, ng|bsdfs0, wo0
-	G_HIT = 1u << 3,    // r7..r10  current path vertex: p|mat, n, ng, pwo
-	G_PATH = 1u << 4,   // r11, r12 throughput|rr.x, path_col|rr.c
-	G_CTRL = 1u << 5,   // r13      col | pc, stage, depth, path_i
-	G_DLC = 1u << 6,    // r14      pending contribution | li, l_end, phase, is
-	G_ACC = 1u << 7,    // r15..r18 ccol, ccol_2, col_dirac, total
-	G_MISC = 1u << 8,   // r19      offs, sampled_flags, one_light_calls, alpha
-};
-
-YG_DEV void wf_need(const WfArgs &a, uint32_t s, PathRegs &p, uint32_t groups)
-{
-	groups &= ~p.have;
-	if(!groups) return;
-	p.have |= groups;
-	const float4 *b = a.state + s; const size_t c = a.cap;
-	float4 r;
-	if(groups & G_RAY) { r = b[0 * c]; p.r_from = v3(r); p.r_tmin = r.w; r = b[1 * c]; p.r_dir = v3(r); p.r_tmax = r.w; }
-	if(groups & G_ANS) { r = b[2 * c]; p.tri = (int)ubits(r.x); p.t = r.y; p.bu = r.z; p.bv = r.w; p.shadowed = (p.tri != 0); }
-	if(groups & G_SP0)
-	{
-		r = b[3 * c]; p.sp0_p = v3(r); p.mat0 = (int)ubits(r.w);
-		r = b[4 * c]; p.sp0_n = v3(r);
-		r = b[5 * c]; p.sp0_ng = v3(r); p.bsdfs0 = ubits(r.w);
-		r = b[6 * c]; p.wo0 = v3(r);
-	}
-	if(groups & G_HIT)
-	{
-		r = b[7 * c]; p.hit_p = v3(r); p.hit_mat = (int)ubits(r.w);
-		r = b[8 * c]; p.hit_n = v3(r);
-		r = b[9 * c]; p.hit_ng = v3(r);
-		r = b[10 * c]; p.pwo = v3(r);
-	}
-	if(groups & G_PATH) { r = b[11 * c]; p.throughput = c3(r); p.rr.x = ubits(r.w); r = b[12 * c]; p.path_col = c3(r); p.rr.c = ubits(r.w); }
-	if(groups & G_CTRL)
-	{
-		r = b[13 * c]; p.col = c3(r);
-		const uint32_t w = ubits(r.w);
-		p.pc = (int)(w & 3u); p.stage = (int)((w >> 2) & 3u); p.dl_on_sp0 = (int)((w >> 4) & 1u);
-		p.depth = (int)((w >> 8) & 0xffu); p.path_i = (int)(w >> 16);
-	}
-	if(groups & G_DLC)
-	{
-		r = b[14 * c]; p.pending = c3(r);
-		const uint32_t w = ubits(r.w);
-		p.li = (int)(w & 0xffu); p.l_end = (int)((w >> 8) & 0xffu); p.phase = (int)((w >> 16) & 0xfu); p.is = (int)(w >> 20);
-	}
-	if(groups & G_ACC) { p.ccol = c3(b[15 * c]); p.ccol_2 = c3(b[16 * c]); p.col_dirac = c3(b[17 * c]); p.total = c3(b[18 * c]); }
-	if(groups & G_MISC) { r = b[19 * c]; p.offs = ubits(r.x); p.sampled_flags = ubits(r.y); p.one_light_calls = ubits(r.z); p.alpha = r.w; }
-}
-
-YG_DEV void wf_store(const WfArgs &a, uint32_t s, const PathRegs &p)
-{
-	float4 *b = a.state + s; const size_t c = a.cap;
-	const uint32_t d = p.dirty;
-	if(d & G_RAY) { b[0 * c] = f4(p.r_from, p.r_tmin); b[1 * c] = f4(p.r_dir, p.r_tmax); }
-	if(d & G_SP0)
-	{
-		b[3 * c] = f4(p.sp0_p, fbits((uint32_t)p.mat0));
-		b[4 * c] = f4(p.sp0_n, 0.f);
-		b[5 * c] = f4(p.sp0_ng, fbits(p.bsdfs0));
-		b[6 * c] = f4(p.wo0, 0.f);
-	}
-	if(d & G_HIT)
-	{
-		b[7 * c] = f4(p.hit_p, fbits((uint32_t)p.hit_mat));
-		b[8 * c] = f4(p.hit_n, 0.f);
-		b[9 * c] = f4(p.hit_ng, 0.f);
-		b[10 * c] = f4(p.pwo, 0.f);
-	}
-	if(d & G_PATH) { b[11 * c] = f4(p.throughput, fbits(p.rr.x)); b[12 * c] = f4(p.path_col, fbits(p.rr.c)); }
-	if(d & G_CTRL)
-		b[13 * c] = f4(p.col, fbits((uint32_t)p.pc | ((uint32_t)p.stage << 2) | ((uint32_t)p.dl_on_sp0 << 4) | ((uint32_t)p.depth << 8) | ((uint32_t)p.path_i << 16)));
-	if(d & G_DLC) b[14 * c] = f4(p.pending, fbits((uint32_t)p.li | ((uint32_t)p.l_end << 8) | ((uint32_t)p.phase << 16) | ((uint32_t)p.is << 20)));
-	if(d & G_ACC) { b[15 * c] = f4(p.ccol, 0.f); b[16 * c] = f4(p.ccol_2, 0.f); b[17 * c] = f4(p.col_dirac, 0.f); b[18 * c] = f4(p.total, 0.f); }
-	if(d & G_MISC) b[19 * c] = make_float4(fbits(p.offs), fbits(p.sampled_flags), fbits(p.one_light_calls), p.alpha);
-}
 
 // pixel of path slot s: chunk-local pixel -> tile (binary search over the per-tile pixel prefix) -> (px, py)
 YG_DEV void wf_pixel_of(const WfArgs &a, uint32_t pixel_local, int &px, int &py)
@@ -153,12 +61,25 @@ YG_DEV void wf_pixel_of(const WfArgs &a, uint32_t pixel_local, int &px, int &py)
 
 YG_DEV void make_sp(V3 p, V3 n, V3 ng, int mat, SurfPt &sp) { sp.p = p; sp.n = n; sp.ng = ng; sp.mat = mat; create_cs(n, sp.nu, sp.nv); }
 
+// The (s_1, s_2) of light sample `is`: doLightEstimation restarts Halton(2)/Halton(3) at offs-1 for both
+// halves of the MIS pair (integrator_montecarlo.cc:164-165,285-286), so the pair shares them.
+YG_DEV void dl_samples(const RenderArgs &ra, const yafgpu_light &light, int li, int is, uint32_t pixel_sample, uint32_t sampling_offs, float &s_1, float &s_2)
+{
+	const int n = (int)ceilf((float)light.samples * ra.rp.aa_light_sample_multiplier);
+	const uint32_t offs = (uint32_t)n * pixel_sample + sampling_offs + (uint32_t)li * 4567u;
+	Halton hal_2, hal_3;
+	hal_2.init(2u); hal_3.init(3u);
+	hal_2.set_start(offs - 1u); hal_3.set_start(offs - 1u);
+	s_1 = 0.f; s_2 = 0.f;
+	for(int k = 0; k <= is; ++k) { s_1 = hal_2.next(); s_2 = hal_3.next(); }   // the incremental sequence, replayed
+}
+
 // One candidate of MonteCarloIntegrator::doLightEstimation (integrator_montecarlo.cc:78-345): light
 // `li`, half `phase` of the MIS pair (0 light sampling :161-262, 1 BSDF sampling :285-333; Dirac lights
-// have a single half :94-148), sample `is`.  Returns whether a shadow ray is wanted and, if so, the ray
-// and the radiance it would carry if unoccluded — identical arithmetic to direct_light().
-YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int li, int phase, int is, const SurfPt &sp, const yafgpu_material &mat,
-                         const BsdfDat &dat, V3 wo, uint32_t pixel_sample, uint32_t sampling_offs, V3 &r_dir, float &r_tmin, float &r_tmax, Col &contrib)
+// have a single half :94-148).  Returns whether a shadow ray is wanted and, if so, the ray and the
+// radiance it would carry if unoccluded — identical arithmetic to direct_light().
+YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int phase, float s_1, float s_2, const SurfPt &sp, const yafgpu_material &mat,
+                         const BsdfDat &dat, V3 wo, V3 &r_dir, float &r_tmin, float &r_tmax, Col &contrib)
 {
 	const uint32_t kMisFlags = kGlossy | kDiffuse | kDispersive | kReflect | kTransmit;
 	r_dir = mk(0.f, 0.f, 0.f); r_tmin = 0.f; r_tmax = -1.f;
@@ -172,13 +93,6 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int li
 		contrib = (mat_eval(mat, dat, sp, wo, r_dir, kAll) * lcol) * angle;
 		return true;
 	}
-	const int n = (int)ceilf((float)light.samples * ra.rp.aa_light_sample_multiplier);
-	const uint32_t offs = (uint32_t)n * pixel_sample + sampling_offs + (uint32_t)li * 4567u;
-	Halton hal_2, hal_3;
-	hal_2.init(2u); hal_3.init(3u);
-	hal_2.set_start(offs - 1u); hal_3.set_start(offs - 1u);
-	float s_1 = 0.f, s_2 = 0.f;
-	for(int k = 0; k <= is; ++k) { s_1 = hal_2.next(); s_2 = hal_3.next(); }   // the incremental sequence, replayed
 	if(phase == 0)
 	{
 		float ls_pdf;
@@ -216,267 +130,339 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int li
 	return true;
 }
 
-// Resume a parked path and run it to its next kd-tree query (or to its end).
-YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, PathRegs &P, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4])
+// ---- the per-path program, cut into steps that talk to each other through the parked records ----
+//
+// Record map (float4 each, record k of path s at state[k*cap + s]):
+//   r0  ray origin | tmin            r1  ray direction | tmax          r2  closest-hit answer (tri, t, u, v)
+//   r3  sp0.p | mat0     r4 sp0.n    r5  sp0.ng | bsdfs0     r6  wo0                      (camera hit)
+//   r7  hit.p | mat      r8 hit.n    r9  hit.ng              r10 pwo                      (current path vertex)
+//   r11 throughput | rr.x            r12 path_col | rr.c     r13 col | pc,stage,dl_on_sp0,depth,path_i
+//   r14 pending A | li,l_end,mask,is r15 ccol   r16 ccol_2   r17 col_dirac   r18 total   (light estimate in flight)
+//   r19 offs, sampled_flags, one_light_calls, alpha
+//   r20 second shadow ray: direction | tmin      r21 pending B | tmax of the second ray
+// Each step loads only what it uses and stores what it produced, so that no step keeps the whole path
+// in registers: the live set of wf_shade is that of its widest step, not of the whole integrator.
+#define REC(k) a.state[(size_t)(k) * a.cap + slot]
+
+struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i; };
+YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.depth << 8) | ((uint32_t)c.path_i << 16); }
+YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 {
-	const RenderArgs &ra = a.ra;
-	const DevScene &sc = ra.sc;
-	const yafgpu_render_params &rp = ra.rp;
+	const float4 r = REC(13);
+	const uint32_t w = ubits(r.w);
+	Ctl c; c.col = c3(r);
+	c.pc = (int)(w & 3u); c.stage = (int)((w >> 2) & 3u); c.dl_on_sp0 = (int)((w >> 4) & 1u); c.depth = (int)((w >> 8) & 0xffu); c.path_i = (int)(w >> 16);
+	return c;
+}
+YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
+
+enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
+
+// the closest-hit query of this path was answered: shade the new vertex up to its light estimate
+YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ordinal)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	const float4 ans = REC(2);
+	const int tri = (int)ubits(ans.x);
+	const bool got = tri >= 0;
+	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if(c.stage == kStPrimary)
+	{
+		c.col = mkc(0.f, 0.f, 0.f);
+		float alpha = rp.bg_transp ? 0.f : 1.f;
+		if(!got)
+		{
+			if(rp.has_background && !rp.bg_transp_refract) c.col = c.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
+			REC(19) = make_float4(0.f, 0.f, 0.f, alpha);
+			return W_FINISH;
+		}
+		const float4 r0 = REC(0), r1 = REC(1);
+		const V3 dir = v3(r1);
+		SurfPt sp0;
+		get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, sp0);
+		const yafgpu_material &m = sc.mats[sp0.mat];
+		BsdfDat dat0;
+		const uint32_t bsdfs0 = mat_init_bsdf(m, dat0);
+		const V3 wo0 = -dir;
+		if(bsdfs0 & kEmit) c.col = c.col + mat_emit(m, sp0, wo0, true);                       // :152 (include_lights_ :133)
+		alpha = 1.f;
+		if(rp.bg_transp_refract)
+		{
+			const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+			alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
+		}
+		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
+		Mwc rr; rr.init(fnv32a(ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
+		REC(11) = make_float4(1.f, 1.f, 1.f, fbits(rr.x));
+		REC(12) = make_float4(0.f, 0.f, 0.f, fbits(rr.c));
+		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(0u), alpha);
+		REC(18) = z4;
+		c.path_i = 0; c.depth = 0;
+		if((bsdfs0 & kDiffuse) && sc.n_lights > 0)
+		{
+			REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0)));
+			REC(15) = z4; REC(16) = z4; REC(17) = z4;
+			c.dl_on_sp0 = 1;
+			return W_DL_NEXT;
+		}
+		REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0)));
+		return W_DL_DONE;
+	}
+	if(!got) { ++c.path_i; return W_START_PATH; }                                              // :218 / :259-266
+	const float4 r0 = REC(0), r1 = REC(1);
+	const V3 dir = v3(r1);
+	SurfPt hit;
+	get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, hit);
+	const yafgpu_material &pm = sc.mats[hit.mat];
+	BsdfDat dat_n;
+	const uint32_t mb = mat_init_bsdf(pm, dat_n);
+	float4 misc = REC(19);
+	V3 pwo = -dir;                                                                              // :271
+	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
+	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, 0.f); REC(9) = f4(hit.ng, 0.f); REC(10) = f4(pwo, 0.f);
+	REC(18) = z4;
+	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
+	if(want_dl)
+	{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
+		const uint32_t calls = ubits(misc.z);
+		int lnum = 0;
+		if(sc.n_lights > 1)
+		{
+			Halton h2; h2.init(2u);
+			h2.set_start(rp.base_sampling_offset + (ordinal * 16u + calls) - 1u);
+			lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
+		}
+		misc.z = fbits(calls + 1u);
+		REC(19) = misc;
+		REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0)));
+		REC(15) = z4; REC(16) = z4; REC(17) = z4;
+		c.dl_on_sp0 = 0;
+		return W_DL_NEXT;
+	}
+	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0)));   // l_end == 0: no light estimate ran
+	return W_DL_DONE;
+}
+
+// the shadow rays of one MIS pair were answered: add what was unoccluded
+YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot)
+{
+	const DevScene &sc = a.ra.sc;
+	float4 r14 = REC(14);
+	const uint32_t w = ubits(r14.w);
+	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0xfu), is = (int)(w >> 20);
+	const bool dirac = sc.lights[li].type == YAFGPU_LIGHT_POINT;
+	if((mask & 1) && a.verdict[2u * slot] == 0u)
+	{
+		const int k = dirac ? 17 : 15;
+		REC(k) = f4(c3(REC(k)) + c3(r14), 0.f);
+	}
+	if((mask & 2) && a.verdict[2u * slot + 1u] == 0u) REC(16) = f4(c3(REC(16)) + c3(REC(21)), 0.f);
+	r14.w = fbits(pack_dlc(li, l_end, 0, is + 1));
+	REC(14) = r14;
+	return W_DL_NEXT;
+}
+
+// direct_light()'s loops, with the two halves of a MIS pair (same light, same sample index) taken together:
+// each half adds into its own accumulator (ccol / ccol_2) in sample order, exactly as `for phase { for is }` does
+YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	const uint32_t w = ubits(REC(14).w);
+	int li = (int)(w & 0xffu), is = (int)(w >> 20);
+	const int l_end = (int)((w >> 8) & 0xffu);
+	SurfPt sp; V3 wo;
+	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
+	else { const float4 p = REC(7); make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), sp); wo = v3(REC(10)); }
+	const yafgpu_material &mat = sc.mats[sp.mat];
+	BsdfDat dat; mat_init_bsdf(mat, dat);
+	while(li < l_end)
+	{
+		const yafgpu_light &light = sc.lights[li];
+		const bool dirac = light.type == YAFGPU_LIGHT_POINT;
+		const int n = dirac ? 1 : (int)ceilf((float)light.samples * rp.aa_light_sample_multiplier);
+		if(is >= n)
+		{
+			const float inv_ns = 1.f / (float)n;
+			Col col = mkc(0.f, 0.f, 0.f);
+			if(dirac) col = col + c3(REC(17));
+			else { col = col + c3(REC(15)) * inv_ns; col = col + c3(REC(16)) * inv_ns; }
+			REC(18) = f4(c3(REC(18)) + col, 0.f);
+			const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+			REC(15) = z4; REC(16) = z4; REC(17) = z4;
+			is = 0; ++li;
+			continue;
+		}
+		const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
+		float s_1 = 0.f, s_2 = 0.f;
+		if(!dirac) dl_samples(ra, light, li, is, pixel_sample, sampling_offs, s_1, s_2);
+		V3 d; float tmin, tmax; Col contrib;
+		int mask = 0;
+		Col pending_a = mkc(0.f, 0.f, 0.f);
+		float tmin_a = 0.f;
+		if(dl_candidate(ra, light, 0, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
+		{
+			if(cast_shadows) { pending_a = contrib; tmin_a = tmin; REC(1) = f4(d, tmax); mask |= 1; }
+			else { const int k = dirac ? 17 : 15; REC(k) = f4(c3(REC(k)) + contrib, 0.f); }
+		}
+		if(!dirac && dl_candidate(ra, light, 1, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
+		{
+			if(cast_shadows) { REC(20) = f4(d, tmin); REC(21) = f4(contrib, tmax); mask |= 2; }
+			else REC(16) = f4(c3(REC(16)) + contrib, 0.f);
+		}
+		if(mask)
+		{
+			REC(0) = f4(sp.p, tmin_a);
+			REC(14) = f4(pending_a, fbits(pack_dlc(li, l_end, mask, is)));
+			out_mask = mask;
+			return W_PARK_SHADOW;
+		}
+		++is;
+	}
+	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is)));
+	return W_DL_DONE;
+}
+
+// the light estimate of the current vertex is complete: book it and decide how the path goes on
+YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	const Col total = c3(REC(18));
+	const int l_end = (int)((ubits(REC(14).w) >> 8) & 0xffu);
+	if(c.stage == kStPrimary)
+	{
+		const uint32_t bsdfs0 = ubits(REC(5).w);
+		if(bsdfs0 & kDiffuse) c.col = c.col + total;                                            // :156
+		const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
+		if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) return W_FINISH;
+		c.path_i = 0;
+		return W_START_PATH;
+	}
+	const yafgpu_material &pm = sc.mats[(int)ubits(REC(7).w)];
+	BsdfDat dat_n;
+	const uint32_t mb = mat_init_bsdf(pm, dat_n);
+	Col lcol = mkc(0.f, 0.f, 0.f);
+	if(l_end > 0) lcol = total * (float)sc.n_lights;
+	float4 r11 = REC(11), r12 = REC(12);
+	Col throughput = c3(r11), path_col = c3(r12);
+	if(c.stage == kStFirst)
+	{
+		if(mb & kEmit)
+		{	// :226 — include_lights_ is false here, so only shinydiffuse's own emission can contribute
+			SurfPt dummy; dummy.n = mk(0.f, 0.f, 0.f);
+			lcol = lcol + mat_emit(pm, dummy, mk(0.f, 0.f, 0.f), false);
+		}
+		path_col = path_col + lcol * throughput;                                                // :228
+		REC(12) = f4(path_col, r12.w);
+		c.depth = 1;
+		if(c.depth < rp.bounces) return W_EXTEND;
+		++c.path_i;
+		return W_START_PATH;
+	}
+	bool alive = true;
+	if(c.depth > rp.rr_min_bounces)
+	{	// Russian roulette :282-288
+		Mwc rr; rr.x = ubits(r11.w); rr.c = ubits(r12.w);
+		const float random_value = (float)rr.next();
+		r11.w = fbits(rr.x); r12.w = fbits(rr.c);
+		const float probability = smax(throughput.r, smax(throughput.g, throughput.b));
+		if(probability <= 0.f || probability < random_value) alive = false;
+		else throughput = throughput * (1.f / probability);
+	}
+	if(alive)
+	{
+		path_col = path_col + lcol * throughput;                                                // :292
+		++c.depth;
+	}
+	REC(11) = f4(throughput, r11.w); REC(12) = f4(path_col, r12.w);
+	if(alive && c.depth < rp.bounces) return W_EXTEND;
+	++c.path_i;
+	return W_START_PATH;
+}
+
+// next segment from the current vertex, :232-257
+YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
+	const float4 p = REC(7);
+	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
+	const V3 pwo = v3(REC(10));
+	const yafgpu_material &pm = sc.mats[hit.mat];
+	BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
+	const uint32_t offs = ubits(REC(19).x);
+	const int d_4 = 4 * c.depth;
+	BsdfSample bs;
+	bs.s_1 = (float)scr_halton(sc, d_4 + 3, offs);
+	bs.s_2 = (float)scr_halton(sc, d_4 + 4, offs);
+	bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
+	float w = 0.f;
+	V3 p_dir = mk(0.f, 0.f, 0.f);
+	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
+	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
+	const float4 r11 = REC(11);
+	REC(11) = f4(c3(r11) * scol, r11.w);
+	REC(0) = f4(hit.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
+	c.stage = kStDepth;
+	return W_PARK_CLOSEST;
+}
+
+// first segment of path sample `path_i` from the camera hit, :186-216 — or the end of the sample
+YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
-	enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH };
-#define NEED(g) wf_need(a, slot, P, (g))
-#define DIRTY(g) do { P.have |= (g); P.dirty |= (g); } while(0)
-	NEED(G_CTRL | G_ANS);
-	int where = (P.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
+	if(c.path_i >= n_paths) { c.col = c.col + c3(REC(12)) / (float)n_paths; return W_FINISH; } // :297
+	const float4 p = REC(3);
+	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
+	const V3 wo0 = v3(REC(6));
+	const yafgpu_material &m = sc.mats[sp0.mat];
+	BsdfDat dat0; mat_init_bsdf(m, dat0);
+	const uint32_t offs = (uint32_t)rp.path_samples * pixel_sample + sampling_offs + (uint32_t)c.path_i;
+	BsdfSample bs;
+	bs.s_1 = ri_vdc(offs, 0u);
+	bs.s_2 = (float)scr_halton(sc, 2, offs);
+	bs.pdf = 0.f; bs.sampled = kNone;
+	bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
+	float w = 0.f;
+	V3 p_dir = mk(0.f, 0.f, 0.f);
+	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
+	REC(10) = f4(wo0, 0.f);                          // pwo = wo
+	REC(11) = f4(scol, REC(11).w);                   // throughput = scol
+	float4 misc = REC(19);
+	misc.x = fbits(offs); misc.y = fbits(bs.sampled);
+	REC(19) = misc;
+	REC(0) = f4(sp0.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
+	c.stage = kStFirst;
+	return W_PARK_CLOSEST;
+}
+
+// Resume a parked path and run it to its next kd-tree query (or to its end).
+YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4], int &out_mask)
+{
+	Ctl c = load_ctl(a, slot);
+	int where = (c.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
 	for(;;)
 	{
 		switch(where)
 		{
-			case W_AFTER_CLOSEST:
-			{
-				const bool got = P.tri >= 0;
-				NEED(G_RAY);
-				if(P.stage == kStPrimary)
-				{
-					DIRTY(G_CTRL | G_MISC);
-					P.col = mkc(0.f, 0.f, 0.f);
-					P.alpha = rp.bg_transp ? 0.f : 1.f;
-					if(!got)
-					{
-						if(rp.has_background && !rp.bg_transp_refract) P.col = P.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
-						where = W_FINISH; break;
-					}
-					DIRTY(G_SP0 | G_PATH | G_ACC | G_DLC);
-					SurfPt sp0;
-					get_surface(sc, P.tri, P.r_from + P.r_dir * P.t, P.bu, P.bv, sp0);
-					P.sp0_p = sp0.p; P.sp0_n = sp0.n; P.sp0_ng = sp0.ng; P.mat0 = sp0.mat;
-					const yafgpu_material &m = sc.mats[sp0.mat];
-					BsdfDat dat0;
-					P.bsdfs0 = mat_init_bsdf(m, dat0);
-					P.wo0 = -P.r_dir;
-					if(P.bsdfs0 & kEmit) P.col = P.col + mat_emit(m, sp0, P.wo0, true);
-					P.alpha = 1.f;
-					if(rp.bg_transp_refract)
-					{
-						const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, P.wo0) : 1.f;
-						P.alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
-					}
-					P.path_col = mkc(0.f, 0.f, 0.f); P.throughput = mkc(1.f, 1.f, 1.f);
-					P.rr.init(fnv32a(ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
-					P.path_i = 0; P.depth = 0; P.one_light_calls = 0u; P.sampled_flags = kNone; P.offs = 0u;
-					P.total = mkc(0.f, 0.f, 0.f);
-					if((P.bsdfs0 & kDiffuse) && sc.n_lights > 0)
-					{
-						P.li = 0; P.l_end = sc.n_lights; P.phase = 0; P.is = 0; P.dl_on_sp0 = 1;
-						P.ccol = P.ccol_2 = P.col_dirac = mkc(0.f, 0.f, 0.f);
-						where = W_DL_NEXT; break;
-					}
-					where = W_DL_DONE; break;
-				}
-				if(!got) { DIRTY(G_CTRL); ++P.path_i; where = W_START_PATH; break; }
-				NEED(G_MISC);
-				DIRTY(G_HIT | G_ACC | G_DLC | G_MISC | G_CTRL);
-				SurfPt hit;
-				get_surface(sc, P.tri, P.r_from + P.r_dir * P.t, P.bu, P.bv, hit);
-				P.hit_p = hit.p; P.hit_n = hit.n; P.hit_ng = hit.ng; P.hit_mat = hit.mat;
-				const yafgpu_material &pm = sc.mats[hit.mat];
-				BsdfDat dat_n;
-				const uint32_t mb = mat_init_bsdf(pm, dat_n);
-				if(P.stage == kStFirst)
-				{
-					if(P.sampled_flags != kNone) P.pwo = -P.r_dir;
-					else { const float4 r10 = a.state[10 * (size_t)a.cap + slot]; P.pwo = v3(r10); }   // keeps the pwo of the first segment (:224)
-				}
-				else P.pwo = -P.r_dir;
-				P.total = mkc(0.f, 0.f, 0.f);
-				const bool want_dl = sc.n_lights > 0 && (P.stage == kStFirst || (mb & kDiffuse));
-				if(want_dl)
-				{
-					int lnum = 0;
-					if(sc.n_lights > 1)
-					{
-						Halton h2; h2.init(2u);
-						h2.set_start(rp.base_sampling_offset + (ordinal * 16u + P.one_light_calls) - 1u);
-						lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
-					}
-					++P.one_light_calls;
-					P.li = lnum; P.l_end = lnum + 1; P.phase = 0; P.is = 0; P.dl_on_sp0 = 0;
-					P.ccol = P.ccol_2 = P.col_dirac = mkc(0.f, 0.f, 0.f);
-					where = W_DL_NEXT; break;
-				}
-				P.li = 0; P.l_end = 0;   // marks "no light estimate ran" for W_DL_DONE
-				where = W_DL_DONE; break;
-			}
-			case W_AFTER_SHADOW:
-			{
-				NEED(G_DLC | G_ACC);
-				DIRTY(G_DLC | G_ACC);
-				if(!P.shadowed)
-				{
-					const bool dirac = sc.lights[P.li].type == YAFGPU_LIGHT_POINT;
-					if(dirac) P.col_dirac = P.col_dirac + P.pending;
-					else if(P.phase == 0) P.ccol = P.ccol + P.pending;
-					else P.ccol_2 = P.ccol_2 + P.pending;
-				}
-				++P.is;
-				where = W_DL_NEXT; break;
-			}
-			case W_DL_NEXT:
-			{
-				// iterate (li, phase, is) in the order of direct_light(): for li { for phase { for is } }
-				NEED(P.dl_on_sp0 ? G_SP0 : G_HIT);
-				SurfPt sp;
-				if(P.dl_on_sp0) make_sp(P.sp0_p, P.sp0_n, P.sp0_ng, P.mat0, sp);
-				else make_sp(P.hit_p, P.hit_n, P.hit_ng, P.hit_mat, sp);
-				const yafgpu_material &mat = sc.mats[sp.mat];
-				BsdfDat dat; mat_init_bsdf(mat, dat);
-				const V3 wo = P.dl_on_sp0 ? P.wo0 : P.pwo;
-				bool parked = false;
-				while(P.li < P.l_end)
-				{
-					const yafgpu_light &light = sc.lights[P.li];
-					const bool dirac = light.type == YAFGPU_LIGHT_POINT;
-					const int n = dirac ? 1 : (int)ceilf((float)light.samples * rp.aa_light_sample_multiplier);
-					const int n_phase = dirac ? 1 : 2;
-					if(P.is >= n) { P.is = 0; ++P.phase; }
-					if(P.phase >= n_phase)
-					{
-						const float inv_ns = 1.f / (float)n;
-						Col col = mkc(0.f, 0.f, 0.f);
-						if(dirac) col = col + P.col_dirac;
-						else { col = col + P.ccol * inv_ns; col = col + P.ccol_2 * inv_ns; }
-						P.total = P.total + col;
-						P.ccol = P.ccol_2 = P.col_dirac = mkc(0.f, 0.f, 0.f);
-						P.phase = 0; P.is = 0; ++P.li;
-						continue;
-					}
-					V3 d; float tmin, tmax; Col contrib;
-					if(dl_candidate(ra, light, P.li, P.phase, P.is, sp, mat, dat, wo, pixel_sample, sampling_offs, d, tmin, tmax, contrib))
-					{
-						const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
-						if(cast_shadows)
-						{
-							P.pending = contrib;
-							P.r_from = sp.p; P.r_dir = d; P.r_tmin = tmin; P.r_tmax = tmax;
-							parked = true;
-							break;
-						}
-						if(dirac) P.col_dirac = P.col_dirac + contrib;
-						else if(P.phase == 0) P.ccol = P.ccol + contrib;
-						else P.ccol_2 = P.ccol_2 + contrib;
-					}
-					++P.is;
-				}
-				if(parked) { DIRTY(G_RAY | G_CTRL | G_DLC | G_ACC); P.pc = kPcAfterShadow; return kReqShadow; }
-				where = W_DL_DONE; break;
-			}
-			case W_DL_DONE:
-			{
-				NEED(G_ACC | G_DLC);
-				DIRTY(G_CTRL);
-				if(P.stage == kStPrimary)
-				{
-					NEED(G_SP0);
-					if(P.bsdfs0 & kDiffuse) P.col = P.col + P.total;                                  // :156
-					const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
-					if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(P.bsdfs0 & path_flags)) { where = W_FINISH; break; }
-					P.path_i = 0;
-					where = W_START_PATH; break;
-				}
-				NEED(G_HIT | G_PATH);
-				DIRTY(G_PATH);
-				const yafgpu_material &pm = sc.mats[P.hit_mat];
-				BsdfDat dat_n;
-				const uint32_t mb = mat_init_bsdf(pm, dat_n);
-				SurfPt hit; make_sp(P.hit_p, P.hit_n, P.hit_ng, P.hit_mat, hit);
-				Col lcol = mkc(0.f, 0.f, 0.f);
-				if(P.l_end > 0) lcol = P.total * (float)sc.n_lights;
-				if(P.stage == kStFirst)
-				{
-					if(mb & kEmit) lcol = lcol + mat_emit(pm, hit, P.pwo, false);                    // :226
-					P.path_col = P.path_col + lcol * P.throughput;                                    // :228
-					P.depth = 1;
-					where = (P.depth < rp.bounces) ? W_EXTEND : W_START_PATH;
-					if(where == W_START_PATH) ++P.path_i;
-					break;
-				}
-				bool alive = true;
-				if(P.depth > rp.rr_min_bounces)
-				{
-					const float random_value = (float)P.rr.next();
-					const float probability = smax(P.throughput.r, smax(P.throughput.g, P.throughput.b));
-					if(probability <= 0.f || probability < random_value) alive = false;
-					else P.throughput = P.throughput * (1.f / probability);
-				}
-				if(alive)
-				{
-					P.path_col = P.path_col + lcol * P.throughput;                                    // :292
-					++P.depth;
-					if(P.depth < rp.bounces) { where = W_EXTEND; break; }
-				}
-				++P.path_i;
-				where = W_START_PATH; break;
-			}
-			case W_EXTEND:
-			{
-				NEED(G_HIT | G_PATH | G_MISC | G_RAY);
-				DIRTY(G_PATH | G_RAY | G_CTRL);
-				const yafgpu_material &pm = sc.mats[P.hit_mat];
-				BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
-				SurfPt hit; make_sp(P.hit_p, P.hit_n, P.hit_ng, P.hit_mat, hit);
-				const int d_4 = 4 * P.depth;
-				BsdfSample bs;
-				bs.s_1 = (float)scr_halton(sc, d_4 + 3, P.offs);
-				bs.s_2 = (float)scr_halton(sc, d_4 + 4, P.offs);
-				bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
-				float w = 0.f;
-				V3 p_dir = P.r_dir;
-				const Col scol = mat_sample(pm, dat_n, hit, P.pwo, p_dir, bs, w) * w;
-				if(is_black(scol)) { ++P.path_i; where = W_START_PATH; break; }
-				P.throughput = P.throughput * scol;
-				P.r_from = hit.p; P.r_dir = p_dir; P.r_tmin = ra.ray_min_dist; P.r_tmax = -1.f;
-				P.stage = kStDepth; P.pc = kPcAfterClosest;
-				return kReqClosest;
-			}
-			case W_START_PATH:
-			{
-				NEED(G_PATH);
-				if(P.path_i >= n_paths) { P.col = P.col + P.path_col / (float)n_paths; where = W_FINISH; break; }
-				NEED(G_SP0 | G_MISC);
-				DIRTY(G_PATH | G_MISC | G_RAY | G_CTRL);
-				const yafgpu_material &m = sc.mats[P.mat0];
-				BsdfDat dat0; mat_init_bsdf(m, dat0);
-				SurfPt sp0; make_sp(P.sp0_p, P.sp0_n, P.sp0_ng, P.mat0, sp0);
-				P.offs = (uint32_t)rp.path_samples * pixel_sample + sampling_offs + (uint32_t)P.path_i;
-				BsdfSample bs;
-				bs.s_1 = ri_vdc(P.offs, 0u);
-				bs.s_2 = (float)scr_halton(sc, 2, P.offs);
-				bs.pdf = 0.f; bs.sampled = kNone;
-				bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
-				float w = 0.f;
-				V3 p_dir = mk(0.f, 0.f, 0.f);
-				P.pwo = P.wo0;
-				a.state[10 * (size_t)a.cap + slot] = f4(P.pwo, 0.f);
-				const Col scol = mat_sample(m, dat0, sp0, P.pwo, p_dir, bs, w) * w;
-				P.throughput = scol;
-				P.sampled_flags = bs.sampled;
-				P.r_from = sp0.p; P.r_dir = p_dir; P.r_tmin = ra.ray_min_dist; P.r_tmax = -1.f;
-				P.stage = kStFirst; P.pc = kPcAfterClosest;
-				return kReqClosest;
-			}
+			case W_AFTER_CLOSEST: where = st_after_closest(a, slot, c, ordinal); break;
+			case W_AFTER_SHADOW: where = st_after_shadow(a, slot); break;
+			case W_DL_NEXT: where = st_dl_next(a, slot, c, pixel_sample, sampling_offs, out_mask); break;
+			case W_DL_DONE: where = st_dl_done(a, slot, c); break;
+			case W_EXTEND: where = st_extend(a, slot, c); break;
+			case W_START_PATH: where = st_start_path(a, slot, c, pixel_sample, sampling_offs); break;
+			case W_PARK_CLOSEST: c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest;
+			case W_PARK_SHADOW: c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow;
 			default: // W_FINISH
 			{
-				NEED(G_MISC);
-				float alpha = P.alpha;
-				if(rp.bg_transp) alpha = smax(alpha, 0.f);
-				result[0] = P.col.r; result[1] = P.col.g; result[2] = P.col.b; result[3] = alpha;
+				float alpha = REC(19).w;
+				if(a.ra.rp.bg_transp) alpha = smax(alpha, 0.f);   // EmptyVolumeIntegrator: transmittance 1 (integrator_empty_volume.cc:32-38)
+				result[0] = c.col.r; result[1] = c.col.g; result[2] = c.col.b; result[3] = alpha;
 				return kReqDone;
 			}
 		}
 	}
-#undef NEED
-#undef DIRTY
 }
+#undef REC
 
 // identity of a path slot: slot = pixel_local * spp + sample
 YG_DEV void wf_identity(const WfArgs &a, uint32_t slot, int &px, int &py, int &sample, uint32_t &pixel_sample, uint32_t &sampling_offs, uint32_t &ordinal)
@@ -532,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 		b[1 * c] = f4(dir, tmax);
 		b[13 * c] = make_float4(0.f, 0.f, 0.f, fbits((uint32_t)kPcAfterClosest | ((uint32_t)kStPrimary << 2)));
 	}
-	if(blockIdx.x == 0 && threadIdx.x == 0) { a.cnt_in[0] = a.n_paths; a.cnt_in[1] = 0u; a.cnt_in[2] = 0u; a.cnt_in[3] = 0u; }
+	if(blockIdx.x == 0 && threadIdx.x == 0) { a.cnt_in[0] = a.n_paths; a.cnt_in[1] = 0u; a.cnt_in[2] = 0u; a.cnt_in[3] = 0u; a.cnt_in[4] = 0u; }
 }
 
 // The traversal kernels: Scene::intersect (scene.cc:896-927) / Scene::isShadowed (:962-994) over a queue.
@@ -542,6 +528,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 // queue with one atomic (ballot + prefix rank) and the freed lanes start them while the others carry
 // on.  Traversal state (current node, [tmin,tmax], best hit, short stack in LDS) is per lane, so lanes
 // of one wave can be at any point of any ray.  The walk itself is kd_trace's, cut at leaf granularity.
+#ifndef YAFGPU_TRACE_BATCH
+#define YAFGPU_TRACE_BATCH 512
+#endif
+constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_REFILL
 #define YAFGPU_REFILL 32               // C2 sweep: 16 -> 1134, 32 -> 1408, 48 -> 1360 Mrays/s
 #endif
@@ -560,7 +550,10 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 	const size_t c = a.cap;
 	// per-lane ray + traversal state
 	bool active = false, exhausted = (n == 0u) || (sc.n_nodes == 0u && false);
-	uint32_t slot = 0u, node = 0u;
+	uint32_t slot = 0u, node = 0u, which = 0u;
+	uint32_t w_next = 0u, w_end = 0u;      // this wave's reserved queue range (wave-uniform)
+	// reservation size: large enough to keep the counter word off the critical path, small enough that a short queue still spreads over all waves
+	const uint32_t batch = min((uint32_t)kTraceBatch, max((uint32_t)kWave, (n / (gridDim.x * (uint32_t)kWavesPerBlock * 2u)) & ~63u));
 	V3 from = mk(0.f, 0.f, 0.f), dir = from, inv_dir = from;
 	float ray_tmin = 0.f, dist = 0.f, t_exit = 0.f, tmin = 0.f, tmax = 0.f, z = 0.f, bu = 0.f, bv = 0.f;
 	int tri = -1; bool hit = false;
@@ -570,18 +563,35 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 		const int n_idle = __popcll(idle);
 		if(!exhausted && (n_idle >= YAFGPU_REFILL || n_idle == kWave))
 		{
-			const int leader = __ffsll((long long)idle) - 1;
-			uint32_t base = 0u;
-			if(lane == leader) base = atomicAdd(cursor, (uint32_t)n_idle);
-			base = (uint32_t)__shfl((int)base, leader, kWave);
-			if(base + (uint32_t)n_idle >= n) exhausted = true;
-			if(!active)
+			// the wave owns [w_next, w_end) of the queue; one atomic reserves kTraceBatch entries at a time (a single
+			// counter word sustains only ~90 returning atomics per microsecond: MI355X_MICROARCH.md, row "dequeue")
+			if(w_next >= w_end)
 			{
-				const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-				if(i < n)
+				const int leader = __ffsll((long long)idle) - 1;
+				uint32_t base = 0u;
+				if(lane == leader) base = atomicAdd(cursor, batch);
+				base = (uint32_t)__shfl((int)base, leader, kWave);
+				w_next = base; w_end = min(base + batch, n);
+				if(base >= n) { exhausted = true; w_next = w_end = 0u; }
+			}
+			const uint32_t avail = w_end - w_next;
+			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+			const uint32_t first = w_next;
+			w_next += min(avail, (uint32_t)n_idle);
+			if(!active && rank < avail)
+			{
+				const uint32_t i = first + rank;
 				{
 					slot = q ? q[i] : i;
-					const float4 r0 = a.state[slot], r1 = a.state[c + slot];
+					which = 0u;
+					if(kAny) { which = slot >> 31; slot &= 0x7fffffffu; }
+					float4 r0 = a.state[slot], r1 = a.state[c + slot];
+					if(kAny && which)
+					{	// second ray of the pair: same origin, direction/tmin in r20, tmax in r21.w
+						const float4 r20 = a.state[20 * c + slot];
+						r1 = make_float4(r20.x, r20.y, r20.z, a.state[21 * c + slot].w);
+						r0.w = r20.w;
+					}
 					from = v3(r0); dir = v3(r1);
 					if(kAny)
 					{
@@ -607,7 +617,8 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					}
 					else
 					{	// misses the scene bound: answer at once
-						a.state[2 * c + slot] = kAny ? make_float4(fbits(0u), 0.f, 0.f, 0.f) : make_float4(fbits(0xffffffffu), dist, 0.f, 0.f);
+						if(kAny) a.verdict[2u * slot + which] = 0u;
+						else a.state[2 * c + slot] = make_float4(fbits(0xffffffffu), dist, 0.f, 0.f);
 					}
 				}
 			}
@@ -663,8 +674,8 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			}
 			if(done)
 			{
-				a.state[2 * c + slot] = kAny ? make_float4(fbits(found ? 1u : 0u), 0.f, 0.f, 0.f)
-				                             : make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
+				if(kAny) a.verdict[2u * slot + which] = found ? 1u : 0u;
+				else a.state[2 * c + slot] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
 				active = false;
 			}
 		}
@@ -688,40 +699,82 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 	}
 }
 
-// resume every answered path; entries [0, n_closest) come from the closest queue, the rest from the shadow queue
+// resume every answered path: entries [0, n_closest) come from the closest queue, the rest from the resume queue
 #ifndef YAFGPU_SHADE_WAVES
 #define YAFGPU_SHADE_WAVES 1
 #endif
 __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
 {
-	const uint32_t nc = a.cnt_in[0], ns = a.cnt_in[1];
-	const uint32_t total = nc + ns;
-	// every lane of a wave runs the same number of iterations so that wf_push's ballots see whole waves
-	const uint32_t stride = gridDim.x * blockDim.x;
-	for(uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride)
+	// Queue appends are aggregated per workgroup over kItems items per thread: one returning atomic per queue
+	// per 1024 paths.  (A single counter word sustains ~90 returning atomics per microsecond; one per wave and
+	// queue — 2 M per pass on C2 — was the whole cost of this kernel.)
+	constexpr int kItems = 4;
+	__shared__ uint32_t s_tot[kWavesPerBlock][3];
+	__shared__ uint32_t s_base[kWavesPerBlock][3];
+	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
+	const uint32_t nc = a.cnt_in[0], nr = a.cnt_in[4];
+	const uint32_t total = nc + nr;
+	const uint32_t per_block = (uint32_t)kBlock * kItems;
+	for(uint32_t base = blockIdx.x * per_block; base < total; base += gridDim.x * per_block)
 	{
-		const uint32_t i = base + threadIdx.x;
-		const bool live = i < total;
-		int req = kReqDone;
-		uint32_t slot = 0u;
-		if(live)
+		uint32_t slot_k[kItems]; int code_k[kItems];   // code: bit0 closest, bit1 resume, bit2 shadow ray A, bit3 shadow ray B
+		uint32_t wc = 0u, wr = 0u, ws = 0u;            // this wave's totals per queue
+#pragma unroll
+		for(int k = 0; k < kItems; ++k)
 		{
-			slot = (i < nc) ? (a.q_closest_in ? a.q_closest_in[i] : i) : a.q_shadow_in[i - nc];
-			int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
-			wf_identity(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
-			PathRegs P;
-			P.have = 0u; P.dirty = 0u;
-			float res[4];
-			req = wf_advance(a, slot, P, pixel_sample, sampling_offs, ordinal, res);
-			if(req == kReqDone)
+			const uint32_t i = base + (uint32_t)k * kBlock + threadIdx.x;
+			const bool live = i < total;
+			int code = 0;
+			uint32_t slot = 0u;
+			if(live)
 			{
-				if(res[3] > 1.f) res[3] = 1.f;    // integrator_tiled.cc:459
-				a.results[slot] = make_float4(res[0], res[1], res[2], res[3]);
+				slot = (i < nc) ? (a.q_closest_in ? a.q_closest_in[i] : i) : a.q_resume_in[i - nc];
+				int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
+				wf_identity(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+				float res[4];
+				int m = 0;
+				const int req = wf_advance(a, slot, pixel_sample, sampling_offs, ordinal, res, m);
+				if(req == kReqDone)
+				{
+					if(res[3] > 1.f) res[3] = 1.f;    // integrator_tiled.cc:459
+					a.results[slot] = make_float4(res[0], res[1], res[2], res[3]);
+				}
+				else if(req == kReqClosest) code = 1;
+				else code = 2 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);
 			}
-			else wf_store(a, slot, P);
+			slot_k[k] = slot; code_k[k] = code;
+			wc += (uint32_t)__popcll(__ballot(code & 1));
+			wr += (uint32_t)__popcll(__ballot(code & 2));
+			ws += (uint32_t)__popcll(__ballot(code & 4)) + (uint32_t)__popcll(__ballot(code & 8));
 		}
-		wf_push(a.q_closest_out, &a.cnt_out[0], live && req == kReqClosest, slot);
-		wf_push(a.q_shadow_out, &a.cnt_out[1], live && req == kReqShadow, slot);
+		if(lane == 0) { s_tot[wave][0] = wc; s_tot[wave][1] = wr; s_tot[wave][2] = ws; }
+		__syncthreads();
+		if(threadIdx.x < 3)
+		{
+			const int qi = (int)threadIdx.x;
+			uint32_t sum = 0u;
+			for(int w = 0; w < kWavesPerBlock; ++w) sum += s_tot[w][qi];
+			uint32_t b = 0u;
+			if(sum) b = atomicAdd(&a.cnt_out[qi == 0 ? 0 : (qi == 1 ? 4 : 1)], sum);
+			for(int w = 0; w < kWavesPerBlock; ++w) { s_base[w][qi] = b; b += s_tot[w][qi]; }
+		}
+		__syncthreads();
+		uint32_t oc = s_base[wave][0], orr = s_base[wave][1], os = s_base[wave][2];
+		const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+		for(int k = 0; k < kItems; ++k)
+		{
+			const int code = code_k[k];
+			const uint32_t slot = slot_k[k];
+			const unsigned long long bc = __ballot(code & 1), br = __ballot(code & 2), ba = __ballot(code & 4), bb = __ballot(code & 8);
+			if(code & 1) a.q_closest_out[oc + (uint32_t)__popcll(bc & below)] = slot;
+			if(code & 2) a.q_resume_out[orr + (uint32_t)__popcll(br & below)] = slot;
+			if(code & 4) a.q_shadow_out[os + (uint32_t)__popcll(ba & below)] = slot;
+			const uint32_t na = (uint32_t)__popcll(ba);
+			if(code & 8) a.q_shadow_out[os + na + (uint32_t)__popcll(bb & below)] = slot | 0x80000000u;
+			oc += (uint32_t)__popcll(bc); orr += (uint32_t)__popcll(br); os += na + (uint32_t)__popcll(bb);
+		}
+		__syncthreads();   // s_tot / s_base are reused by the next round
 	}
 }
 

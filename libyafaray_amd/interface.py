@@ -54,13 +54,14 @@ C_API_SYMBOLS = [
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
     "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_prepareRender",
-    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe",
+    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
 ]
 GPU_ABI_SYMBOLS = [
     "yafgpu_last_error", "yafgpu_device_count", "yafgpu_set_device", "yafgpu_scene_create", "yafgpu_scene_destroy",
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
     "yafgpu_kdtree_build", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
+    "yafgpu_set_profiling", "yafgpu_get_profile",
 ]
 
 
@@ -101,6 +102,8 @@ def load():
         "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
         "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
         "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
+        "yafaray_setProfiling": (ci, [vp, ci]),
+        "yafaray_getKernelProfile": (ci, [vp, C.POINTER(cd), C.POINTER(C.c_uint64)]),
         "yafgpu_last_error": (cp, []), "yafgpu_device_count": (ci, []), "yafgpu_set_device": (ci, [ci]),
         "yafgpu_planes_bytes": (C.c_uint64, [ci, ci]),
         "yafgpu_film_combine": (ci, [vp, vp, ci, ci, vp]),
@@ -320,6 +323,16 @@ class Interface:
         fp = C.POINTER(C.c_float)
         self._ok(self._L.yafaray_probe(self._h, op, x.shape[0], x.ctypes.data_as(fp), x.shape[1], out.ctypes.data_as(fp), n_out), "probe")
         return out
+
+    def setProfiling(self, enable):
+        return self._ok(self._L.yafaray_setProfiling(self._h, int(enable)), "setProfiling")
+
+    def getKernelProfile(self):
+        """-> {name: (total_ms, launches)} of the last profiled pass"""
+        ms = (C.c_double * 4)(); n = (C.c_uint64 * 4)()
+        self._ok(self._L.yafaray_getKernelProfile(self._h, ms, n), "getKernelProfile")
+        names = ("trace_closest", "trace_shadow", "shade", "other")
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(names)}
 
     def getFilm(self, width, height):
         film = np.zeros((height, width, 5), dtype=np.float32)

@@ -9,4 +9,4 @@ echo "== $flags"
 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; print('   Mrays/s', d['value'], 'kernel_ms', r['kernel_ms'], 'B/ray', r['bytes_per_ray'], r['per_ray'])"
+        d=json.loads(l); r=d['roofline']; print('   Mrays/s', d['value'], 'ms/step', d['ms_per_step'], r['pass_ms'], 'B/ray', r['bytes_per_ray'], r['per_ray'])"

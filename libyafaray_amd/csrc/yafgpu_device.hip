@@ -1052,7 +1052,11 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	int rc = 0;
 	DevScene &dv = s->dev;
 	const uint2 *nodes = nullptr;
-	if((rc = upload(s, (const uint2 *)s->tree.nodes.data(), s->tree.nodes.size(), &nodes))) { yafgpu_scene_destroy(s); return rc; }
+	{	// the traversal kernels fetch a window of 8 nodes starting at the current one: pad the array so the last window stays in bounds
+		std::vector<KdNode> padded(s->tree.nodes);
+		padded.resize(padded.size() + 8, KdNode{0u, 3u});
+		if((rc = upload(s, (const uint2 *)padded.data(), padded.size(), &nodes))) { yafgpu_scene_destroy(s); return rc; }
+	}
 	dv.nodes = nodes;
 	if((rc = upload(s, s->tree.refs.data(), s->tree.refs.size(), &dv.refs))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, rec.data(), rec.size(), &dv.tri))) { yafgpu_scene_destroy(s); return rc; }

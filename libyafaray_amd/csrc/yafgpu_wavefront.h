@@ -528,6 +528,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 // queue with one atomic (ballot + prefix rank) and the freed lanes start them while the others carry
 // on.  Traversal state (current node, [tmin,tmax], best hit, short stack in LDS) is per lane, so lanes
 // of one wave can be at any point of any ray.  The walk itself is kd_trace's, cut at leaf granularity.
+#ifndef YAFGPU_NODE_WINDOW
+#define YAFGPU_NODE_WINDOW 1   // C2 sweep: 1 -> 22.1, 2 -> 23.7, 4 -> 27.2, 8 -> 37.0 ms of traversal per pass: extra node fetches cost more than the latency they hide
+#endif
 #ifndef YAFGPU_TRACE_BATCH
 #define YAFGPU_TRACE_BATCH 512
 #endif
@@ -630,7 +633,15 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			if(z < tmin) done = true;                     // kdtree_triangle.cc:717
 			else
 			{
-				uint2 nd = sc.nodes[node];
+				// Depth-first layout: the left child of node n is n+1, so a run of left turns walks consecutive
+				// nodes.  Every fetch brings a window of kWin nodes (same or next cache line as the node itself),
+				// and a step into the window costs no memory round trip.
+				constexpr int kWin = YAFGPU_NODE_WINDOW;
+				uint2 win[kWin];
+				uint32_t wbase = node;
+#pragma unroll
+				for(int k = 0; k < kWin; ++k) win[k] = sc.nodes[node + (uint32_t)k];
+				uint2 nd = win[0];
 				while((nd.y & 3u) != 3u)
 				{
 					const int axis = (int)(nd.y & 3u);
@@ -644,7 +655,20 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
 					else if(tplane < tmin) node = far_c;
 					else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
-					nd = sc.nodes[node];
+					const uint32_t off = node - wbase;
+					if(off < (uint32_t)kWin)
+					{
+						nd = win[0];
+#pragma unroll
+						for(int k = 1; k < kWin; ++k) if(off == (uint32_t)k) nd = win[k];
+					}
+					else
+					{
+						wbase = node;
+#pragma unroll
+						for(int k = 0; k < kWin; ++k) win[k] = sc.nodes[node + (uint32_t)k];
+						nd = win[0];
+					}
 				}
 				const uint32_t np = nd.y >> 2, first = nd.x;
 				if(kStats) ++cn.leaves;
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 
 // resume every answered path: entries [0, n_closest) come from the closest queue, the rest from the resume queue
 #ifndef YAFGPU_SHADE_WAVES
-#define YAFGPU_SHADE_WAVES 1
+#define YAFGPU_SHADE_WAVES 3     // 168 VGPRs, light spilling; C2: 1 -> 13.9 ms, 3 -> 11.8 ms, 4 -> 12.9 ms per pass
 #endif
 __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
 {

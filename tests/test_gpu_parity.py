@@ -106,3 +106,22 @@ def test_glossy_two_lights_point_light_run_and_match_oracle_where_defined():
     film, st, ofilm, ost = render_both(sc2, rd2)
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, "point light cornell")
+
+
+def test_config0_test01_xml_path_tracing():
+    """BASELINE.json config 0: the reference's own test scene (tests/test01/test01.xml, textures removed,
+    integrator switched to pathtracing per SURVEY Appendix C), 256x256, 16 spp — loaded by the C++ XML
+    loader, rendered on the GPU, compared with the oracle fed by an independent Python parse of the same file."""
+    import os
+    from tests import xml_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test01_pt.xml")
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film = yi.getFilm(256, 256)
+    st = yi.getRenderStats()
+    sc, rd = xml_scene.load(path)
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=8))
+    assert st.n_triangles == 74 and st.camera_samples == 256 * 256 * 16
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "test01 path tracing 256x256 16spp")

@@ -55,7 +55,7 @@ def make_workload(name, res=None, spp=None):
     return w, sc, rd
 
 
-def cpu_baseline(name, budget_s=15.0):
+def cpu_baseline(name, budget_s=20.0):
     """Time the CPU oracle (multi-threaded port of the reference path) on a bounded sample of the workload:
     the same scene at reduced resolution / samples per pixel, sized from a pilot run to ~budget_s of CPU wall."""
     from oracle import pyoracle as po
@@ -74,7 +74,7 @@ def cpu_baseline(name, budget_s=15.0):
     sres = int(max(32, min(WORKLOADS[name]["res"], (samples / spp) ** 0.5))) // 32 * 32
     w, sc, rd = make_workload(name, res=sres)
     osc = po.OracleScene(sc)
-    _, st = osc.render(dict(rd, AA_minsamples=spp, oracle_threads=cores))
+    _, st = osc.render(dict(rd, AA_minsamples=spp, oracle_threads=cores, tile_size=8))
     rays = st.rays_closest + st.rays_shadow
     osc.close()
     return {"value": round(rays / st.render_seconds / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
@@ -191,6 +191,15 @@ def main():
         trace_ms, trace_launches = kernel_ms, 1
     # dominant kernel = the traversal kernel (wf_trace): algorithmic bytes of all its launches / their summed duration
     achieved = bytes_per_ray * rays_launch / (trace_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch of the same kernel come from a rocprofv3 PMC run (FETCH_SIZE / WRITE_SIZE in separate
+    # passes, tools/pmc.sh); they cannot be read live, so the committed summary of that run is quoted when it exists
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"r01_{args.workload}_traffic.json")
+    if world == 1 and not args.res and not args.spp and os.path.exists(tpath):
+        try:
+            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
 
     if rank == 0:
         out = {
@@ -204,7 +213,8 @@ def main():
                        "scene_device_MB": round(stats0.scene_device_bytes / 1e6, 1), "setup_s": round(setup_s, 2),
                        "tree_build_s": round(stats0.tree_build_seconds, 2)},
             "roofline": {"bound": "hbm", "kernel": "wf_trace (closest-hit + any-hit kd traversal)", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_launch / max(trace_launches, 1)),
                          "launches_per_pass": int(trace_launches), "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),
                          "rays_per_launch": round(rays_launch / max(trace_launches, 1)),
                          "pass_ms": {k: round(v[0], 3) for k, v in prof.items()}, "pass_ms_total": round(kernel_ms, 3),

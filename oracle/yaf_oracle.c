@@ -1948,6 +1948,7 @@ typedef struct
 	const yor_scene *s; const yor_render_desc *rd; film_t *film;
 	int n_tiles_x, n_tiles_y;
 	int thread_id, n_threads;
+	int *next_tile;
 	counters_t cn; uint64_t camera_samples;
 	splat_list deferred;
 } worker_t;
@@ -2007,12 +2008,23 @@ static void *worker_main(void *arg)
 	st.ray_min_dist = rd->min_raydist_auto ? (float)MIN_RAYDIST : rd->min_raydist;      /* scene.cc:826 */
 	int n_tiles = wk->n_tiles_x * wk->n_tiles_y;
 	int shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
-	int k = 0;
-	for(int t = 0; t < n_tiles; ++t)
+	if(wk->n_threads == 1)
 	{
-		if((t % shard_count) != rd->shard_index) continue;
-		if((k++ % wk->n_threads) != wk->thread_id) continue;
-		render_tile(wk, t % wk->n_tiles_x, t / wk->n_tiles_x, &st);
+		for(int t = 0; t < n_tiles; ++t)
+		{
+			if((t % shard_count) != rd->shard_index) continue;
+			render_tile(wk, t % wk->n_tiles_x, t / wk->n_tiles_x, &st);
+		}
+	}
+	else
+	{	/* workers pull tiles from a shared counter, like renderWorker does from ImageFilm::nextArea (integrator_tiled.cc:48-66) */
+		for(;;)
+		{
+			int t = __atomic_fetch_add(wk->next_tile, 1, __ATOMIC_RELAXED);
+			if(t >= n_tiles) break;
+			if((t % shard_count) != rd->shard_index) continue;
+			render_tile(wk, t % wk->n_tiles_x, t / wk->n_tiles_x, &st);
+		}
 	}
 	wk->cn = st.cn;
 	return NULL;
@@ -2034,9 +2046,11 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 	int nthreads = rd->n_threads > 0 ? rd->n_threads : 1;
 	worker_t *wk = (worker_t *)calloc((size_t)nthreads, sizeof(worker_t));
 	pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+	int next_tile = 0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for(int i = 0; i < nthreads; ++i)
 	{
+		wk[i].next_tile = &next_tile;
 		wk[i].s = s; wk[i].rd = rd; wk[i].film = &film; wk[i].n_tiles_x = ntx; wk[i].n_tiles_y = nty;
 		wk[i].thread_id = i; wk[i].n_threads = nthreads;
 	}

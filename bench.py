@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--res", type=int, default=0, help="override resolution (debug)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the film reduce goes through gloo "
+                         "(host staging). Exercises sharding + reduce + combine with the real kernels; not a measurement.")
     args = ap.parse_args()
 
     import torch
@@ -105,11 +108,16 @@ def main():
         sys.exit(f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, sc, rd = make_workload(args.workload, args.res, args.spp)
     yi = Interface()
@@ -126,9 +134,17 @@ def main():
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    def reduce_film():
+        if args.rehearse_one_gpu and world > 1:
+            host = planes.cpu()
+            reduce_planes(host, dst=0)
+            planes.copy_(host)
+        else:
+            reduce_planes(planes, dst=0)
+
     def step():
         yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
-        reduce_planes(planes, dst=0)
+        reduce_film()
         if rank == 0:
             yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
 
@@ -148,7 +164,7 @@ def main():
         ev[k][0].record()
         yi.renderPassDevice(planes.data_ptr(), counters.data_ptr(), stream)
         ev[k][1].record()
-        reduce_planes(planes, dst=0)
+        reduce_film()
         if rank == 0:
             yi_mod.film_combine(planes.data_ptr(), film.data_ptr(), W, H, stream)
     barrier()
@@ -157,6 +173,8 @@ def main():
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     cnt = counters.clone()
+    if args.rehearse_one_gpu:
+        el, cnt = el.cpu(), cnt.cpu()
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -224,6 +242,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+        if args.rehearse_one_gpu:
+            f = film.cpu().numpy()
+            out["film_checksum"] = {"sum_rgb": float(f[..., :3].astype(np.float64).sum()), "sum_weight": float(f[..., 4].astype(np.float64).sum()),
+                                    "crc": int(np.frombuffer(f.tobytes(), dtype=np.uint32).astype(np.uint64).sum() & 0xffffffff)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -31,6 +31,7 @@ extern "C" {
 enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2 };
 enum { YAFGPU_LIGHT_AREA = 0, YAFGPU_LIGHT_POINT = 1 };
 enum { YAFGPU_INTEGRATOR_PATH = 0, YAFGPU_INTEGRATOR_DIRECT = 1 };
+enum { YAFGPU_FILTER_BOX = 0, YAFGPU_FILTER_MITCHELL = 1, YAFGPU_FILTER_GAUSS = 2, YAFGPU_FILTER_LANCZOS = 3 };
 
 /* A material after its factory()/config() ran on the host (material_shiny_diffuse.cc:46-92,
  * material_glossy.cc:32-50, material_simple.cc:36-39).  64 floats, 16-byte aligned. */
@@ -97,7 +98,8 @@ typedef struct yafgpu_render_params
 	int32_t path_samples, bounces, rr_min_bounces, no_recursive, bg_transp, bg_transp_refract;
 	int32_t width, height, xstart, ystart;
 	int32_t aa_minsamples;
-	float aa_pixelwidth;           /* box filter; the GPU film supports filterw <= 0.501 (AA_pixelwidth <= 1.002) */
+	float aa_pixelwidth;           /* reconstruction filter width in pixels (AA_pixelwidth) */
+	int32_t filter_type;           /* YAFGPU_FILTER_*: box | mitchell | gauss | lanczos (ImageFilm::FilterType, imagefilm.cc:155-163) */
 	int32_t tile_size;
 	uint32_t base_sampling_offset;
 	int32_t shadow_bias_auto; float shadow_bias;

@@ -549,7 +549,10 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	p.get("adv_base_sampling_offset", base_offset); p.get("adv_computer_node", node);
 	p.get("color_space", yi->color_space); p.get("gamma", yi->gamma);
 	if(aa_passes != 1) return fail(yi, "render: adaptive multi-pass AA (AA_passes > 1) is not supported by the GPU path (SURVEY row N4)");
-	if(filter != "box" && !filter.empty()) return fail(yi, "render: filter_type \"" + filter + "\" is not supported by the GPU path (box with AA_pixelwidth <= 1.002 only)");
+	int filter_type = YAFGPU_FILTER_BOX;      // RenderEnvironment::createImageFilm, environment.cc:537-541: unknown names default to box
+	if(filter == "mitchell") filter_type = YAFGPU_FILTER_MITCHELL;
+	else if(filter == "gauss") filter_type = YAFGPU_FILTER_GAUSS;
+	else if(filter == "lanczos") filter_type = YAFGPU_FILTER_LANCZOS;
 	if(premult) return fail(yi, "render: premultiplied alpha is not supported by the GPU path");
 	if(clamp_samples != 0.f || clamp_indirect != 0.f) return fail(yi, "render: AA_clamp_samples / AA_clamp_indirect are not supported by the GPU path");
 	const IntegratorCfg &ic = inte->second->c;
@@ -559,7 +562,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.path_samples = ic.path_samples; rp.bounces = ic.bounces; rp.rr_min_bounces = ic.rr_min_bounces;
 	rp.no_recursive = ic.no_recursive; rp.bg_transp = ic.bg_transp; rp.bg_transp_refract = ic.bg_transp_refract;
 	rp.width = width; rp.height = height; rp.xstart = xstart; rp.ystart = ystart;
-	rp.aa_minsamples = aa_samples; rp.aa_pixelwidth = filt_sz; rp.tile_size = tile_size;
+	rp.aa_minsamples = aa_samples; rp.aa_pixelwidth = filt_sz; rp.filter_type = filter_type; rp.tile_size = tile_size;
 	rp.base_sampling_offset = (uint32_t)base_offset + (uint32_t)node * 100000u;   // imagefilm.h:124
 	rp.shadow_bias_auto = auto_bias; rp.shadow_bias = shadow_bias; rp.min_raydist_auto = auto_dist; rp.min_raydist = min_raydist;
 	rp.aa_light_sample_multiplier = 1.f;

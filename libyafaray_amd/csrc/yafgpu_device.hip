@@ -76,6 +76,8 @@ struct RenderArgs
 	DevScene sc;
 	yafgpu_render_params rp;
 	float shadow_bias, ray_min_dist, filterw;
+	float table_scale; int wide_filter;   // wide_filter: footprint beyond the 2x2 box case -> table weights + atomics (wavefront accumulate)
+	const float *filter_table;            // 16x16 reconstruction-filter table (ImageFilm ctor, imagefilm.cc:152-176)
 	int lanes_per_pixel, pixels_per_wave, iters;
 	int n_tiles; uint32_t n_units;
 	const int4 *tile_rect;         // x0,y0,w,h per tile of this shard
@@ -911,6 +913,7 @@ struct yafgpu_scene
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr; uint32_t wf_cap = 0;
+	float *d_filter_table = nullptr;
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
 };
@@ -1093,6 +1096,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_queues) (void)hipFree(s->wf_queues);
 	if(s->wf_counts) (void)hipFree(s->wf_counts);
 	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
+	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	delete s;
 }
 
@@ -1112,11 +1116,75 @@ int yafgpu_scene_get_tree(const yafgpu_scene_t *s, uint32_t *nodes, uint32_t *re
 	return 0;
 }
 
+// ---- reconstruction-filter table on the host: ImageFilm ctor + filter functions, src/common/imagefilm.cc:60-121,152-176.
+// fExp__/fSin__ are the reference's polynomial approximations (util_math_optimizations.h:116-129,222-244), restated
+// for the host so that the table holds the values the reference's film would hold.
+static float host_fexp2(float x)
+{
+	x = std::min(x, 129.00000f);
+	x = std::max(x, -126.99999f);
+	const int ipart = (int)(x - 0.5f);
+	const float p = (x - (float)ipart);
+	int bits = (int)((unsigned)(ipart + 127) << 23);
+	float expi; std::memcpy(&expi, &bits, 4);
+	const float poly = (p * (p * (p * (p * (p * 1.8775767e-3f + 8.9893397e-3f) + 5.5826318e-2f) + 2.4015361e-1f) + 6.9315308e-1f) + 9.9999994e-1f);
+	return expi * poly;
+}
+static float host_fsin(float x)
+{
+	const double k2Pi = 6.28318530717958647692, kPi = 3.14159265358979323846;
+	if((double)x > k2Pi || (double)x < -k2Pi) x -= ((int)(x * (float)0.15915494309189533577)) * (float)k2Pi;
+	if((double)x < -kPi) x += (float)k2Pi;
+	else if((double)x > kPi) x -= (float)k2Pi;
+	x = ((float)1.27323954473516268615 * x) - ((float)0.40528473456935108578 * x * std::fabs(x));
+	const float result = 0.225f * (x * std::fabs(x) - x) + x;
+	if(result <= -1.0f) return -1.0f;
+	if(result >= 1.0f) return 1.0f;
+	return result;
+}
+static float host_filter(int type, float dx, float dy)
+{
+	switch(type)
+	{
+		case YAFGPU_FILTER_MITCHELL:
+		{
+			const float x = 2.f * std::sqrt(dx * dx + dy * dy);
+			if(x >= 2.f) return 0.f;
+			if(x >= 1.f) return (float)(x * (x * (x * -0.38888889f + 2.0f) - 3.33333333f) + 1.77777778f);
+			return (float)(x * x * (1.16666666f * x - 2.0f) + 0.88888889f);
+		}
+		case YAFGPU_FILTER_GAUSS:
+		{
+			const float r_2 = dx * dx + dy * dy;
+			const float e = host_fexp2((float)1.4426950408889634074 * (float)(-6 * r_2));
+			return std::max(0.f, (float)((double)e - 0.00247875));
+		}
+		case YAFGPU_FILTER_LANCZOS:
+		{
+			const float x = std::sqrt(dx * dx + dy * dy);
+			if(x == 0.f) return 1.f;
+			if(-2 < x && x < 2)
+			{
+				const float a = (float)(3.14159265358979323846 * (double)x), b = (float)(1.57079632679489661923 * (double)x);
+				return ((host_fsin(a) * host_fsin(b)) / (a * b));
+			}
+			return 0.f;
+		}
+		default: return 1.f;
+	}
+}
+static void host_filter_table(int type, float table[256])
+{
+	const float scale = 1.f / 16.f;
+	for(int y = 0; y < 16; ++y)
+		for(int x = 0; x < 16; ++x) table[y * 16 + x] = host_filter(type, (x + .5f) * scale, (y + .5f) * scale);
+}
+
 static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
 {
 	if(rp->width <= 0 || rp->height <= 0 || rp->aa_minsamples <= 0 || rp->tile_size <= 0) return fail(-10, "empty image, sample count or tile size");
 	if(rp->bounces > 12) return fail(-11, "bounces > 12 would use scrHalton dimensions >= 50, which are a global racy LCG in the reference (scr_halton.h:70-73)");
-	if(rp->aa_pixelwidth > 1.002f) return fail(-12, "the GPU film implements the box filter with AA_pixelwidth <= 1.002 (filter half-width 0.501) only");
+	if(rp->filter_type < YAFGPU_FILTER_BOX || rp->filter_type > YAFGPU_FILTER_LANCZOS) return fail(-12, "unknown filter type");
 	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
 	if(rp->integrator != YAFGPU_INTEGRATOR_PATH && rp->integrator != YAFGPU_INTEGRATOR_DIRECT) return fail(-14, "unknown integrator");
 	(void)s;
@@ -1254,9 +1322,22 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	ra.rp = *rp;
 	ra.shadow_bias = rp->shadow_bias_auto ? kShadowBias : rp->shadow_bias;     // scene.cc:825
 	ra.ray_min_dist = rp->min_raydist_auto ? kMinRayDist : rp->min_raydist;    // scene.cc:826
-	{	// ImageFilm ctor, imagefilm.cc:127,165 (box: no widening)
+	{	// ImageFilm ctor, imagefilm.cc:127,152-176: half-width, per-type widening, clamp to [0.501, 4], 16x16 table
 		float fw = (float)((double)rp->aa_pixelwidth * 0.5);
+		if(rp->filter_type == YAFGPU_FILTER_MITCHELL) fw *= 2.6f;
+		else if(rp->filter_type == YAFGPU_FILTER_GAUSS) fw *= 2.f;
 		ra.filterw = std::min(std::max(0.501f, fw), 0.5f * 8.f);
+		ra.table_scale = (float)(0.9999 * 16 / (double)ra.filterw);
+		ra.wide_filter = (rp->filter_type != YAFGPU_FILTER_BOX || ra.filterw > 0.501f) ? 1 : 0;
+		ra.filter_table = nullptr;
+		if(ra.wide_filter)
+		{
+			float table[256];
+			host_filter_table(rp->filter_type, table);
+			if(!s->d_filter_table) HIP_OK(hipMalloc((void **)&s->d_filter_table, sizeof table));
+			HIP_OK(hipMemcpy(s->d_filter_table, table, sizeof table, hipMemcpyHostToDevice));
+			ra.filter_table = s->d_filter_table;
+		}
 	}
 	const int spp = rp->aa_minsamples;
 	ra.lanes_per_pixel = std::min(spp, kWave);
@@ -1312,6 +1393,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		const char *pl = std::getenv("YAFGPU_PIPELINE");
 		const bool mega = pl && std::strcmp(pl, "megakernel") == 0;
 		if(!mega) return render_wavefront(s, ra, stream, stats);
+		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
 	}
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev));

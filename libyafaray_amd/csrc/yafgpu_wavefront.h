@@ -815,6 +815,45 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 		int px, py;
 		wf_pixel_of(a, pl, px, py);
 		const uint32_t sampling_offs = fnv32a((uint32_t)py * fnv32a((uint32_t)px));
+		if(a.ra.wide_filter)
+		{	// general footprint: table weights, neighbours through float atomics on plane 0 (their order is the only
+			// non-deterministic part: last-bit noise); the pixel's own share is summed in sample order first
+			const int cx0 = rp.xstart, cy0 = rp.ystart;
+			const double fw = (double)a.ra.filterw, ts = (double)a.ra.table_scale;
+			float own[YAFGPU_FILM_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+			for(int s = 0; s < spp; ++s)
+			{
+				const float4 r = a.results[(size_t)pl * (size_t)spp + (size_t)s];
+				float dx, dy;
+				wf_sample_offsets(a, s, sampling_offs, dx, dy);
+				const int dx_0 = max(cx0 - px, round2int((double)dx - fw)), dx_1 = min(cx1 - px - 1, round2int((double)dx + fw - 1.0));
+				const int dy_0 = max(cy0 - py, round2int((double)dy - fw)), dy_1 = min(cy1 - py - 1, round2int((double)dy + fw - 1.0));
+				const double x_offs = (double)dx - 0.5, y_offs = (double)dy - 0.5;
+				for(int j = dy_0; j <= dy_1; ++j)
+				{
+					const int yi = (int)floor(fabs(((double)j - y_offs) * ts));
+					for(int i = dx_0; i <= dx_1; ++i)
+					{
+						const int xi = (int)floor(fabs(((double)i - x_offs) * ts));
+						const float w = a.ra.filter_table[yi * 16 + xi];
+						if(i == 0 && j == 0)
+						{
+							own[0] += r.x * w; own[1] += r.y * w; own[2] += r.z * w; own[3] += r.w * w; own[4] += w;
+						}
+						else
+						{
+							float *dst = a.ra.planes + ((size_t)(py + j - cy0) * (size_t)rp.width + (size_t)(px + i - cx0)) * YAFGPU_FILM_CHANNELS;
+							atomicAdd(dst + 0, r.x * w); atomicAdd(dst + 1, r.y * w); atomicAdd(dst + 2, r.z * w); atomicAdd(dst + 3, r.w * w);
+							atomicAdd(dst + 4, w);
+						}
+					}
+				}
+			}
+			float *dst = a.ra.planes + ((size_t)(py - cy0) * (size_t)rp.width + (size_t)(px - cx0)) * YAFGPU_FILM_CHANNELS;
+#pragma unroll
+			for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) atomicAdd(dst + c, own[c]);
+			continue;
+		}
 		float acc[YAFGPU_FILM_PLANES][YAFGPU_FILM_CHANNELS];
 #pragma unroll
 		for(int k = 0; k < YAFGPU_FILM_PLANES; ++k)

@@ -5,7 +5,11 @@ Reads /root/reference/tests/test01/test01.xml — a scene DATA file of the refer
 tests/golden/test01_pt.xml following SURVEY.md Appendix C: integrator directlighting -> pathtracing
 (path_samples 1, bounces 3, Russian roulette off, no caustics), 256x256, 16 spp, box filter width 1,
 linear tiles, one thread; textures / shader nodes / render passes / orco coordinates removed (no
-textures on the device path: the six cubes keep their plain material colours)."""
+textures on the device path: the six cubes keep their plain material colours).
+
+With --shipped it writes tests/golden/test01_dl.xml instead: the same stripping of textures, but the
+integrator and render settings the reference ships (directlighting, 480x270, 1 spp, gauss filter width 1.5) —
+the configuration BASELINE.md's 0.9 s badge was rendered with."""
 import os
 import re
 import sys
@@ -15,6 +19,8 @@ DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test01_pt.xml")
 
 
 def main():
+    shipped = "--shipped" in sys.argv[1:]
+    dst = DST.replace("test01_pt", "test01_dl") if shipped else DST
     if not os.path.exists(SRC):
         sys.exit("reference tree not present")
     x = open(SRC).read()
@@ -38,19 +44,22 @@ def main():
 	<transpShad bval="false"/>
 	<type sval="pathtracing"/>
 </integrator>"""
-    x = re.sub(r'<integrator name="default">.*?</integrator>', integ, x, flags=re.S)
-    for k, v in (("resx", 256), ("resy", 256), ("width", 256), ("height", 256), ("AA_minsamples", 16), ("threads", 1)):
-        x = re.sub(rf'<{k} ival="[^"]*"/>', f'<{k} ival="{v}"/>', x)
-    x = re.sub(r'<AA_pixelwidth fval="[^"]*"/>', '<AA_pixelwidth fval="1"/>', x)
-    x = re.sub(r'<filter_type sval="[^"]*"/>', '<filter_type sval="box"/>', x)
+    if not shipped:
+        x = re.sub(r'<integrator name="default">.*?</integrator>', integ, x, flags=re.S)
+        for k, v in (("resx", 256), ("resy", 256), ("width", 256), ("height", 256), ("AA_minsamples", 16)):
+            x = re.sub(rf'<{k} ival="[^"]*"/>', f'<{k} ival="{v}"/>', x)
+        x = re.sub(r'<AA_pixelwidth fval="[^"]*"/>', '<AA_pixelwidth fval="1"/>', x)
+        x = re.sub(r'<filter_type sval="[^"]*"/>', '<filter_type sval="box"/>', x)
+    x = re.sub(r'<threads ival="[^"]*"/>', '<threads ival="1"/>', x)
     x = re.sub(r'<tiles_order sval="[^"]*"/>', '<tiles_order sval="linear"/>', x)
     x = re.sub(r'<color_space sval="[^"]*"/>', '<color_space sval="LinearRGB"/>', x)
     x = re.sub(r"\n\s*\n+", "\n", x)
     head = ("<?xml version=\"1.0\"?>\n<!-- derived from the reference's tests/test01/test01.xml by tests/golden/make_test01_pt.py "
-            "(BASELINE.json config 0: path tracing, 256x256, 16 spp; textures removed) -->\n")
+            + ("(shipped settings: directlighting, gauss 1.5, 1 spp; textures removed) -->\n" if shipped else
+               "(BASELINE.json config 0: path tracing, 256x256, 16 spp; textures removed) -->\n"))
     x = re.sub(r"^<\?xml[^>]*\?>\s*", "", x)
-    open(DST, "w").write(head + x.strip() + "\n")
-    print(DST, len(x), "bytes")
+    open(dst, "w").write(head + x.strip() + "\n")
+    print(dst, len(x), "bytes")
 
 
 if __name__ == "__main__":

@@ -11,15 +11,19 @@ RTOL = 1e-4     # BASELINE.json north_star: per-pixel RGB within 1e-4 relative
 ABS_FLOOR = 1e-3
 
 
-def compare_films(gpu_film, ora_film, what, max_outliers=0):
+def compare_films(gpu_film, ora_film, what, max_outliers=0, exact_weights=True):
     a, b = po.film_to_rgb(gpu_film), po.film_to_rgb(ora_film)
-    assert np.array_equal(gpu_film[..., 4], ora_film[..., 4]), f"{what}: film weights differ"
+    if exact_weights:
+        assert np.array_equal(gpu_film[..., 4], ora_film[..., 4]), f"{what}: film weights differ"
+    else:
+        np.testing.assert_allclose(gpu_film[..., 4], ora_film[..., 4], rtol=2e-6, err_msg=f"{what}: film weights differ")
     rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(b[..., :3]), ABS_FLOOR)
     worst = rel.max(axis=-1)
     n_bad = int((worst > RTOL).sum())
     exact = float((gpu_film == ora_film).all(axis=-1).mean())
     print(f"{what}: {n_bad}/{worst.size} pixels over {RTOL}, max rel {worst.max():.3g}, bit-exact pixels {exact:.4f}")
-    assert np.array_equal(a[..., 3], b[..., 3]), f"{what}: alpha differs"
+    if exact_weights:
+        assert np.array_equal(a[..., 3], b[..., 3]), f"{what}: alpha differs"
     assert n_bad <= max_outliers, f"{what}: {n_bad} pixels over tolerance (max rel {worst.max():.3g})"
     return n_bad, exact
 
@@ -125,3 +129,104 @@ def test_config0_test01_xml_path_tracing():
     assert st.n_triangles == 74 and st.camera_samples == 256 * 256 * 16
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, "test01 path tracing 256x256 16spp")
+
+
+def test_test01_xml_shipped_settings_direct_lighting_gauss(pipeline):
+    """The reference's test scene with the integrator and film settings it ships (tests/test01/test01.xml:
+    directlighting, 480x270, 1 spp, gauss 1.5 — the render behind BASELINE.md's 0.9 s badge), textures removed."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline implements the narrow box filter only")
+    import os
+    from tests import xml_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test01_dl.xml")
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film = yi.getFilm(480, 270)
+    st = yi.getRenderStats()
+    sc, rd = xml_scene.load(path)
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=8))
+    assert st.camera_samples == 480 * 270
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "test01 shipped settings", exact_weights=False)
+
+
+def _sphere_soup(n_lat=10, n_lon=16, radius=0.45, centre=(0.0, 0.1, -0.3)):
+    """a tessellated sphere with exported vertex normals (addNormal path, Triangle::getSurface smooth branch)"""
+    c = np.array(centre, np.float32)
+    verts, norms = [], []
+    def pt(i, j):
+        th = np.pi * i / n_lat; ph = 2 * np.pi * j / n_lon
+        n = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], np.float32)
+        return c + radius * n, n
+    for i in range(n_lat):
+        for j in range(n_lon):
+            p00, n00 = pt(i, j); p01, n01 = pt(i, j + 1); p10, n10 = pt(i + 1, j); p11, n11 = pt(i + 1, j + 1)
+            if i > 0:
+                verts.append([p00, p10, p01]); norms.append([n00, n10, n01])
+            if i < n_lat - 1:
+                verts.append([p01, p10, p11]); norms.append([n01, n10, n11])
+    return np.array(verts, np.float32), np.array(norms, np.float32)
+
+
+def test_vertex_normals_crop_window_sampling_offset_and_alpha():
+    sc = scenes.cornell_soup(12, seed=2, res=(64, 48))
+    sv, sn = _sphere_soup()
+    walls = sc["verts"]
+    sc["verts"] = np.concatenate([walls, sv], axis=0)
+    sc["vnormals"] = np.concatenate([np.zeros_like(walls), sn], axis=0)      # zero triple = geometric normal
+    sc["tri_mat"] = np.concatenate([sc["tri_mat"], np.full(sv.shape[0], 1, np.int32)])
+    # crop window, non-zero base sampling offset + computer node, transparent background
+    rd = scenes.render_settings(40, 30, 8, bounces=3, xstart=13, ystart=9, adv_base_sampling_offset=7, adv_computer_node=2,
+                                bg_transp=True, tile_size=16)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "smooth sphere, crop window, sampling offset, bg_transp")
+
+
+def test_material_flags_translucency_orennayar_and_direct_lighting():
+    sc = scenes.cornell_soup(1200, seed=31, res=(48, 48))
+    sc["materials"][0] = {"type": "shinydiffusemat", "color": (0.8, 0.8, 0.7), "diffuse_reflect": 0.9, "diffuse_brdf": "oren_nayar", "sigma": 0.3}
+    sc["materials"][1] = {"type": "shinydiffusemat", "color": (0.7, 0.2, 0.2), "diffuse_reflect": 0.8, "translucency": 0.4, "emit": 0.05}
+    sc["materials"][2] = {"type": "shinydiffusemat", "color": (0.2, 0.7, 0.2), "visibility": "no_shadows", "receive_shadows": False}
+    sc["materials"][4] = {"type": "shinydiffusemat", "color": (0.5, 0.5, 0.9), "visibility": "shadow_only", "flat_material": True}
+    sc["tri_mat"][20::9] = 4
+    for integ in ("pathtracing", "directlighting"):
+        rd = scenes.render_settings(48, 48, 8, bounces=3, integrator=integ, background=(0.05, 0.06, 0.08))
+        film, st, ofilm, ost = render_both(sc, rd)
+        assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+        compare_films(film, ofilm, f"material flags / translucency / oren-nayar ({integ})")
+
+
+def test_path_samples_and_deep_bounces():
+    sc = scenes.cornell_soup(700, seed=44, res=(32, 32), open_front=False)
+    rd = scenes.render_settings(32, 32, 4, bounces=6, path_samples=3)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "closed box, path_samples 3, 6 bounces")
+
+
+def test_empty_scene_and_single_pixel():
+    sc = scenes.cornell_soup(12, seed=1, res=(8, 8))
+    sc["verts"] = sc["verts"][:0]; sc["tri_mat"] = sc["tri_mat"][:0]
+    rd = scenes.render_settings(8, 8, 2, background=(0.25, 0.5, 0.75))
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert np.array_equal(film, ofilm) and np.allclose(po.film_to_rgb(film)[..., :3], (0.25, 0.5, 0.75))
+    sc = scenes.cornell_soup(50, seed=1, res=(1, 1))
+    rd = scenes.render_settings(1, 1, 130)       # one pixel, more samples than a wave, not a multiple of 64
+    film, st, ofilm, ost = render_both(sc, rd)
+    compare_films(film, ofilm, "1x1 pixel, 130 spp")
+
+
+@pytest.mark.parametrize("filt,width", [("gauss", 1.5), ("mitchell", 1.2), ("lanczos", 2.0), ("box", 2.5)])
+def test_reconstruction_filters(filt, width, pipeline):
+    """ImageFilm's filter table and footprint (imagefilm.cc:124-187, 925-1015) beyond the 1-pixel box: the
+    reference's own test scene ships with gauss 1.5.  Neighbour splats go through float atomics, so the sum
+    order — and only that — differs from the oracle: same tolerance, weights to 2e-6."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline implements the narrow box filter only")
+    sc = scenes.cornell_soup(900, seed=12, res=(45, 37))
+    rd = scenes.render_settings(45, 37, 6, bounces=2, filter_type=filt, AA_pixelwidth=width, background=(0.1, 0.1, 0.2))
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"{filt} {width}", exact_weights=False)

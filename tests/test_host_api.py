@@ -82,9 +82,9 @@ def test_render_requires_names_and_supported_settings():
     scenes.load_scene(yi, sc, scenes.render_settings(8, 8, 1))
     yi.paramsSet({"AA_passes": 3})
     assert not yi.prepareRender() and "AA_passes" in yi.getLastError()
-    yi.paramsSet({"AA_passes": 1, "filter_type": "gauss"})
-    assert not yi.prepareRender() and "gauss" in yi.getLastError()
-    yi.paramsSet({"filter_type": "box", "camera_name": "nope"})
+    yi.paramsSet({"AA_passes": 1, "premult": True})
+    assert not yi.prepareRender() and "premult" in yi.getLastError()
+    yi.paramsSet({"premult": False, "camera_name": "nope"})
     assert not yi.prepareRender() and "Camera" in yi.getLastError()
 
 

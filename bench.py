@@ -238,7 +238,10 @@ def main():
                          "pass_ms": {k: round(v[0], 3) for k, v in prof.items()}, "pass_ms_total": round(kernel_ms, 3),
                          "bytes_per_ray": round(bytes_per_ray, 1),
                          "per_ray": {"interior_nodes": round(n_int, 2), "leaves": round(n_leaf, 2), "tri_tests": round(n_tri, 2),
-                                     "restarts": round(s[6] / rays_launch, 5)}},
+                                     "restarts": round(s[6] / rays_launch, 5)},
+                         # lanes doing a step per wave round of that kind / 64 (stats pass only)
+                         "simt": {"node_rounds": round((int(s[2]) + int(s[3])) / max(64 * (int(s[7]) & 0xffffffff), 1), 3),
+                                  "tri_rounds": round(int(s[4]) / max(64 * (int(s[7]) >> 32), 1), 3)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

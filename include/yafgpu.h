@@ -112,7 +112,8 @@ typedef struct yafgpu_render_params
 
 typedef struct yafgpu_counters   /* device atomics, accumulated per launch */
 {
-	uint64_t rays_closest, rays_shadow, interior_steps, leaves, tri_tests, camera_samples, restarts, pad;
+	uint64_t rays_closest, rays_shadow, interior_steps, leaves, tri_tests, camera_samples, restarts;
+	uint64_t wave_rounds;   /* YAFGPU_STATS only: node-step rounds executed by waves | triangle rounds << 32 (SIMT efficiency of the traversal) */
 } yafgpu_counters;
 
 typedef struct yafgpu_tree_info

@@ -1198,7 +1198,9 @@ static int wf_grid(const void *kernel, int cus)
 {
 	int per_cu = 0;
 	if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-	return cus * std::min(per_cu, 8);
+	int cap = 8;
+	if(const char *e = std::getenv("YAFGPU_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(e));   // occupancy experiments
+	return cus * std::min(per_cu, cap);
 }
 
 static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream, bool stats)

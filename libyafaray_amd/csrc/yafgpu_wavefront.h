@@ -142,7 +142,14 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int ph
 //   r20 second shadow ray: direction | tmin      r21 pending B | tmax of the second ray
 // Each step loads only what it uses and stores what it produced, so that no step keeps the whole path
 // in registers: the live set of wf_shade is that of its widest step, not of the whole integrator.
-#define REC(k) a.state[(size_t)(k) * a.cap + slot]
+// Addressing: the record base state + k*cap is wave-uniform (scalar registers) and the path's byte offset slot*16
+// fits 32 bits (cap <= 2^27), so an access is one `global_load/store ... v_off, s[base]` with no per-lane 64-bit
+// pointer arithmetic — and no per-record pointers for the optimizer to keep alive across the whole step loop.
+YG_DEV float4 &wf_rec(const WfArgs &a, int k, uint32_t slot)
+{
+	return *(float4 *)((char *)(a.state + (size_t)k * a.cap) + (slot << 4));
+}
+#define REC(k) wf_rec(a, (k), slot)
 
 struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i; };
 YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.depth << 8) | ((uint32_t)c.path_i << 16); }
@@ -156,7 +163,7 @@ YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 }
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
 
-enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
+enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
 
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
 YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ordinal)
@@ -263,63 +270,77 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot)
 }
 
 // direct_light()'s loops, with the two halves of a MIS pair (same light, same sample index) taken together:
-// each half adds into its own accumulator (ccol / ccol_2) in sample order, exactly as `for phase { for is }` does
-YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
+// each half adds into its own accumulator (ccol / ccol_2) in sample order, exactly as `for phase { for is }` does.
+// The loops are cut in two steps.  st_dl_next is the bookkeeping: it closes every light whose samples are all in
+// and says whether a candidate pair has to be evaluated next (W_DL_EVAL).  st_dl_eval evaluates that pair — the
+// widest step of the path program (81 VGPRs).
+YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const uint32_t w = ubits(REC(14).w);
 	int li = (int)(w & 0xffu), is = (int)(w >> 20);
 	const int l_end = (int)((w >> 8) & 0xffu);
-	SurfPt sp; V3 wo;
-	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
-	else { const float4 p = REC(7); make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), sp); wo = v3(REC(10)); }
-	const yafgpu_material &mat = sc.mats[sp.mat];
-	BsdfDat dat; mat_init_bsdf(mat, dat);
 	while(li < l_end)
 	{
 		const yafgpu_light &light = sc.lights[li];
 		const bool dirac = light.type == YAFGPU_LIGHT_POINT;
 		const int n = dirac ? 1 : (int)ceilf((float)light.samples * rp.aa_light_sample_multiplier);
-		if(is >= n)
+		if(is < n)
 		{
-			const float inv_ns = 1.f / (float)n;
-			Col col = mkc(0.f, 0.f, 0.f);
-			if(dirac) col = col + c3(REC(17));
-			else { col = col + c3(REC(15)) * inv_ns; col = col + c3(REC(16)) * inv_ns; }
-			REC(18) = f4(c3(REC(18)) + col, 0.f);
-			const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-			REC(15) = z4; REC(16) = z4; REC(17) = z4;
-			is = 0; ++li;
-			continue;
+			REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is)));
+			return W_DL_EVAL;
 		}
-		const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
-		float s_1 = 0.f, s_2 = 0.f;
-		if(!dirac) dl_samples(ra, light, li, is, pixel_sample, sampling_offs, s_1, s_2);
-		V3 d; float tmin, tmax; Col contrib;
-		int mask = 0;
-		Col pending_a = mkc(0.f, 0.f, 0.f);
-		float tmin_a = 0.f;
-		if(dl_candidate(ra, light, 0, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
-		{
-			if(cast_shadows) { pending_a = contrib; tmin_a = tmin; REC(1) = f4(d, tmax); mask |= 1; }
-			else { const int k = dirac ? 17 : 15; REC(k) = f4(c3(REC(k)) + contrib, 0.f); }
-		}
-		if(!dirac && dl_candidate(ra, light, 1, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
-		{
-			if(cast_shadows) { REC(20) = f4(d, tmin); REC(21) = f4(contrib, tmax); mask |= 2; }
-			else REC(16) = f4(c3(REC(16)) + contrib, 0.f);
-		}
-		if(mask)
-		{
-			REC(0) = f4(sp.p, tmin_a);
-			REC(14) = f4(pending_a, fbits(pack_dlc(li, l_end, mask, is)));
-			out_mask = mask;
-			return W_PARK_SHADOW;
-		}
-		++is;
+		const float inv_ns = 1.f / (float)n;
+		Col col = mkc(0.f, 0.f, 0.f);
+		if(dirac) col = col + c3(REC(17));
+		else { col = col + c3(REC(15)) * inv_ns; col = col + c3(REC(16)) * inv_ns; }
+		REC(18) = f4(c3(REC(18)) + col, 0.f);
+		const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+		REC(15) = z4; REC(16) = z4; REC(17) = z4;
+		is = 0; ++li;
 	}
 	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is)));
 	return W_DL_DONE;
+}
+
+YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
+	const uint32_t w = ubits(REC(14).w);
+	const int li = (int)(w & 0xffu), is = (int)(w >> 20), l_end = (int)((w >> 8) & 0xffu);
+	SurfPt sp; V3 wo;
+	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
+	else { const float4 p = REC(7); make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), sp); wo = v3(REC(10)); }
+	const yafgpu_material &mat = sc.mats[sp.mat];
+	BsdfDat dat; mat_init_bsdf(mat, dat);
+	const yafgpu_light &light = sc.lights[li];
+	const bool dirac = light.type == YAFGPU_LIGHT_POINT;
+	const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
+	float s_1 = 0.f, s_2 = 0.f;
+	if(!dirac) dl_samples(ra, light, li, is, pixel_sample, sampling_offs, s_1, s_2);
+	V3 d; float tmin, tmax; Col contrib;
+	int mask = 0;
+	Col pending_a = mkc(0.f, 0.f, 0.f);
+	float tmin_a = 0.f;
+	if(dl_candidate(ra, light, 0, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
+	{
+		if(cast_shadows) { pending_a = contrib; tmin_a = tmin; REC(1) = f4(d, tmax); mask |= 1; }
+		else { const int k = dirac ? 17 : 15; REC(k) = f4(c3(REC(k)) + contrib, 0.f); }
+	}
+	if(!dirac && dl_candidate(ra, light, 1, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
+	{
+		if(cast_shadows) { REC(20) = f4(d, tmin); REC(21) = f4(contrib, tmax); mask |= 2; }
+		else REC(16) = f4(c3(REC(16)) + contrib, 0.f);
+	}
+	if(mask)
+	{
+		REC(0) = f4(sp.p, tmin_a);
+		REC(14) = f4(pending_a, fbits(pack_dlc(li, l_end, mask, is)));
+		out_mask = mask;
+		return W_PARK_SHADOW;
+	}
+	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is + 1)));
+	return W_DL_NEXT;
 }
 
 // the light estimate of the current vertex is complete: book it and decide how the path goes on
@@ -440,28 +461,48 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 {
 	Ctl c = load_ctl(a, slot);
 	int where = (c.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
-	for(;;)
+	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
+	// order (a dispatch loop makes the optimizer thread the transitions, duplicate the steps and keep the union
+	// of their registers alive: 163 VGPRs against 81 for the widest single step).
+	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, c, ordinal);
+	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot);
+	while(where == W_DL_NEXT || where == W_DL_EVAL)
 	{
-		switch(where)
-		{
-			case W_AFTER_CLOSEST: where = st_after_closest(a, slot, c, ordinal); break;
-			case W_AFTER_SHADOW: where = st_after_shadow(a, slot); break;
-			case W_DL_NEXT: where = st_dl_next(a, slot, c, pixel_sample, sampling_offs, out_mask); break;
-			case W_DL_DONE: where = st_dl_done(a, slot, c); break;
-			case W_EXTEND: where = st_extend(a, slot, c); break;
-			case W_START_PATH: where = st_start_path(a, slot, c, pixel_sample, sampling_offs); break;
-			case W_PARK_CLOSEST: c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest;
-			case W_PARK_SHADOW: c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow;
-			default: // W_FINISH
-			{
-				float alpha = REC(19).w;
-				if(a.ra.rp.bg_transp) alpha = smax(alpha, 0.f);   // EmptyVolumeIntegrator: transmittance 1 (integrator_empty_volume.cc:32-38)
-				result[0] = c.col.r; result[1] = c.col.g; result[2] = c.col.b; result[3] = alpha;
-				return kReqDone;
-			}
-		}
+		if(where == W_DL_NEXT) where = st_dl_next(a, slot);
+		else where = st_dl_eval(a, slot, c, pixel_sample, sampling_offs, out_mask);
 	}
+	if(where == W_DL_DONE) where = st_dl_done(a, slot, c);
+	if(where == W_EXTEND) where = st_extend(a, slot, c);
+	if(where == W_START_PATH) where = st_start_path(a, slot, c, pixel_sample, sampling_offs);
+	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
+	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
+	// W_FINISH
+	float alpha = REC(19).w;
+	if(a.ra.rp.bg_transp) alpha = smax(alpha, 0.f);   // EmptyVolumeIntegrator: transmittance 1 (integrator_empty_volume.cc:32-38)
+	result[0] = c.col.r; result[1] = c.col.g; result[2] = c.col.b; result[3] = alpha;
+	return kReqDone;
 }
+#ifdef YAFGPU_STEP_PROBE
+__global__ __launch_bounds__(kBlock) void probe_advance(const WfArgs a, int *out) { const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; float r[4] = {0.f, 0.f, 0.f, 0.f}; int m = 0; out[slot] = wf_advance(a, slot, slot * 3u, slot * 5u, slot * 7u, r, m) + m + (int)r[0] + (int)r[3]; }
+// compile-time probe (not built by default): register footprint of each step in isolation
+#ifndef PROBE_WAVES
+#define PROBE_WAVES 1
+#endif
+#define PROBE(name, call) __global__ __launch_bounds__(kBlock, PROBE_WAVES) void name(const WfArgs a, int *out) { \
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
+	const int w = call; a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
+PROBE(probe_after_closest, st_after_closest(a, slot, c, slot * 7u))
+PROBE(probe_after_shadow, st_after_shadow(a, slot))
+PROBE(probe_dl_next, st_dl_next(a, slot))
+PROBE(probe_dl_eval, st_dl_eval(a, slot, c, slot * 3u, slot * 5u, m))
+PROBE(probe_dl_done, st_dl_done(a, slot, c))
+PROBE(probe_extend, st_extend(a, slot, c))
+PROBE(probe_start_path, st_start_path(a, slot, c, slot * 3u, slot * 5u))
+PROBE(probe_done_extend, (st_dl_done(a, slot, c) == W_EXTEND ? st_extend(a, slot, c) : st_start_path(a, slot, c, slot * 3u, slot * 5u)))
+PROBE(probe_closest_next, (st_after_closest(a, slot, c, slot * 7u) == W_DL_NEXT ? st_dl_next(a, slot) : 0))
+#undef PROBE
+#endif
+
 #undef REC
 
 // identity of a path slot: slot = pixel_local * spp + sample
@@ -531,6 +572,15 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 #ifndef YAFGPU_NODE_WINDOW
 #define YAFGPU_NODE_WINDOW 1   // C2 sweep: 1 -> 22.1, 2 -> 23.7, 4 -> 27.2, 8 -> 37.0 ms of traversal per pass: extra node fetches cost more than the latency they hide
 #endif
+#ifndef YAFGPU_VOTE_NUM
+#define YAFGPU_VOTE_NUM 1      // triangle round when n_tri * NUM >= n_node * DEN
+#endif
+#ifndef YAFGPU_VOTE_DEN
+#define YAFGPU_VOTE_DEN 1
+#endif
+#ifndef YAFGPU_NODE_BURST
+#define YAFGPU_NODE_BURST 4    // node steps per vote
+#endif
 #ifndef YAFGPU_TRACE_BATCH
 #define YAFGPU_TRACE_BATCH 512
 #endif
@@ -560,6 +610,10 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 	V3 from = mk(0.f, 0.f, 0.f), dir = from, inv_dir = from;
 	float ray_tmin = 0.f, dist = 0.f, t_exit = 0.f, tmin = 0.f, tmax = 0.f, z = 0.f, bu = 0.f, bv = 0.f;
 	int tri = -1; bool hit = false;
+	enum : uint32_t { kAtNode = 0u, kAtTri = 1u };
+	constexpr int kVoteNum = YAFGPU_VOTE_NUM, kVoteDen = YAFGPU_VOTE_DEN, kNodeBurst = YAFGPU_NODE_BURST;
+	uint32_t mode = kAtNode, np = 0u, first = 0u, k = 0u, ti = 0u;
+	uint32_t rounds_node = 0u, rounds_tri = 0u;     // wave-uniform (kStats)
 	for(;;)
 	{
 		const unsigned long long idle = __ballot(!active);
@@ -611,10 +665,10 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					}
 					float ea, eb;
 					tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f;
-					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, dist, ea, eb))
+					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
 					{
 						inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
-						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u;
+						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; mode = kAtNode;
 						stk.reset();
 						active = true;
 					}
@@ -626,82 +680,93 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				}
 			}
 		}
-		if(__ballot(active) == 0ull) { if(exhausted) break; else continue; }
-		if(active)
-		{
-			bool done = false, found = false;
-			if(z < tmin) done = true;                     // kdtree_triangle.cc:717
-			else
+		const unsigned long long m_act = __ballot(active);
+		if(m_act == 0ull) { if(exhausted) break; else continue; }
+		// The kernel is bound by instruction issue, not by memory (PMC: VALU and SALU issue slots 60-70 % busy,
+		// 28 % of lanes active per VALU instruction), so what counts is how many lanes share each instruction.
+		// A lane is either walking down the tree (kAtNode) or standing at a non-empty leaf with triangles to test
+		// (kAtTri).  Each round the WAVE does one kind of work, chosen by vote: a round of triangle tests when
+		// enough lanes stand at leaves, else a burst of node steps during which lanes that reach a leaf with
+		// triangles stop and wait, and lanes that reach an empty leaf pop and walk on.  Per ray the steps and
+		// their order are kd_trace's; only the interleaving between the rays of a wave changes.
+		const unsigned long long m_tri = __ballot(active && mode == kAtTri);
+		const int n_tri = __popcll(m_tri), n_node = __popcll(m_act) - n_tri;
+		bool done = false, found = false;
+		// end of a leaf (kdtree_triangle.cc:822-835 / :936-960): stop on a hit inside the cell, else continue at the
+		// nearest pending far child, or restart at the cell exit if the short stack lost it
+		auto leaf_end = [&]() {
+			mode = kAtNode;
+			if(!kAny && hit && z <= tmax) done = true;
+			else if(stk.count == 0)
 			{
-				// Depth-first layout: the left child of node n is n+1, so a run of left turns walks consecutive
-				// nodes.  Every fetch brings a window of kWin nodes (same or next cache line as the node itself),
-				// and a step into the window costs no memory round trip.
-				constexpr int kWin = YAFGPU_NODE_WINDOW;
-				uint2 win[kWin];
-				uint32_t wbase = node;
-#pragma unroll
-				for(int k = 0; k < kWin; ++k) win[k] = sc.nodes[node + (uint32_t)k];
-				uint2 nd = win[0];
-				while((nd.y & 3u) != 3u)
+				if(!stk.dropped || tmax >= t_exit) done = true;
+				else { tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false; if(kStats) ++cn.restarts; }
+			}
+			else { tmin = tmax; stk.pop(node, tmax); }
+			if(!done && z < tmin) done = true;                                  // :717
+		};
+		if(n_tri * kVoteNum >= n_node * kVoteDen)
+		{
+			if(kStats) ++rounds_tri;
+			if(active && mode == kAtTri)
+			{
+				uint32_t ref_v = 0u;
+				if(k + 1u < np) ref_v = sc.refs[first + k + 1u];
+				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
+				float t, u, v;
+				if(kStats) ++cn.tests;
+				if(tri_test(r0, r1, r2, from, dir, t, u, v))
 				{
-					const int axis = (int)(nd.y & 3u);
-					const float split = __uint_as_float(nd.x);
-					const float o = comp(from, axis), d = comp(dir, axis);
-					const float tplane = (split - o) * comp(inv_dir, axis);
-					const bool below = (o < split) || (o == split && d <= 0.f);
-					const uint32_t left = node + 1u, right = nd.y >> 2;
-					const uint32_t near_c = below ? left : right, far_c = below ? right : left;
-					if(kStats) ++cn.interior;
-					if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
-					else if(tplane < tmin) node = far_c;
-					else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
-					const uint32_t off = node - wbase;
-					if(off < (uint32_t)kWin)
+					const uint32_t vis = __float_as_uint(r1.w) >> 30;
+					if(kAny)
 					{
-						nd = win[0];
-#pragma unroll
-						for(int k = 1; k < kWin; ++k) if(off == (uint32_t)k) nd = win[k];
+						if(t < dist && t >= 0.f && (vis == 0u || vis == 2u)) found = true;
+					}
+					else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u)) { z = t; tri = (int)ti; bu = u; bv = v; hit = true; }
+				}
+				if(kAny && found) done = true;
+				else if(++k < np) ti = ref_v;
+				else leaf_end();
+			}
+		}
+		else
+		{
+#pragma unroll 1
+			for(int s = 0; s < kNodeBurst; ++s)
+			{
+				if(kStats && __ballot(active && !done && mode == kAtNode) != 0ull) ++rounds_node;
+				if(active && !done && mode == kAtNode)
+				{
+					const uint2 nd = sc.nodes[node];
+					if((nd.y & 3u) != 3u)
+					{
+						const int axis = (int)(nd.y & 3u);
+						const float split = __uint_as_float(nd.x);
+						const float o = comp(from, axis), d = comp(dir, axis);
+						const float tplane = (split - o) * comp(inv_dir, axis);
+						const bool below = (o < split) || (o == split && d <= 0.f);
+						const uint32_t left = node + 1u, right = nd.y >> 2;
+						const uint32_t near_c = below ? left : right, far_c = below ? right : left;
+						if(kStats) ++cn.interior;
+						if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
+						else if(tplane < tmin) node = far_c;
+						else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
 					}
 					else
 					{
-						wbase = node;
-#pragma unroll
-						for(int k = 0; k < kWin; ++k) win[k] = sc.nodes[node + (uint32_t)k];
-						nd = win[0];
+						np = nd.y >> 2; first = nd.x; k = 0u;
+						if(kStats) ++cn.leaves;
+						if(np == 0u) leaf_end();
+						else { ti = sc.refs[first]; mode = kAtTri; }     // in flight while the lane waits for the triangle round
 					}
 				}
-				const uint32_t np = nd.y >> 2, first = nd.x;
-				if(kStats) ++cn.leaves;
-				for(uint32_t k = 0; k < np; ++k)
-				{
-					const uint32_t ti = sc.refs[first + k];
-					const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
-					float t, u, v;
-					if(kStats) ++cn.tests;
-					if(tri_test(r0, r1, r2, from, dir, t, u, v))
-					{
-						const uint32_t vis = __float_as_uint(r1.w) >> 30;
-						if(kAny)
-						{
-							if(t < dist && t >= 0.f && (vis == 0u || vis == 2u)) { found = true; break; }
-						}
-						else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u)) { z = t; tri = (int)ti; bu = u; bv = v; hit = true; }
-					}
-				}
-				if(kAny ? found : (hit && z <= tmax)) done = true;         // :822 / :936-945
-				else if(stk.count == 0)
-				{
-					if(!stk.dropped || tmax >= t_exit) done = true;
-					else { tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false; if(kStats) ++cn.restarts; }
-				}
-				else { tmin = tmax; stk.pop(node, tmax); }
 			}
-			if(done)
-			{
-				if(kAny) a.verdict[2u * slot + which] = found ? 1u : 0u;
-				else a.state[2 * c + slot] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
-				active = false;
-			}
+		}
+		if(done)
+		{
+			if(kAny) a.verdict[2u * slot + which] = found ? 1u : 0u;
+			else a.state[2 * c + slot] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
+			active = false;
 		}
 	}
 	if(a.ra.counters != nullptr)
@@ -718,6 +783,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				atomicAdd((unsigned long long *)&a.ra.counters->leaves, (unsigned long long)v3_);
 				atomicAdd((unsigned long long *)&a.ra.counters->tri_tests, (unsigned long long)v4);
 				atomicAdd((unsigned long long *)&a.ra.counters->restarts, (unsigned long long)v6);
+				atomicAdd((unsigned long long *)&a.ra.counters->wave_rounds, (unsigned long long)rounds_node | ((unsigned long long)rounds_tri << 32));
 			}
 		}
 	}
@@ -725,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 
 // resume every answered path: entries [0, n_closest) come from the closest queue, the rest from the resume queue
 #ifndef YAFGPU_SHADE_WAVES
-#define YAFGPU_SHADE_WAVES 3     // 168 VGPRs, light spilling; C2: 1 -> 13.9 ms, 3 -> 11.8 ms, 4 -> 12.9 ms per pass
+#define YAFGPU_SHADE_WAVES 4     // 128 VGPRs, 64 B of scratch; C2: 3 -> 10.5, 4 -> 9.1, 5 -> 10.2 ms per pass
 #endif
 __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
 {
@@ -735,15 +801,18 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 	constexpr int kItems = 4;
 	__shared__ uint32_t s_tot[kWavesPerBlock][3];
 	__shared__ uint32_t s_base[kWavesPerBlock][3];
+	__shared__ uint32_t s_item[kItems][kBlock];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const uint32_t nc = a.cnt_in[0], nr = a.cnt_in[4];
 	const uint32_t total = nc + nr;
 	const uint32_t per_block = (uint32_t)kBlock * kItems;
 	for(uint32_t base = blockIdx.x * per_block; base < total; base += gridDim.x * per_block)
 	{
-		uint32_t slot_k[kItems]; int code_k[kItems];   // code: bit0 closest, bit1 resume, bit2 shadow ray A, bit3 shadow ray B
+		// what each item asked for, kept in LDS between the two loops: slot | code << 28
+		// (code: bit0 closest, bit1 resume, bit2 shadow ray A, bit3 shadow ray B); the item loop is not unrolled, so
+		// the register footprint is that of one item
 		uint32_t wc = 0u, wr = 0u, ws = 0u;            // this wave's totals per queue
-#pragma unroll
+#pragma unroll 1
 		for(int k = 0; k < kItems; ++k)
 		{
 			const uint32_t i = base + (uint32_t)k * kBlock + threadIdx.x;
@@ -764,9 +833,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 					a.results[slot] = make_float4(res[0], res[1], res[2], res[3]);
 				}
 				else if(req == kReqClosest) code = 1;
-				else code = 2 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);
+				else if(req == kReqShadow) code = 2 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);
 			}
-			slot_k[k] = slot; code_k[k] = code;
+			s_item[k][threadIdx.x] = slot | ((uint32_t)code << 28);
 			wc += (uint32_t)__popcll(__ballot(code & 1));
 			wr += (uint32_t)__popcll(__ballot(code & 2));
 			ws += (uint32_t)__popcll(__ballot(code & 4)) + (uint32_t)__popcll(__ballot(code & 8));
@@ -788,8 +857,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 #pragma unroll
 		for(int k = 0; k < kItems; ++k)
 		{
-			const int code = code_k[k];
-			const uint32_t slot = slot_k[k];
+			const uint32_t item = s_item[k][threadIdx.x];
+			const int code = (int)(item >> 28);
+			const uint32_t slot = item & 0x0fffffffu;
 			const unsigned long long bc = __ballot(code & 1), br = __ballot(code & 2), ba = __ballot(code & 4), bb = __ballot(code & 8);
 			if(code & 1) a.q_closest_out[oc + (uint32_t)__popcll(bc & below)] = slot;
 			if(code & 2) a.q_resume_out[orr + (uint32_t)__popcll(br & below)] = slot;

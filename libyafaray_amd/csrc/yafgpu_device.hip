@@ -171,21 +171,21 @@ YG_DEV bool tri_test(const float4 r0, const float4 r1, const float4 r2, V3 from,
 struct LaneStack
 {
 	uint2 *col;     // &stack[0][lane]; slot s lives at col[s * kWave]
-	int head, count; bool dropped;
-	YG_DEV void reset() { head = 0; count = 0; dropped = false; }
+	int sp, lo;     // entries [lo, sp) are live (ring of kStack); lo > 0: older pending far-children were overwritten
+	YG_DEV void reset() { sp = 0; lo = 0; }
+	YG_DEV bool empty() const { return sp == lo; }
+	YG_DEV bool lost() const { return lo > 0; }      // a restart will recover what was overwritten
 	YG_DEV void push(uint32_t node, float tmax)
 	{
-		col[head * kWave] = make_uint2(node, __float_as_uint(tmax));
-		head = (head + 1) & (kStack - 1);
-		if(count < kStack) ++count;
-		else dropped = true;       // the oldest pending far-child was overwritten: a restart will recover it
+		col[(sp & (kStack - 1)) * kWave] = make_uint2(node, __float_as_uint(tmax));
+		++sp;
+		lo = max(lo, sp - kStack);
 	}
 	YG_DEV void pop(uint32_t &node, float &tmax)
 	{
-		head = (head + kStack - 1) & (kStack - 1);
-		const uint2 e = col[head * kWave];
+		--sp;
+		const uint2 e = col[(sp & (kStack - 1)) * kWave];
 		node = e.x; tmax = __uint_as_float(e.y);
-		--count;
 	}
 };
 
@@ -252,11 +252,11 @@ YG_DEV bool kd_trace(const DevScene &sc, LaneStack &stk, V3 from, V3 dir, float 
 			}
 		}
 		if(!kAny && hit && z <= tmax) break;   // :822
-		if(stk.count == 0)
+		if(stk.empty())
 		{
-			if(!stk.dropped || tmax >= t_exit) break;
+			if(!stk.lost() || tmax >= t_exit) break;
 			// kd-restart: pending far-children were lost to the short stack; resume at the cell exit
-			tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false;
+			tmin = tmax; tmax = t_exit; node = 0u; stk.reset();
 			if(kStats) ++cn.restarts;
 			continue;
 		}

@@ -592,31 +592,36 @@ template<bool kAny, bool kStats>
 __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 {
 	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
+	// (origin, 1/direction) of the lane's ray per axis: a node step fetches the pair of its split axis with one
+	// ds_read_b64 instead of selecting it out of six registers (the kernel is VALU-bound, the LDS port is idle)
+	__shared__ float2 s_axis[kWavesPerBlock][3][kWave];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const DevScene &sc = a.ra.sc;
 	LaneStack stk;
 	stk.col = &s_stack[wave][0][lane];
+	float2 *const axis_col = &s_axis[wave][0][lane];      // axis k at axis_col[k * kWave]
 	LaneCounters cn = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
 	const uint32_t n = kAny ? a.cnt_in[1] : a.cnt_in[0];
 	uint32_t *cursor = kAny ? &a.cnt_in[3] : &a.cnt_in[2];
 	const uint32_t *q = kAny ? a.q_shadow_in : a.q_closest_in;
 	const size_t c = a.cap;
 	// per-lane ray + traversal state
-	bool active = false, exhausted = (n == 0u) || (sc.n_nodes == 0u && false);
+	bool exhausted = (n == 0u);
 	uint32_t slot = 0u, node = 0u, which = 0u;
 	uint32_t w_next = 0u, w_end = 0u;      // this wave's reserved queue range (wave-uniform)
 	// reservation size: large enough to keep the counter word off the critical path, small enough that a short queue still spreads over all waves
 	const uint32_t batch = min((uint32_t)kTraceBatch, max((uint32_t)kWave, (n / (gridDim.x * (uint32_t)kWavesPerBlock * 2u)) & ~63u));
-	V3 from = mk(0.f, 0.f, 0.f), dir = from, inv_dir = from;
+	V3 from = mk(0.f, 0.f, 0.f), dir = from;
+	uint32_t dneg = 0u;                    // bit k: direction component k <= 0 (the tie rule at o == split)
 	float ray_tmin = 0.f, dist = 0.f, t_exit = 0.f, tmin = 0.f, tmax = 0.f, z = 0.f, bu = 0.f, bv = 0.f;
 	int tri = -1; bool hit = false;
-	enum : uint32_t { kAtNode = 0u, kAtTri = 1u };
+	enum : uint32_t { kAtNode = 0u, kAtTri = 1u, kIdle = 2u, kDone = 3u };     // kIdle: no ray; kDone: answer to be written
 	constexpr int kVoteNum = YAFGPU_VOTE_NUM, kVoteDen = YAFGPU_VOTE_DEN, kNodeBurst = YAFGPU_NODE_BURST;
-	uint32_t mode = kAtNode, np = 0u, first = 0u, k = 0u, ti = 0u;
+	uint32_t mode = kIdle, np = 0u, first = 0u, k = 0u, ti = 0u;
 	uint32_t rounds_node = 0u, rounds_tri = 0u;     // wave-uniform (kStats)
 	for(;;)
 	{
-		const unsigned long long idle = __ballot(!active);
+		const unsigned long long idle = __ballot(mode == kIdle);
 		const int n_idle = __popcll(idle);
 		if(!exhausted && (n_idle >= YAFGPU_REFILL || n_idle == kWave))
 		{
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 			const uint32_t first = w_next;
 			w_next += min(avail, (uint32_t)n_idle);
-			if(!active && rank < avail)
+			if(mode == kIdle && rank < avail)
 			{
 				const uint32_t i = first + rank;
 				{
@@ -667,10 +672,12 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f;
 					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
 					{
-						inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+						axis_col[0] = make_float2(from.x, 1.f / dir.x);
+						axis_col[kWave] = make_float2(from.y, 1.f / dir.y);
+						axis_col[2 * kWave] = make_float2(from.z, 1.f / dir.z);
+						dneg = (dir.x <= 0.f ? 1u : 0u) | (dir.y <= 0.f ? 2u : 0u) | (dir.z <= 0.f ? 4u : 0u);
 						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; mode = kAtNode;
 						stk.reset();
-						active = true;
 					}
 					else
 					{	// misses the scene bound: answer at once
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				}
 			}
 		}
-		const unsigned long long m_act = __ballot(active);
+		const unsigned long long m_act = __ballot(mode != kIdle);
 		if(m_act == 0ull) { if(exhausted) break; else continue; }
 		// The kernel is bound by instruction issue, not by memory (PMC: VALU and SALU issue slots 60-70 % busy,
 		// 28 % of lanes active per VALU instruction), so what counts is how many lanes share each instruction.
@@ -689,32 +696,37 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 		// enough lanes stand at leaves, else a burst of node steps during which lanes that reach a leaf with
 		// triangles stop and wait, and lanes that reach an empty leaf pop and walk on.  Per ray the steps and
 		// their order are kd_trace's; only the interleaving between the rays of a wave changes.
-		const unsigned long long m_tri = __ballot(active && mode == kAtTri);
+		const unsigned long long m_tri = __ballot(mode == kAtTri);
 		const int n_tri = __popcll(m_tri), n_node = __popcll(m_act) - n_tri;
-		bool done = false, found = false;
 		// end of a leaf (kdtree_triangle.cc:822-835 / :936-960): stop on a hit inside the cell, else continue at the
-		// nearest pending far child, or restart at the cell exit if the short stack lost it
+		// nearest pending far child, or restart at the cell exit if the short stack lost it.  Written with selects:
+		// the wave pays for every branch some lane takes, and exec-mask bookkeeping was as many scalar
+		// instructions as the whole walk had vector ones.
 		auto leaf_end = [&]() {
-			mode = kAtNode;
-			if(!kAny && hit && z <= tmax) done = true;
-			else if(stk.count == 0)
-			{
-				if(!stk.dropped || tmax >= t_exit) done = true;
-				else { tmin = tmax; tmax = t_exit; node = 0u; stk.dropped = false; if(kStats) ++cn.restarts; }
-			}
-			else { tmin = tmax; stk.pop(node, tmax); }
-			if(!done && z < tmin) done = true;                                  // :717
+			const uint2 top = stk.col[((stk.sp - 1) & (kStack - 1)) * kWave];        // garbage when empty: unused then
+			const bool hit_here = !kAny && hit && z <= tmax;
+			const bool emp = stk.empty();
+			const bool restart = emp && stk.lost() && !(tmax >= t_exit);
+			if(kStats && restart && !hit_here) ++cn.restarts;
+			tmin = tmax;
+			node = emp ? 0u : top.x;
+			tmax = emp ? t_exit : __uint_as_float(top.y);
+			stk.sp = emp ? 0 : stk.sp - 1;
+			stk.lo = emp ? 0 : stk.lo;
+			const bool fin = hit_here || (emp && !restart) || z < tmin;                // z < tmin: :717
+			mode = fin ? kDone : kAtNode;
 		};
 		if(n_tri * kVoteNum >= n_node * kVoteDen)
 		{
 			if(kStats) ++rounds_tri;
-			if(active && mode == kAtTri)
+			if(mode == kAtTri)
 			{
 				uint32_t ref_v = 0u;
 				if(k + 1u < np) ref_v = sc.refs[first + k + 1u];
 				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
 				float t, u, v;
 				if(kStats) ++cn.tests;
+				bool found = false;
 				if(tri_test(r0, r1, r2, from, dir, t, u, v))
 				{
 					const uint32_t vis = __float_as_uint(r1.w) >> 30;
@@ -724,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					}
 					else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u)) { z = t; tri = (int)ti; bu = u; bv = v; hit = true; }
 				}
-				if(kAny && found) done = true;
+				if(kAny && found) { hit = true; mode = kDone; }
 				else if(++k < np) ti = ref_v;
 				else leaf_end();
 			}
@@ -734,23 +746,31 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 #pragma unroll 1
 			for(int s = 0; s < kNodeBurst; ++s)
 			{
-				if(kStats && __ballot(active && !done && mode == kAtNode) != 0ull) ++rounds_node;
-				if(active && !done && mode == kAtNode)
+				if(kStats && __ballot(mode == kAtNode) != 0ull) ++rounds_node;
+				if(mode == kAtNode)
 				{
 					const uint2 nd = sc.nodes[node];
 					if((nd.y & 3u) != 3u)
 					{
-						const int axis = (int)(nd.y & 3u);
+						const uint32_t axis = nd.y & 3u;
 						const float split = __uint_as_float(nd.x);
-						const float o = comp(from, axis), d = comp(dir, axis);
-						const float tplane = (split - o) * comp(inv_dir, axis);
-						const bool below = (o < split) || (o == split && d <= 0.f);
+						const float2 oi = axis_col[axis * kWave];
+						const float o = oi.x;
+						const float tplane = (split - o) * oi.y;
+						const bool below = (o < split) || (o == split && ((dneg >> axis) & 1u) != 0u);
 						const uint32_t left = node + 1u, right = nd.y >> 2;
 						const uint32_t near_c = below ? left : right, far_c = below ? right : left;
 						if(kStats) ++cn.interior;
-						if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
-						else if(tplane < tmin) node = far_c;
-						else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
+						const bool near_only = !(tplane <= tmax) || tplane <= 0.f;        // plane beyond the cell or behind the origin (also NaN)
+						const bool far_only = !near_only && tplane < tmin;
+						const bool both = !near_only && !far_only;
+						// the slot above the top is always free (at most kStack-1 live entries), so the far child is written
+						// unconditionally and only the stack pointer says whether it was a push
+						stk.col[(stk.sp & (kStack - 1)) * kWave] = make_uint2(far_c, __float_as_uint(tmax));
+						stk.sp += both ? 1 : 0;
+						stk.lo = max(stk.lo, stk.sp - (kStack - 1));
+						node = far_only ? far_c : near_c;
+						tmax = both ? tplane : tmax;
 					}
 					else
 					{
@@ -762,11 +782,11 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				}
 			}
 		}
-		if(done)
+		if(mode == kDone)
 		{
-			if(kAny) a.verdict[2u * slot + which] = found ? 1u : 0u;
+			if(kAny) a.verdict[2u * slot + which] = hit ? 1u : 0u;
 			else a.state[2 * c + slot] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
-			active = false;
+			mode = kIdle;
 		}
 	}
 	if(a.ra.counters != nullptr)

@@ -113,21 +113,22 @@ YG_DEV double scr_halton(const DevScene &sc, int dim, uint32_t n)
 }
 
 // Bound::cross, include/common/bound.h:144-212
-YG_DEV bool bound_cross(const DevScene &sc, V3 from, V3 dir, float dist, float &enter, float &leave)
+// (inv_dir = 1/dir per component, computed once by the caller: the traversal needs the same three quotients)
+YG_DEV bool bound_cross(const DevScene &sc, V3 from, V3 dir, V3 inv_dir, float dist, float &enter, float &leave)
 {
 	const V3 a0 = mk(sc.blo[0], sc.blo[1], sc.blo[2]), a1 = mk(sc.bhi[0], sc.bhi[1], sc.bhi[2]);
 	const V3 p = from - a0;
 	float lmin = -1e38f, lmax = 1e38f, ltmin, ltmax;
 	if(dir.x != 0.f)
 	{
-		const float inv = 1.f / dir.x;
+		const float inv = inv_dir.x;
 		if(inv > 0.f) { lmin = -p.x * inv; lmax = ((a1.x - a0.x) - p.x) * inv; }
 		else { lmin = ((a1.x - a0.x) - p.x) * inv; lmax = -p.x * inv; }
 		if((lmax < 0.f) || (lmin > dist)) return false;
 	}
 	if(dir.y != 0.f)
 	{
-		const float inv = 1.f / dir.y;
+		const float inv = inv_dir.y;
 		if(inv > 0.f) { ltmin = -p.y * inv; ltmax = ((a1.y - a0.y) - p.y) * inv; }
 		else { ltmin = ((a1.y - a0.y) - p.y) * inv; ltmax = -p.y * inv; }
 		lmin = smax(ltmin, lmin);
@@ -136,7 +137,7 @@ YG_DEV bool bound_cross(const DevScene &sc, V3 from, V3 dir, float dist, float &
 	}
 	if(dir.z != 0.f)
 	{
-		const float inv = 1.f / dir.z;
+		const float inv = inv_dir.z;
 		if(inv > 0.f) { ltmin = -p.z * inv; ltmax = ((a1.z - a0.z) - p.z) * inv; }
 		else { ltmin = ((a1.z - a0.z) - p.z) * inv; ltmax = -p.z * inv; }
 		lmin = smax(ltmin, lmin);
@@ -165,6 +166,26 @@ YG_DEV bool tri_test(const float4 r0, const float4 r1, const float4 r2, V3 from,
 	t = dot(e2, qvec) * inv_det;
 	if(t < eps) return false;
 	return true;
+}
+
+// the same test, straight-line: identical operations and roundings, the four rejections combined at the end
+// (a rejected lane may compute with inf / NaN on the way; its result is discarded)
+YG_DEV bool tri_test_flat(const float4 r0, const float4 r1, const float4 r2, V3 from, V3 dir, float &t, float &u, float &v)
+{
+	const V3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r1.x, r1.y, r1.z), e2 = mk(r2.x, r2.y, r2.z);
+	const float eps = r0.w;
+	const V3 pvec = cross(dir, e2);
+	const float det = dot(e1, pvec);
+	const bool det_ok = !(det > -eps && det < eps);
+	const float inv_det = 1.f / det;
+	const V3 tvec = from - a;
+	u = dot(tvec, pvec) * inv_det;
+	const bool u_ok = !(u < 0.f || u > 1.f);
+	const V3 qvec = cross(tvec, e1);
+	v = dot(dir, qvec) * inv_det;
+	const bool v_ok = !((v < 0.f) || ((u + v) > 1.f));
+	t = dot(e2, qvec) * inv_det;
+	return det_ok && u_ok && v_ok && !(t < eps);
 }
 
 // per-lane stack in LDS: column `lane` of a [kStack][64] array of (node, tmax)
@@ -201,8 +222,8 @@ YG_DEV bool kd_trace(const DevScene &sc, LaneStack &stk, V3 from, V3 dir, float 
 {
 	float a, b;
 	if(sc.n_nodes == 0u) return false;
-	if(!bound_cross(sc, from, dir, dist, a, b)) return false;
 	const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+	if(!bound_cross(sc, from, dir, inv_dir, dist, a, b)) return false;
 	const float t_exit = b;
 	float tmin = smax(a, 0.f), tmax = t_exit;
 	float z = dist;

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 #endif
 constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_REFILL
-#define YAFGPU_REFILL 32               // C2 sweep: 16 -> 1134, 32 -> 1408, 48 -> 1360 Mrays/s
+#define YAFGPU_REFILL 24               // C2 sweep (voted rounds): 8..32 within 2 %, 48 -> -5 %, 56 -> -12 %
 #endif
 template<bool kAny, bool kStats>
 __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
@@ -670,11 +670,12 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					}
 					float ea, eb;
 					tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f;
-					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
+					const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, inv_dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
 					{
-						axis_col[0] = make_float2(from.x, 1.f / dir.x);
-						axis_col[kWave] = make_float2(from.y, 1.f / dir.y);
-						axis_col[2 * kWave] = make_float2(from.z, 1.f / dir.z);
+						axis_col[0] = make_float2(from.x, inv_dir.x);
+						axis_col[kWave] = make_float2(from.y, inv_dir.y);
+						axis_col[2 * kWave] = make_float2(from.z, inv_dir.z);
 						dneg = (dir.x <= 0.f ? 1u : 0u) | (dir.y <= 0.f ? 2u : 0u) | (dir.z <= 0.f ? 4u : 0u);
 						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; mode = kAtNode;
 						stk.reset();
@@ -726,15 +727,16 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
 				float t, u, v;
 				if(kStats) ++cn.tests;
+				// Triangle::intersect without its early returns: the same operations in the same order, every lane to the
+				// end (a wave of 30 rays almost never leaves early as a whole), the rejections folded into one predicate
+				const bool ok = tri_test_flat(r0, r1, r2, from, dir, t, u, v);
+				const uint32_t vis = __float_as_uint(r1.w) >> 30;
 				bool found = false;
-				if(tri_test(r0, r1, r2, from, dir, t, u, v))
+				if(kAny) found = ok && t < dist && t >= 0.f && (vis == 0u || vis == 2u);
+				else
 				{
-					const uint32_t vis = __float_as_uint(r1.w) >> 30;
-					if(kAny)
-					{
-						if(t < dist && t >= 0.f && (vis == 0u || vis == 2u)) found = true;
-					}
-					else if(t < z && t >= ray_tmin && (vis == 0u || vis == 1u)) { z = t; tri = (int)ti; bu = u; bv = v; hit = true; }
+					const bool better = ok && t < z && t >= ray_tmin && (vis == 0u || vis == 1u);
+					z = better ? t : z; tri = better ? (int)ti : tri; bu = better ? u : bu; bv = better ? v : bv; hit = hit || better;
 				}
 				if(kAny && found) { hit = true; mode = kDone; }
 				else if(++k < np) ti = ref_v;

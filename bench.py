@@ -42,13 +42,15 @@ WORKLOADS = {
 }
 
 
-def make_workload(name, res=None, spp=None):
+def make_workload(name, res=None, spp=None, lights=None):
     from libyafaray_amd import scenes
     w = dict(WORKLOADS[name])
     if res:
         w["res"] = res
     if spp:
         w["spp"] = spp
+    if lights:
+        w["lights"] = lights      # C4's parity variant has one light (the two-light counter is serial state)
     sc = scenes.cornell_soup(w["n_tris"], seed=w["seed"], sigma=w["sigma"], glossy_fraction=w["glossy"], n_lights=w["lights"],
                              res=(w["res"], w["res"]))
     rd = scenes.render_settings(w["res"], w["res"], w["spp"], bounces=w["bounces"])
@@ -60,23 +62,27 @@ def cpu_baseline(name, budget_s=20.0):
     the same scene at reduced resolution / samples per pixel, sized from a pilot run to ~budget_s of CPU wall."""
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # pilot at 64x64x2 to size the sample; the camera resolution is part of the scene, so each size is its own scene
-    w, sc, rd = make_workload(name, res=64)
-    t0 = time.time()
-    osc = po.OracleScene(sc)            # kd build is setup, not timed
-    build_s = time.time() - t0
-    _, st = osc.render(dict(rd, AA_minsamples=2, oracle_threads=cores))
-    osc.close()
-    rate = (st.rays_closest + st.rays_shadow) / max(st.render_seconds, 1e-6)
-    rays_per_sample = (st.rays_closest + st.rays_shadow) / max(st.camera_samples, 1)
-    samples = budget_s * rate / rays_per_sample
-    spp = w["spp"]
-    sres = int(max(32, min(WORKLOADS[name]["res"], (samples / spp) ** 0.5))) // 32 * 32
-    w, sc, rd = make_workload(name, res=sres)
-    osc = po.OracleScene(sc)
-    _, st = osc.render(dict(rd, AA_minsamples=spp, oracle_threads=cores, tile_size=8))
-    rays = st.rays_closest + st.rays_shadow
-    osc.close()
+    # sized iteratively: a small pilot, then runs at the workload's spp whose pixel count is scaled from the rate of
+    # the previous one until a run lasts at least half the budget (the first runs pay thread start-up and cold
+    # caches, so their rate underestimates).  The camera resolution is part of the scene, so each size is its own
+    # scene; sizes may exceed the workload's own resolution: same scene, more pixels.
+    spp = w_spp = WORKLOADS[name]["spp"]
+    sres, run_spp, build_s = 128, 8, 0.0
+    for attempt in range(4):
+        w, sc, rd = make_workload(name, res=sres)
+        t0 = time.time()
+        osc = po.OracleScene(sc)            # kd build is setup, not timed
+        build_s = time.time() - t0
+        _, st = osc.render(dict(rd, AA_minsamples=run_spp, oracle_threads=cores, tile_size=8))
+        osc.close()
+        rays = st.rays_closest + st.rays_shadow
+        if run_spp == w_spp and (st.render_seconds >= 0.5 * budget_s or sres >= 2048):
+            break
+        rate = rays / max(st.render_seconds, 1e-6)
+        rays_per_sample = rays / max(st.camera_samples, 1)
+        samples = budget_s * rate / rays_per_sample
+        sres = int(max(32, min(2048, (samples / spp) ** 0.5))) // 32 * 32
+        run_spp = w_spp
     return {"value": round(rays / st.render_seconds / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"same scene ({w['n_tris']} tris), {sres}x{sres} px, {spp} spp, {rays} rays in {st.render_seconds:.2f} s "
                       f"(oracle kd build {build_s:.1f} s excluded)"}

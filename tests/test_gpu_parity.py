@@ -230,3 +230,60 @@ def test_reconstruction_filters(filt, width, pipeline):
     film, st, ofilm, ost = render_both(sc, rd)
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, f"{filt} {width}", exact_weights=False)
+
+
+# ---- BASELINE.json's full-size configurations -----------------------------------------------------------
+# In the parity regime the film is a pure function of (pixel, sample index) (experiment 2), so the
+# oracle rendering a CROP WINDOW of the frame must reproduce that region of the full-size GPU film — except the
+# crop's first row and column, which in the full frame also receive the box filter's splats from the pixels
+# above / to the left (ImageFilm::addSample).  That pins the full-size renders to the oracle at a cost of a few
+# tens of thousands of oracle samples per window.
+def _full_size_against_crops(name, crops, size, lights=None):
+    import bench
+    w, sc, rd = bench.make_workload(name, lights=lights)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film = yi.getFilm(rd["width"], rd["height"])
+    st = yi.getRenderStats()
+    assert st.camera_samples == rd["width"] * rd["height"] * rd["AA_minsamples"]
+    assert st.n_triangles == len(sc["verts"])
+    # every sample adds weight 1 to its own pixel, and to the right / lower neighbour as well when its offset is
+    # >= 0.999 of a pixel (box half-width 0.501): about 0.1 % of the samples per axis
+    n_samples = rd["width"] * rd["height"] * rd["AA_minsamples"]
+    extra = float(film[..., 4].astype(np.float64).sum()) - n_samples
+    assert 0 <= extra < 0.004 * n_samples, f"film weight {extra} over the sample count"
+    yi.render()                                   # determinism: the second pass gives the same bits
+    assert np.array_equal(film, yi.getFilm(rd["width"], rd["height"])), "two passes over the same scene differ"
+    osc = po.OracleScene(sc)
+    bad = total = 0
+    for (x0, y0) in crops:
+        ofilm, _ = osc.render(dict(rd, xstart=x0, ystart=y0, width=size, height=size, oracle_threads=8))
+        g = film[y0 + 1:y0 + size, x0 + 1:x0 + size]
+        n_bad, exact = compare_films(g, ofilm[1:, 1:], f"{name} full size, window at ({x0},{y0})", max_outliers=2)
+        bad += n_bad; total += g.shape[0] * g.shape[1]
+    osc.close()
+    assert bad <= max(1, total // 2000)       # two builds of the reference itself differ on ~3e-5 of pixels
+    return st
+
+
+def test_full_size_c2_against_oracle_windows(pipeline):
+    """BASELINE.json configs[1]: 100k triangles, 512x512, 64 spp, primary + 1 bounce."""
+    if pipeline == "megakernel":
+        pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
+    _full_size_against_crops("c2", [(40, 60), (250, 250), (470, 300), (200, 480)], 24)
+
+
+def test_full_size_c3_against_oracle_windows(pipeline):
+    """BASELINE.json configs[2]: 1M triangles, 1024x1024, 256 spp, 2 bounces."""
+    if pipeline == "megakernel":
+        pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
+    _full_size_against_crops("c3", [(100, 700), (512, 512)], 12)
+
+
+def test_full_size_c4_one_light_against_oracle_windows(pipeline):
+    """BASELINE.json configs[3] in its parity variant (one area light: SURVEY 8d): 1M triangles, half of them
+    glossy, 1024x1024, 64 spp, 2 bounces, MIS."""
+    if pipeline == "megakernel":
+        pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
+    _full_size_against_crops("c4", [(300, 800), (640, 400)], 16, lights=1)

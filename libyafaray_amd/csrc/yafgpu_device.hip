@@ -933,7 +933,7 @@ struct yafgpu_scene
 	int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
-	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr; uint32_t wf_cap = 0;
+	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
 	float *d_filter_table = nullptr;
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
@@ -1117,6 +1117,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_queues) (void)hipFree(s->wf_queues);
 	if(s->wf_counts) (void)hipFree(s->wf_counts);
 	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
+	if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	delete s;
 }
@@ -1204,6 +1205,7 @@ static void host_filter_table(int type, float table[256])
 static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
 {
 	if(rp->width <= 0 || rp->height <= 0 || rp->aa_minsamples <= 0 || rp->tile_size <= 0) return fail(-10, "empty image, sample count or tile size");
+	if(rp->xstart < 0 || rp->ystart < 0 || rp->xstart + rp->width > 65535 || rp->ystart + rp->height > 65535) return fail(-10, "render window outside [0, 65535) pixels");
 	if(rp->bounces > 12) return fail(-11, "bounces > 12 would use scrHalton dimensions >= 50, which are a global racy LCG in the reference (scr_halton.h:70-73)");
 	if(rp->filter_type < YAFGPU_FILTER_BOX || rp->filter_type > YAFGPU_FILTER_LANCZOS) return fail(-12, "unknown filter type");
 	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
@@ -1250,12 +1252,14 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(s->wf_results) (void)hipFree(s->wf_results);
 		if(s->wf_queues) (void)hipFree(s->wf_queues);
 		if(s->wf_verdict) (void)hipFree(s->wf_verdict);
-		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_verdict = nullptr; s->wf_cap = 0;
+		if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
+		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_verdict = nullptr; s->wf_pix_xy = nullptr; s->wf_cap = 0;
 		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)kWfRecs * cap * sizeof(float4)));
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
 		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
 		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
 		HIP_OK(hipMalloc((void **)&s->wf_verdict, (size_t)2 * cap * sizeof(uint32_t)));
+		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
 	}
 	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 64 * sizeof(uint32_t)));
@@ -1298,7 +1302,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		a.ra = ra;
 		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results;
 		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
-		a.pix_prefix = s->d_pix_prefix;
+		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy;
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume

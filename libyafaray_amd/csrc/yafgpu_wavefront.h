@@ -28,6 +28,8 @@ struct WfArgs
 	float4 *results;                  // final rgba per path
 	uint32_t n_paths, pixel_begin, n_pixels;
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
+	uint32_t *pix_xy;                 // px | py << 16 per pixel of the chunk: written by wf_generate, so that resuming a path
+	                                  // costs one load instead of a binary search over the tile prefix (9 dependent loads)
 	// closest queue: one entry per path (the path's ray).  shadow queue: one entry per shadow RAY,
 	// slot | which<<31 — a path parks with up to two (the light-sampling and the BSDF-sampling ray of one
 	// MIS pair).  resume queue: the paths (once each) that wait for shadow answers.
@@ -165,8 +167,63 @@ YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t
 
 enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
 
+// register-resident copies of records 11, 12, 14, 18 (and, with YAFGPU_HOT_ACC, the accumulators 15..17) during
+// one advance (see wf_advance); the other records of the 11..18 range go straight to memory
+#ifndef YAFGPU_HOT_ACC
+#define YAFGPU_HOT_ACC 1      // C2 shade: 0 -> 7.8 ms, 1 -> 6.9 ms per pass (3 waves/SIMD)
+#endif
+struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty; };
+template<int K> constexpr bool hot_cached() { return K == 11 || K == 12 || K == 14 || K == 18 || (YAFGPU_HOT_ACC && K >= 15 && K <= 17); }
+template<int K> YG_DEV float4 &hot_ref(Hot &h)
+{
+	static_assert(K == 11 || K == 12 || (K >= 14 && K <= 18), "not a hot record");
+	if constexpr(K == 11) return h.r11; else if constexpr(K == 12) return h.r12; else if constexpr(K == 14) return h.r14;
+	else if constexpr(K == 15) return h.r15; else if constexpr(K == 16) return h.r16; else if constexpr(K == 17) return h.r17;
+	else return h.r18;
+}
+template<int K> YG_DEV float4 hot_get(const WfArgs &a, uint32_t slot, Hot &h)
+{
+	if constexpr(!hot_cached<K>()) return REC(K);
+	else
+	{
+		constexpr uint32_t bit = 1u << (K - 11);
+		if(!(h.valid & bit)) { hot_ref<K>(h) = REC(K); h.valid |= bit; }
+		return hot_ref<K>(h);
+	}
+}
+template<int K> YG_DEV void hot_set(const WfArgs &a, uint32_t slot, Hot &h, float4 v)
+{
+	if constexpr(!hot_cached<K>()) REC(K) = v;
+	else
+	{
+		constexpr uint32_t bit = 1u << (K - 11);
+		hot_ref<K>(h) = v; h.valid |= bit; h.dirty |= bit;
+	}
+}
+YG_DEV void hot_preload(const WfArgs &a, uint32_t slot, Hot &h)
+{
+	h.r11 = REC(11); h.r12 = REC(12); h.r14 = REC(14); h.r18 = REC(18);
+	h.valid = 0x8bu; h.dirty = 0u;
+	if(YAFGPU_HOT_ACC) { h.r15 = REC(15); h.r16 = REC(16); h.r17 = REC(17); h.valid = 0xfbu; }
+}
+YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
+{
+	if(h.dirty & 0x01u) REC(11) = h.r11;
+	if(h.dirty & 0x02u) REC(12) = h.r12;
+	if(h.dirty & 0x08u) REC(14) = h.r14;
+	if(YAFGPU_HOT_ACC)
+	{
+		if(h.dirty & 0x10u) REC(15) = h.r15;
+		if(h.dirty & 0x20u) REC(16) = h.r16;
+		if(h.dirty & 0x40u) REC(17) = h.r17;
+	}
+	if(h.dirty & 0x80u) REC(18) = h.r18;
+}
+#define HGET(k) hot_get<k>(a, slot, h)
+#define HSET(k, v) hot_set<k>(a, slot, h, (v))
+
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
-YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ordinal)
+YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const float4 ans = REC(2);
@@ -200,19 +257,19 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ord
 		}
 		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
 		Mwc rr; rr.init(fnv32a(ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
-		REC(11) = make_float4(1.f, 1.f, 1.f, fbits(rr.x));
-		REC(12) = make_float4(0.f, 0.f, 0.f, fbits(rr.c));
+		HSET(11, make_float4(1.f, 1.f, 1.f, fbits(rr.x)));
+		HSET(12, make_float4(0.f, 0.f, 0.f, fbits(rr.c)));
 		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(0u), alpha);
-		REC(18) = z4;
+		HSET(18, z4);
 		c.path_i = 0; c.depth = 0;
 		if((bsdfs0 & kDiffuse) && sc.n_lights > 0)
 		{
-			REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0)));
-			REC(15) = z4; REC(16) = z4; REC(17) = z4;
+			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0))));
+			HSET(15, z4); HSET(16, z4); HSET(17, z4);
 			c.dl_on_sp0 = 1;
 			return W_DL_NEXT;
 		}
-		REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0)));
+		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
 		return W_DL_DONE;
 	}
 	if(!got) { ++c.path_i; return W_START_PATH; }                                              // :218 / :259-266
@@ -227,7 +284,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ord
 	V3 pwo = -dir;                                                                              // :271
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
 	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, 0.f); REC(9) = f4(hit.ng, 0.f); REC(10) = f4(pwo, 0.f);
-	REC(18) = z4;
+	HSET(18, z4);
 	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
 	if(want_dl)
 	{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
@@ -241,31 +298,31 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t ord
 		}
 		misc.z = fbits(calls + 1u);
 		REC(19) = misc;
-		REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0)));
-		REC(15) = z4; REC(16) = z4; REC(17) = z4;
+		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0))));
+		HSET(15, z4); HSET(16, z4); HSET(17, z4);
 		c.dl_on_sp0 = 0;
 		return W_DL_NEXT;
 	}
-	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0)));   // l_end == 0: no light estimate ran
+	HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));   // l_end == 0: no light estimate ran
 	return W_DL_DONE;
 }
 
 // the shadow rays of one MIS pair were answered: add what was unoccluded
-YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot)
+YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict)
 {
 	const DevScene &sc = a.ra.sc;
-	float4 r14 = REC(14);
+	float4 r14 = HGET(14);
 	const uint32_t w = ubits(r14.w);
 	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0xfu), is = (int)(w >> 20);
 	const bool dirac = sc.lights[li].type == YAFGPU_LIGHT_POINT;
-	if((mask & 1) && a.verdict[2u * slot] == 0u)
+	if((mask & 1) && verdict.x == 0u)
 	{
-		const int k = dirac ? 17 : 15;
-		REC(k) = f4(c3(REC(k)) + c3(r14), 0.f);
+		if(dirac) HSET(17, f4(c3(HGET(17)) + c3(r14), 0.f));
+		else HSET(15, f4(c3(HGET(15)) + c3(r14), 0.f));
 	}
-	if((mask & 2) && a.verdict[2u * slot + 1u] == 0u) REC(16) = f4(c3(REC(16)) + c3(REC(21)), 0.f);
+	if((mask & 2) && verdict.y == 0u) HSET(16, f4(c3(HGET(16)) + c3(REC(21)), 0.f));
 	r14.w = fbits(pack_dlc(li, l_end, 0, is + 1));
-	REC(14) = r14;
+	HSET(14, r14);
 	return W_DL_NEXT;
 }
 
@@ -274,10 +331,10 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot)
 // The loops are cut in two steps.  st_dl_next is the bookkeeping: it closes every light whose samples are all in
 // and says whether a candidate pair has to be evaluated next (W_DL_EVAL).  st_dl_eval evaluates that pair — the
 // widest step of the path program (81 VGPRs).
-YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot)
+YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	const uint32_t w = ubits(REC(14).w);
+	const uint32_t w = ubits(HGET(14).w);
 	int li = (int)(w & 0xffu), is = (int)(w >> 20);
 	const int l_end = (int)((w >> 8) & 0xffu);
 	while(li < l_end)
@@ -287,26 +344,26 @@ YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot)
 		const int n = dirac ? 1 : (int)ceilf((float)light.samples * rp.aa_light_sample_multiplier);
 		if(is < n)
 		{
-			REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is)));
+			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is))));
 			return W_DL_EVAL;
 		}
 		const float inv_ns = 1.f / (float)n;
 		Col col = mkc(0.f, 0.f, 0.f);
-		if(dirac) col = col + c3(REC(17));
-		else { col = col + c3(REC(15)) * inv_ns; col = col + c3(REC(16)) * inv_ns; }
-		REC(18) = f4(c3(REC(18)) + col, 0.f);
+		if(dirac) col = col + c3(HGET(17));
+		else { col = col + c3(HGET(15)) * inv_ns; col = col + c3(HGET(16)) * inv_ns; }
+		HSET(18, f4(c3(HGET(18)) + col, 0.f));
 		const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-		REC(15) = z4; REC(16) = z4; REC(17) = z4;
+		HSET(15, z4); HSET(16, z4); HSET(17, z4);
 		is = 0; ++li;
 	}
-	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is)));
+	HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is))));
 	return W_DL_DONE;
 }
 
-YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
+YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
-	const uint32_t w = ubits(REC(14).w);
+	const uint32_t w = ubits(HGET(14).w);
 	const int li = (int)(w & 0xffu), is = (int)(w >> 20), l_end = (int)((w >> 8) & 0xffu);
 	SurfPt sp; V3 wo;
 	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
@@ -325,30 +382,31 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, const Ctl &c, uint32_t pix
 	if(dl_candidate(ra, light, 0, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
 	{
 		if(cast_shadows) { pending_a = contrib; tmin_a = tmin; REC(1) = f4(d, tmax); mask |= 1; }
-		else { const int k = dirac ? 17 : 15; REC(k) = f4(c3(REC(k)) + contrib, 0.f); }
+		else if(dirac) HSET(17, f4(c3(HGET(17)) + contrib, 0.f));
+		else HSET(15, f4(c3(HGET(15)) + contrib, 0.f));
 	}
 	if(!dirac && dl_candidate(ra, light, 1, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
 	{
 		if(cast_shadows) { REC(20) = f4(d, tmin); REC(21) = f4(contrib, tmax); mask |= 2; }
-		else REC(16) = f4(c3(REC(16)) + contrib, 0.f);
+		else HSET(16, f4(c3(HGET(16)) + contrib, 0.f));
 	}
 	if(mask)
 	{
 		REC(0) = f4(sp.p, tmin_a);
-		REC(14) = f4(pending_a, fbits(pack_dlc(li, l_end, mask, is)));
+		HSET(14, f4(pending_a, fbits(pack_dlc(li, l_end, mask, is))));
 		out_mask = mask;
 		return W_PARK_SHADOW;
 	}
-	REC(14) = make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is + 1)));
+	HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is + 1))));
 	return W_DL_NEXT;
 }
 
 // the light estimate of the current vertex is complete: book it and decide how the path goes on
-YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Ctl &c)
+YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	const Col total = c3(REC(18));
-	const int l_end = (int)((ubits(REC(14).w) >> 8) & 0xffu);
+	const Col total = c3(HGET(18));
+	const int l_end = (int)((ubits(HGET(14).w) >> 8) & 0xffu);
 	if(c.stage == kStPrimary)
 	{
 		const uint32_t bsdfs0 = ubits(REC(5).w);
@@ -363,7 +421,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Ctl &c)
 	const uint32_t mb = mat_init_bsdf(pm, dat_n);
 	Col lcol = mkc(0.f, 0.f, 0.f);
 	if(l_end > 0) lcol = total * (float)sc.n_lights;
-	float4 r11 = REC(11), r12 = REC(12);
+	float4 r11 = HGET(11), r12 = HGET(12);
 	Col throughput = c3(r11), path_col = c3(r12);
 	if(c.stage == kStFirst)
 	{
@@ -373,7 +431,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Ctl &c)
 			lcol = lcol + mat_emit(pm, dummy, mk(0.f, 0.f, 0.f), false);
 		}
 		path_col = path_col + lcol * throughput;                                                // :228
-		REC(12) = f4(path_col, r12.w);
+		HSET(12, f4(path_col, r12.w));
 		c.depth = 1;
 		if(c.depth < rp.bounces) return W_EXTEND;
 		++c.path_i;
@@ -394,14 +452,14 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Ctl &c)
 		path_col = path_col + lcol * throughput;                                                // :292
 		++c.depth;
 	}
-	REC(11) = f4(throughput, r11.w); REC(12) = f4(path_col, r12.w);
+	HSET(11, f4(throughput, r11.w)); HSET(12, f4(path_col, r12.w));
 	if(alive && c.depth < rp.bounces) return W_EXTEND;
 	++c.path_i;
 	return W_START_PATH;
 }
 
 // next segment from the current vertex, :232-257
-YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Ctl &c)
+YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
 	const float4 p = REC(7);
@@ -419,19 +477,19 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Ctl &c)
 	V3 p_dir = mk(0.f, 0.f, 0.f);
 	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
 	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
-	const float4 r11 = REC(11);
-	REC(11) = f4(c3(r11) * scol, r11.w);
+	const float4 r11 = HGET(11);
+	HSET(11, f4(c3(r11) * scol, r11.w));
 	REC(0) = f4(hit.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
 	c.stage = kStDepth;
 	return W_PARK_CLOSEST;
 }
 
 // first segment of path sample `path_i` from the camera hit, :186-216 — or the end of the sample
-YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
+YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
-	if(c.path_i >= n_paths) { c.col = c.col + c3(REC(12)) / (float)n_paths; return W_FINISH; } // :297
+	if(c.path_i >= n_paths) { c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_FINISH; } // :297
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
 	const V3 wo0 = v3(REC(6));
@@ -447,7 +505,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel_
 	V3 p_dir = mk(0.f, 0.f, 0.f);
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
 	REC(10) = f4(wo0, 0.f);                          // pwo = wo
-	REC(11) = f4(scol, REC(11).w);                   // throughput = scol
+	HSET(11, f4(scol, HGET(11).w));                   // throughput = scol
 	float4 misc = REC(19);
 	misc.x = fbits(offs); misc.y = fbits(bs.sampled);
 	REC(19) = misc;
@@ -461,19 +519,29 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 {
 	Ctl c = load_ctl(a, slot);
 	int where = (c.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
+	// The records the light-estimate bookkeeping passes from step to step (throughput, path colour, the estimate
+	// in flight and its accumulators) live in registers for the duration of the advance: a resumed shadow answer
+	// loads them in ONE round of loads instead of one dependent round per step (each step used to re-read what the
+	// previous one had just stored), and they are written back once, when the path parks.  (Also forwarding the
+	// vertex st_after_closest writes to st_dl_eval in registers costs more in spills than the round trip it saves:
+	// 6.9 -> 7.7 ms on C2.)
+	Hot h; h.valid = 0u; h.dirty = 0u;
+	uint2 verdict = make_uint2(0u, 0u);
+	if(where == W_AFTER_SHADOW) { verdict = *(const uint2 *)&a.verdict[2u * slot]; hot_preload(a, slot, h); }
 	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
 	// order (a dispatch loop makes the optimizer thread the transitions, duplicate the steps and keep the union
 	// of their registers alive: 163 VGPRs against 81 for the widest single step).
-	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, c, ordinal);
-	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot);
+	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal);
+	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
 	while(where == W_DL_NEXT || where == W_DL_EVAL)
 	{
-		if(where == W_DL_NEXT) where = st_dl_next(a, slot);
-		else where = st_dl_eval(a, slot, c, pixel_sample, sampling_offs, out_mask);
+		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h);
+		else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
 	}
-	if(where == W_DL_DONE) where = st_dl_done(a, slot, c);
-	if(where == W_EXTEND) where = st_extend(a, slot, c);
-	if(where == W_START_PATH) where = st_start_path(a, slot, c, pixel_sample, sampling_offs);
+	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c);
+	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
+	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs);
+	if(where != W_FINISH) hot_flush(a, slot, h);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
 	// W_FINISH
@@ -483,36 +551,42 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	return kReqDone;
 }
 #ifdef YAFGPU_STEP_PROBE
-__global__ __launch_bounds__(kBlock) void probe_advance(const WfArgs a, int *out) { const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; float r[4] = {0.f, 0.f, 0.f, 0.f}; int m = 0; out[slot] = wf_advance(a, slot, slot * 3u, slot * 5u, slot * 7u, r, m) + m + (int)r[0] + (int)r[3]; }
-// compile-time probe (not built by default): register footprint of each step in isolation
+// compile-time probe (not built by default): register footprint of each step in isolation and of the whole program —
+//   hipcc ... -DYAFGPU_STEP_PROBE -Rpass-analysis=kernel-resource-usage
 #ifndef PROBE_WAVES
 #define PROBE_WAVES 1
 #endif
+__global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArgs a, int *out)
+{
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; float r[4] = {0.f, 0.f, 0.f, 0.f}; int m = 0;
+	out[slot] = wf_advance(a, slot, slot * 3u, slot * 5u, slot * 7u, r, m) + m + (int)r[0] + (int)r[3];
+}
 #define PROBE(name, call) __global__ __launch_bounds__(kBlock, PROBE_WAVES) void name(const WfArgs a, int *out) { \
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
-	const int w = call; a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
-PROBE(probe_after_closest, st_after_closest(a, slot, c, slot * 7u))
-PROBE(probe_after_shadow, st_after_shadow(a, slot))
-PROBE(probe_dl_next, st_dl_next(a, slot))
-PROBE(probe_dl_eval, st_dl_eval(a, slot, c, slot * 3u, slot * 5u, m))
-PROBE(probe_dl_done, st_dl_done(a, slot, c))
-PROBE(probe_extend, st_extend(a, slot, c))
-PROBE(probe_start_path, st_start_path(a, slot, c, slot * 3u, slot * 5u))
-PROBE(probe_done_extend, (st_dl_done(a, slot, c) == W_EXTEND ? st_extend(a, slot, c) : st_start_path(a, slot, c, slot * 3u, slot * 5u)))
-PROBE(probe_closest_next, (st_after_closest(a, slot, c, slot * 7u) == W_DL_NEXT ? st_dl_next(a, slot) : 0))
+	Hot h; hot_preload(a, slot, h); const int w = call; hot_flush(a, slot, h); \
+	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
+PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u))
+PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))
+PROBE(probe_dl_next, st_dl_next(a, slot, h))
+PROBE(probe_dl_eval, st_dl_eval(a, slot, h, c, slot * 3u, slot * 5u, m))
+PROBE(probe_dl_done, st_dl_done(a, slot, h, c))
+PROBE(probe_extend, st_extend(a, slot, h, c))
+PROBE(probe_start_path, st_start_path(a, slot, h, c, slot * 3u, slot * 5u))
 #undef PROBE
 #endif
 
 #undef REC
 
 // identity of a path slot: slot = pixel_local * spp + sample
+template<bool kTable>
 YG_DEV void wf_identity(const WfArgs &a, uint32_t slot, int &px, int &py, int &sample, uint32_t &pixel_sample, uint32_t &sampling_offs, uint32_t &ordinal)
 {
 	const yafgpu_render_params &rp = a.ra.rp;
 	const uint32_t spp = (uint32_t)rp.aa_minsamples;
 	const uint32_t pixel_local = slot / spp;
 	sample = (int)(slot - pixel_local * spp);
-	wf_pixel_of(a, pixel_local, px, py);
+	if(kTable) { const uint32_t xy = a.pix_xy[pixel_local]; px = (int)(xy & 0xffffu); py = (int)(xy >> 16); }
+	else wf_pixel_of(a, pixel_local, px, py);
 	sampling_offs = fnv32a((uint32_t)py * fnv32a((uint32_t)px));
 	pixel_sample = rp.base_sampling_offset + (uint32_t)sample;
 	ordinal = ((uint32_t)(py - rp.ystart) * (uint32_t)rp.width + (uint32_t)(px - rp.xstart)) * spp + (uint32_t)sample;
@@ -549,7 +623,8 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 	for(uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.n_paths; slot += gridDim.x * blockDim.x)
 	{
 		int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
-		wf_identity(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+		wf_identity<false>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+		if(sample == 0) a.pix_xy[slot / (uint32_t)a.ra.rp.aa_minsamples] = (uint32_t)px | ((uint32_t)py << 16);
 		float dx, dy;
 		wf_sample_offsets(a, sample, sampling_offs, dx, dy);
 		V3 from, dir; float tmin, tmax;
@@ -813,7 +888,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 
 // resume every answered path: entries [0, n_closest) come from the closest queue, the rest from the resume queue
 #ifndef YAFGPU_SHADE_WAVES
-#define YAFGPU_SHADE_WAVES 4     // 128 VGPRs, 64 B of scratch; C2: 3 -> 10.5, 4 -> 9.1, 5 -> 10.2 ms per pass
+#define YAFGPU_SHADE_WAVES 3     // 168 VGPRs, 44 B of scratch; C2: 3 -> 7.25, 4 -> 8.5 ms per pass (4: 224 B of scratch)
 #endif
 __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
 {
@@ -845,7 +920,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 			{
 				slot = (i < nc) ? (a.q_closest_in ? a.q_closest_in[i] : i) : a.q_resume_in[i - nc];
 				int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
-				wf_identity(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+				wf_identity<true>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
 				float res[4];
 				int m = 0;
 				const int req = wf_advance(a, slot, pixel_sample, sampling_offs, ordinal, res, m);

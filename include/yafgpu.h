@@ -108,7 +108,27 @@ typedef struct yafgpu_render_params
 	float background[3]; int32_t has_background;
 	/* pixel-tile sharding across GPUs: tile t is rendered iff t % shard_count == shard_index */
 	int32_t shard_index, shard_count;
+	/* one pass of the multi-pass schedule (TiledIntegrator::renderPass, integrator_tiled.cc:261-307); all zero for a
+	   single-pass render.  aa_minsamples is the sample count of THIS pass. */
+	int32_t multi_pass;            /* AA_passes > 1: sub-pixel positions from riVdC / riS (integrator_tiled.cc:394-398) */
+	uint32_t pass_offset;          /* samples per pixel taken by the earlier passes (renderPass's `offset`) */
+	int32_t accumulate;            /* add to the planes instead of starting from zero */
+	float aa_clamp_samples;        /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975); 0 = off */
+	const uint8_t *resample_mask;  /* HOST pointer, width*height bytes, row-major in window coordinates: the pixels that
+	                                  get samples in this pass (ImageFilm::doMoreSamples, imagefilm.cc:917-920); NULL = all */
 } yafgpu_render_params;
+
+/* Scene::setAntialiasing (scene.cc:761-778; defaults environment.cc:682-695) */
+typedef struct yafgpu_aa_schedule
+{
+	int32_t passes, inc_samples;
+	float threshold, resampled_floor;
+	float sample_multiplier_factor, light_sample_multiplier_factor;
+	int32_t detect_color_noise;
+	int32_t dark_detection_type;   /* 0 none, 1 linear, 2 curve */
+	float dark_threshold_factor;
+	int32_t variance_edge_size, variance_pixels;
+} yafgpu_aa_schedule;
 
 typedef struct yafgpu_counters   /* device atomics, accumulated per launch */
 {
@@ -147,6 +167,12 @@ int yafgpu_render_tiles(yafgpu_scene_t *scene, const yafgpu_render_params *rp, f
 int yafgpu_film_combine(const float *d_planes, float *d_film, int32_t width, int32_t height, void *stream);
 
 /* Convenience: allocate, render, combine, copy the film to host memory, synchronise. */
+/* TiledIntegrator::render (integrator_tiled.cc:116-258): pass 0 with rp->aa_minsamples samples, then aa->passes - 1
+   adaptive passes; between passes ImageFilm::nextPass (imagefilm.cc:270-480) picks the pixels to resample from the
+   film so far.  aa == NULL or aa->passes <= 1: one pass.  resampled[] (optional, aa->passes entries) receives the
+   number of pixels each pass sampled. */
+int yafgpu_render_passes_to_host(yafgpu_scene_t *scene, const yafgpu_render_params *rp, const yafgpu_aa_schedule *aa,
+                                 float *h_film, yafgpu_counters *h_counters, int32_t *resampled);
 int yafgpu_render_to_host(yafgpu_scene_t *scene, const yafgpu_render_params *rp, float *h_film, yafgpu_counters *h_counters);
 
 /* Ray batches (host pointers): rays = n*8 floats {from.xyz, dir.xyz, tmin, tmax}; closest-hit writes

@@ -92,6 +92,8 @@ struct yafaray_interface
 	// render
 	yafgpu_scene_t *gpu = nullptr;
 	yafgpu_render_params rp{};
+	yafgpu_aa_schedule aa{};
+	std::vector<int32_t> resampled;      // pixels sampled by each pass of the last render
 	bool prepared = false;
 	int shard_index = 0, shard_count = 1;
 	std::vector<float> film;
@@ -548,13 +550,28 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	p.get("adv_auto_min_raydist_enabled", auto_dist); p.get("adv_min_raydist_value", min_raydist);
 	p.get("adv_base_sampling_offset", base_offset); p.get("adv_computer_node", node);
 	p.get("color_space", yi->color_space); p.get("gamma", yi->gamma);
-	if(aa_passes != 1) return fail(yi, "render: adaptive multi-pass AA (AA_passes > 1) is not supported by the GPU path (SURVEY row N4)");
+	// Scene::setAntialiasing (scene.cc:761-778), defaults of RenderEnvironment::setupScene (environment.cc:682-695,747-762)
+	{
+		yafgpu_aa_schedule &aa = yi->aa;
+		aa = yafgpu_aa_schedule{};
+		int inc = aa_samples, var_edge = 10, var_pix = 0; double threshold = 0.05;
+		float floor_pct = 0.f, smf = 1.f, lmf = 1.f, dark_factor = 0.f; bool color_noise = false; std::string dark = "none";
+		p.get("AA_inc_samples", inc); p.get("AA_threshold", threshold); p.get("AA_resampled_floor", floor_pct);
+		p.get("AA_sample_multiplier_factor", smf); p.get("AA_light_sample_multiplier_factor", lmf);
+		p.get("AA_detect_color_noise", color_noise); p.get("AA_dark_detection_type", dark); p.get("AA_dark_threshold_factor", dark_factor);
+		p.get("AA_variance_edge_size", var_edge); p.get("AA_variance_pixels", var_pix);
+		aa.passes = aa_passes; aa.inc_samples = inc; aa.threshold = (float)threshold; aa.resampled_floor = floor_pct;
+		aa.sample_multiplier_factor = smf; aa.light_sample_multiplier_factor = lmf; aa.detect_color_noise = color_noise ? 1 : 0;
+		aa.dark_detection_type = dark == "linear" ? 1 : (dark == "curve" ? 2 : 0);
+		aa.dark_threshold_factor = dark_factor; aa.variance_edge_size = var_edge; aa.variance_pixels = var_pix;
+		if(aa_passes < 1) return fail(yi, "render: AA_passes must be at least 1");
+	}
 	int filter_type = YAFGPU_FILTER_BOX;      // RenderEnvironment::createImageFilm, environment.cc:537-541: unknown names default to box
 	if(filter == "mitchell") filter_type = YAFGPU_FILTER_MITCHELL;
 	else if(filter == "gauss") filter_type = YAFGPU_FILTER_GAUSS;
 	else if(filter == "lanczos") filter_type = YAFGPU_FILTER_LANCZOS;
 	if(premult) return fail(yi, "render: premultiplied alpha is not supported by the GPU path");
-	if(clamp_samples != 0.f || clamp_indirect != 0.f) return fail(yi, "render: AA_clamp_samples / AA_clamp_indirect are not supported by the GPU path");
+	(void)clamp_indirect;   // only clamps caustic-photon estimates (integrator_path_tracer.cc:160-165), which this path does not have
 	const IntegratorCfg &ic = inte->second->c;
 	yafgpu_render_params &rp = yi->rp;
 	std::memset(&rp, 0, sizeof rp);
@@ -566,6 +583,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.base_sampling_offset = (uint32_t)base_offset + (uint32_t)node * 100000u;   // imagefilm.h:124
 	rp.shadow_bias_auto = auto_bias; rp.shadow_bias = shadow_bias; rp.min_raydist_auto = auto_dist; rp.min_raydist = min_raydist;
 	rp.aa_light_sample_multiplier = 1.f;
+	rp.aa_clamp_samples = clamp_samples;
 	if(bg) { rp.has_background = 1; for(int k = 0; k < 3; ++k) rp.background[k] = bg->color[k]; }
 	rp.shard_index = yi->shard_index; rp.shard_count = yi->shard_count;
 
@@ -692,7 +710,7 @@ yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *o
 {
 	yi->abort_flag = false;
 	if(progress && progress->init) progress->init(progress->user, 100);
-	if(progress && progress->setTag) progress->setTag(progress->user, "Rendering pass 1 of 1...");
+	if(progress && progress->setTag) progress->setTag(progress->user, "Rendering...");
 	if(!yafaray_prepareRender(yi)) return 0;
 	if(yi->abort_flag) return fail(yi, "aborted");
 	const int w = yi->rp.width, h = yi->rp.height;
@@ -701,7 +719,8 @@ yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *o
 	hipEvent_t e0, e1;
 	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 	(void)hipEventRecord(e0, nullptr);
-	const int rc = yafgpu_render_to_host(yi->gpu, &yi->rp, yi->film.data(), &cn);
+	yi->resampled.assign((size_t)std::max(1, yi->aa.passes), 0);
+	const int rc = yafgpu_render_passes_to_host(yi->gpu, &yi->rp, &yi->aa, yi->film.data(), &cn, yi->resampled.data());
 	(void)hipEventRecord(e1, nullptr);
 	(void)hipEventSynchronize(e1);
 	float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

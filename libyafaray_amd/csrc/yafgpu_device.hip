@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 		case 3:
 		{
 			const uint32_t bits = __float_as_uint(x[0]), r = __float_as_uint(x[1]);
-			o[0] = ri_vdc(bits, r); o[1] = ri_lp(bits, r); o[2] = __uint_as_float(fnv32a(bits));
+			o[0] = ri_vdc(bits, r); o[1] = ri_lp(bits, r); o[2] = __uint_as_float(fnv32a(bits)); o[3] = ri_s(bits, r);
 			break;
 		}
 		case 4:
@@ -1234,7 +1234,18 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	std::vector<uint32_t> &pp = s->h_pix_prefix;
 	pp.assign(1, 0u);
 	for(const int4 &r : s->h_tiles) pp.push_back(pp.back() + (uint32_t)(r.z * r.w));
-	const uint32_t n_pixels_total = pp.back();
+	// a resample mask (adaptive pass): the pixels of this shard's tiles that are flagged, in tile order
+	std::vector<uint32_t> listed;
+	const bool masked = rp.resample_mask != nullptr;
+	if(masked)
+	{
+		for(const int4 &r : s->h_tiles)
+			for(int y = r.y; y < r.y + r.w; ++y)
+				for(int x = r.x; x < r.x + r.z; ++x)
+					if(rp.resample_mask[(size_t)(y - rp.ystart) * (size_t)rp.width + (size_t)(x - rp.xstart)]) listed.push_back((uint32_t)x | ((uint32_t)y << 16));
+		if(listed.empty()) return 0;
+	}
+	const uint32_t n_pixels_total = masked ? (uint32_t)listed.size() : pp.back();
 	if(pp.size() > s->pix_prefix_cap)
 	{
 		if(s->d_pix_prefix) (void)hipFree(s->d_pix_prefix);
@@ -1302,7 +1313,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		a.ra = ra;
 		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results;
 		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
-		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy;
+		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy; a.pix_listed = masked ? 1 : 0;
+		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + pb, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
@@ -1393,7 +1405,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	}
 	ra.n_tiles = (int)s->h_tiles.size();
 	ra.n_units = s->h_prefix.back();
-	HIP_OK(hipMemsetAsync(d_planes, 0, yafgpu_planes_bytes(rp->width, rp->height), stream));
+	if(!rp->accumulate) HIP_OK(hipMemsetAsync(d_planes, 0, yafgpu_planes_bytes(rp->width, rp->height), stream));
 	if(ra.n_tiles == 0) return 0;
 	if(!s->d_queue) HIP_OK(hipMalloc((void **)&s->d_queue, kQueues * 32 * sizeof(uint32_t)));
 	if(!same)
@@ -1421,6 +1433,8 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		const bool mega = pl && std::strcmp(pl, "megakernel") == 0;
 		if(!mega) return render_wavefront(s, ra, stream, stats);
 		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
+		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)
+			return fail(-15, "the one-kernel pipeline renders single-pass films only; use the wavefront pipeline");
 	}
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev));
@@ -1467,6 +1481,165 @@ int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, flo
 		if(hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
 		if(h_counters && hipMemcpy(h_counters, d_cnt, sizeof(yafgpu_counters), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "counter download failed");
 	}
+	(void)hipFree(d_planes); (void)hipFree(d_film); (void)hipFree(d_cnt);
+	return rc;
+}
+
+// ---- multi-pass anti-aliasing: TiledIntegrator::render (integrator_tiled.cc:116-258) -----------------------------
+// The noise detection between passes (ImageFilm::nextPass, imagefilm.cc:270-480) is an image-space pass over the
+// film so far; it runs on the host on the downloaded film (a few ms per pass at 1024x1024) — the passes themselves
+// are the hot path.
+namespace {
+float dark_threshold_curve(float b)   // ImageFilm::darkThresholdCurveInterpolate, imagefilm.cc:1312-1328
+{
+	if(b <= 0.10f) return 0.0001f;
+	else if(b > 0.10f && b <= 0.20f) return (0.0001f + (b - 0.10f) * (0.0010f - 0.0001f) / 0.10f);
+	else if(b > 0.20f && b <= 0.30f) return (0.0010f + (b - 0.20f) * (0.0020f - 0.0010f) / 0.10f);
+	else if(b > 0.30f && b <= 0.40f) return (0.0020f + (b - 0.30f) * (0.0035f - 0.0020f) / 0.10f);
+	else if(b > 0.40f && b <= 0.50f) return (0.0035f + (b - 0.40f) * (0.0055f - 0.0035f) / 0.10f);
+	else if(b > 0.50f && b <= 0.60f) return (0.0055f + (b - 0.50f) * (0.0075f - 0.0055f) / 0.10f);
+	else if(b > 0.60f && b <= 0.70f) return (0.0075f + (b - 0.60f) * (0.0100f - 0.0075f) / 0.10f);
+	else if(b > 0.70f && b <= 0.80f) return (0.0100f + (b - 0.70f) * (0.0150f - 0.0100f) / 0.10f);
+	else if(b > 0.80f && b <= 0.90f) return (0.0150f + (b - 0.80f) * (0.0250f - 0.0150f) / 0.10f);
+	else if(b > 0.90f && b <= 1.00f) return (0.0250f + (b - 0.90f) * (0.0400f - 0.0250f) / 0.10f);
+	else if(b > 1.00f && b <= 1.20f) return (0.0400f + (b - 1.00f) * (0.0800f - 0.0400f) / 0.20f);
+	else if(b > 1.20f && b <= 1.40f) return (0.0800f + (b - 1.20f) * (0.0950f - 0.0800f) / 0.20f);
+	else if(b > 1.40f && b <= 1.80f) return (0.0950f + (b - 1.40f) * (0.1000f - 0.0950f) / 0.40f);
+	else return 0.1000f;
+}
+struct Px { float c[4]; };
+Px px_normalized(const float *p)   // Pixel::normalized, util_image_buffers.h:39-43; Rgba / float, color.h:310-314
+{
+	Px o;
+	if(p[4] != 0.f) { const float f = (float)(1.0 / (double)p[4]); for(int k = 0; k < 4; ++k) o.c[k] = p[k] * f; }
+	else for(int k = 0; k < 4; ++k) o.c[k] = 0.f;
+	return o;
+}
+float px_difference(const Px &a, const Px &b, bool use_rgb)   // Rgba::colorDifference, color.h:447-464
+{
+	const float bri_a = 0.2126f * a.c[0] + 0.7152f * a.c[1] + 0.0722f * a.c[2];
+	const float bri_b = 0.2126f * b.c[0] + 0.7152f * b.c[1] + 0.0722f * b.c[2];
+	float d = std::fabs(bri_b - bri_a);
+	if(use_rgb) for(int k = 0; k < 4; ++k) { const float dk = std::fabs(b.c[k] - a.c[k]); if(d < dk) d = dk; }
+	return d;
+}
+// which pixels get more samples; returns their number
+int next_pass_mask(const float *film, int w, int h, const yafgpu_aa_schedule &aa, float aa_thesh, std::vector<uint8_t> &flags)
+{
+	flags.assign((size_t)w * (size_t)h, 0);
+	if(!(aa_thesh > 0.f)) { std::fill(flags.begin(), flags.end(), (uint8_t)1); return w * h; }   // :319,460; doMoreSamples :919
+	const int half = aa.variance_edge_size / 2;
+	float scaled = aa_thesh;
+	auto P = [&](int x, int y) { return film + 5 * ((size_t)y * (size_t)w + (size_t)x); };
+	auto set = [&](int x, int y) { flags[(size_t)y * (size_t)w + (size_t)x] = 1; };
+	const bool rgb = aa.detect_color_noise != 0;
+	for(int y = 0; y < h - 1; ++y)
+		for(int x = 0; x < w - 1; ++x)
+		{
+			if(P(x, y)[4] <= 0.f) set(x, y);
+			const Px c = px_normalized(P(x, y));
+			const float bri = 0.2126f * std::fabs(c.c[0]) + 0.7152f * std::fabs(c.c[1]) + 0.0722f * std::fabs(c.c[2]);
+			if(aa.dark_detection_type == 1 && aa.dark_threshold_factor > 0.f) scaled = aa_thesh * ((1.f - aa.dark_threshold_factor) + (bri * aa.dark_threshold_factor));
+			else if(aa.dark_detection_type == 2) scaled = dark_threshold_curve(bri);
+			if(px_difference(c, px_normalized(P(x + 1, y)), rgb) >= scaled) { set(x, y); set(x + 1, y); }
+			if(px_difference(c, px_normalized(P(x, y + 1)), rgb) >= scaled) { set(x, y); set(x, y + 1); }
+			if(px_difference(c, px_normalized(P(x + 1, y + 1)), rgb) >= scaled) { set(x, y); set(x + 1, y + 1); }
+			if(x > 0 && px_difference(c, px_normalized(P(x - 1, y + 1)), rgb) >= scaled) { set(x, y); set(x - 1, y + 1); }
+			if(aa.variance_pixels > 0)
+			{
+				int vx = 0, vy = 0;
+				for(int xd = -half; xd < half - 1; ++xd)
+				{
+					int xi = x + xd; if(xi < 0) xi = 0; else if(xi >= w - 1) xi = w - 2;
+					if(px_difference(px_normalized(P(xi, y)), px_normalized(P(xi + 1, y)), rgb) >= scaled) ++vx;
+				}
+				for(int yd = -half; yd < half - 1; ++yd)
+				{
+					int yi = y + yd; if(yi < 0) yi = 0; else if(yi >= h - 1) yi = h - 2;
+					if(px_difference(px_normalized(P(x, yi)), px_normalized(P(x, yi + 1)), rgb) >= scaled) ++vy;
+				}
+				if(vx + vy >= aa.variance_pixels)
+					for(int xd = -half; xd < half; ++xd)
+						for(int yd = -half; yd < half; ++yd)
+						{
+							int xi = x + xd; if(xi < 0) xi = 0; else if(xi >= w) xi = w - 1;
+							int yi = y + yd; if(yi < 0) yi = 0; else if(yi >= h) yi = h - 1;
+							set(xi, yi);
+						}
+			}
+		}
+	int n = 0;
+	for(uint8_t f : flags) n += f;
+	return n;
+}
+} // namespace
+
+int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp_in, const yafgpu_aa_schedule *aa_in,
+                                 float *h_film, yafgpu_counters *h_counters, int32_t *resampled_out)
+{
+	if(!s || !rp_in || !h_film) return fail(-1, "null argument");
+	yafgpu_aa_schedule aa{};
+	if(aa_in) aa = *aa_in;
+	if(aa.passes < 1) aa.passes = 1;
+	if(aa.passes > 1 && rp_in->shard_count > 1) return fail(-16, "multi-pass anti-aliasing needs the whole frame on one GPU: the noise detection between passes reads every pixel");
+	yafgpu_render_params rp = *rp_in;
+	const int w = rp.width, h = rp.height;
+	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
+	const size_t film_bytes = (size_t)w * (size_t)h * YAFGPU_FILM_CHANNELS * sizeof(float);
+	HIP_OK(hipMalloc((void **)&d_planes, yafgpu_planes_bytes(w, h)));
+	HIP_OK(hipMalloc((void **)&d_film, film_bytes));
+	HIP_OK(hipMalloc((void **)&d_cnt, sizeof(yafgpu_counters)));
+	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
+	auto film_now = [&]() -> int {
+		int rc = yafgpu_film_combine(d_planes, d_film, w, h, nullptr);
+		if(!rc && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
+		return rc;
+	};
+	// integrator_tiled.cc:136-258
+	const int aa_samples = std::max(1, rp.aa_minsamples);
+	const int aa_inc = aa.inc_samples > 0 ? aa.inc_samples : aa_samples;       // scene.cc:765
+	float threshold = aa.threshold, sample_mult = 1.f, light_mult = 1.f;
+	const int floor_pixels = (int)std::floor(aa.resampled_floor * (float)(w * h) / 100.f);
+	rp.aa_minsamples = aa_samples; rp.multi_pass = aa.passes > 1 ? 1 : 0; rp.pass_offset = 0u; rp.accumulate = 0; rp.resample_mask = nullptr;
+	if(aa.passes > 1) rp.aa_light_sample_multiplier = light_mult;
+	int rc = yafgpu_render_tiles(s, &rp, d_planes, d_cnt, nullptr);
+	if(resampled_out) resampled_out[0] = w * h;
+	std::vector<uint8_t> mask;
+	int acum = aa_samples, resampled = 0; bool threshold_changed = true;
+	for(int i = 1; i < aa.passes && !rc; ++i)
+	{
+		sample_mult *= aa.sample_multiplier_factor;
+		light_mult *= aa.light_sample_multiplier_factor;
+		if(!(resampled <= 0 && !threshold_changed))
+		{
+			if((rc = film_now())) break;
+			resampled = next_pass_mask(h_film, w, h, aa, threshold, mask);
+			threshold_changed = false;
+		}
+		const int n = (int)std::ceil((float)aa_inc * sample_mult);
+		if(resampled_out) resampled_out[i] = resampled > 0 ? resampled : 0;
+		if(resampled > 0)
+		{
+			rp.aa_minsamples = n; rp.pass_offset = (uint32_t)acum; rp.accumulate = 1;
+			rp.aa_light_sample_multiplier = light_mult;
+			rp.resample_mask = threshold > 0.f ? mask.data() : nullptr;
+			rc = yafgpu_render_tiles(s, &rp, d_planes, d_cnt, nullptr);
+		}
+		acum += n;
+		if(resampled < floor_pixels)
+		{
+			const float ratio = std::min(8.f, ((float)floor_pixels / (float)resampled));
+			threshold *= (1.f - 0.1f * ratio);
+			if(threshold > 0.f) threshold_changed = true;
+		}
+	}
+	if(!rc) rc = film_now();
+	if(!rc)
+	{
+		hipError_t e = hipDeviceSynchronize();
+		if(e != hipSuccess) rc = fail(-100, std::string("render: ") + hipGetErrorString(e));
+	}
+	if(!rc && h_counters && hipMemcpy(h_counters, d_cnt, sizeof(yafgpu_counters), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "counter download failed");
 	(void)hipFree(d_planes); (void)hipFree(d_film); (void)hipFree(d_cnt);
 	return rc;
 }

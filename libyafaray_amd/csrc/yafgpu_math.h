@@ -124,6 +124,12 @@ YG_DEV float ri_vdc(uint32_t bits, uint32_t r) // :93-101
 	bits = __brev(bits);
 	return clamp01((float)((double)(bits ^ r) * kMultRatio));
 }
+YG_DEV float ri_s(uint32_t i, uint32_t r) // :103-108
+{
+	for(uint32_t v = 1u << 31; i; i >>= 1, v ^= v >> 1)
+		if(i & 1u) r ^= v;
+	return clamp01((float)((double)r * kMultRatio));
+}
 YG_DEV float ri_lp(uint32_t i, uint32_t r) // :110-115
 {
 	for(uint32_t v = 1u << 31; i; i >>= 1, v |= v >> 1)

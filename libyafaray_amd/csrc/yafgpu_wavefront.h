@@ -28,6 +28,7 @@ struct WfArgs
 	float4 *results;                  // final rgba per path
 	uint32_t n_paths, pixel_begin, n_pixels;
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
+	int pix_listed;                   // the chunk's pixels are given by pix_xy (a resample mask picked them), not by the tile list
 	uint32_t *pix_xy;                 // px | py << 16 per pixel of the chunk: written by wf_generate, so that resuming a path
 	                                  // costs one load instead of a binary search over the tile prefix (9 dependent loads)
 	// closest queue: one entry per path (the path's ray).  shadow queue: one entry per shadow RAY,
@@ -588,7 +589,7 @@ YG_DEV void wf_identity(const WfArgs &a, uint32_t slot, int &px, int &py, int &s
 	if(kTable) { const uint32_t xy = a.pix_xy[pixel_local]; px = (int)(xy & 0xffffu); py = (int)(xy >> 16); }
 	else wf_pixel_of(a, pixel_local, px, py);
 	sampling_offs = fnv32a((uint32_t)py * fnv32a((uint32_t)px));
-	pixel_sample = rp.base_sampling_offset + (uint32_t)sample;
+	pixel_sample = rp.base_sampling_offset + rp.pass_offset + (uint32_t)sample;     // pass_offs + sample, integrator_tiled.cc:389
 	ordinal = ((uint32_t)(py - rp.ystart) * (uint32_t)rp.width + (uint32_t)(px - rp.xstart)) * spp + (uint32_t)sample;
 }
 
@@ -596,7 +597,13 @@ YG_DEV void wf_sample_offsets(const WfArgs &a, int sample, uint32_t sampling_off
 {
 	const int n_samples = a.ra.rp.aa_minsamples;
 	dx = 0.5f; dy = 0.5f;
-	if(n_samples > 1)
+	if(a.ra.rp.multi_pass)
+	{	// integrator_tiled.cc:394-398: scrambled van der Corput / Sobol, good for any total sample count
+		const uint32_t pixel_sample = a.ra.rp.base_sampling_offset + a.ra.rp.pass_offset + (uint32_t)sample;
+		dx = ri_vdc(pixel_sample, sampling_offs);
+		dy = ri_s(pixel_sample, sampling_offs);
+	}
+	else if(n_samples > 1)
 	{
 		const float d_1 = (float)(1.0 / (double)(float)n_samples);
 		dx = (float)((0.5 + (double)(float)sample) * (double)d_1);
@@ -623,8 +630,12 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 	for(uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.n_paths; slot += gridDim.x * blockDim.x)
 	{
 		int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
-		wf_identity<false>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
-		if(sample == 0) a.pix_xy[slot / (uint32_t)a.ra.rp.aa_minsamples] = (uint32_t)px | ((uint32_t)py << 16);
+		if(a.pix_listed) wf_identity<true>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+		else
+		{
+			wf_identity<false>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
+			if(sample == 0) a.pix_xy[slot / (uint32_t)a.ra.rp.aa_minsamples] = (uint32_t)px | ((uint32_t)py << 16);
+		}
 		float dx, dy;
 		wf_sample_offsets(a, sample, sampling_offs, dx, dy);
 		V3 from, dir; float tmin, tmax;
@@ -969,6 +980,23 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 	}
 }
 
+// Rgb::clampProportionalRgb (color.h:412-445), applied by addSample to every sample (imagefilm.cc:975)
+YG_DEV float4 wf_clamped(float4 c, float max_value)
+{
+	if(max_value > 0.f)
+	{
+		const float max_rgb = smax(c.x, smax(c.y, c.z));
+		const float adj = max_value / max_rgb;
+		if(max_rgb > max_value)
+		{
+			if(c.x >= max_rgb) { c.x = max_value; c.y *= adj; c.z *= adj; }
+			else if(c.y >= max_rgb) { c.y = max_value; c.x *= adj; c.z *= adj; }
+			else { c.z = max_value; c.x *= adj; c.y *= adj; }
+		}
+	}
+	return c;
+}
+
 // ImageFilm::addSample (imagefilm.cc:925-1015), box filter half-width 0.501: one thread per pixel of the
 // chunk adds its samples in index order into the own / right / down / diagonal planes
 __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
@@ -979,8 +1007,8 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 	const size_t plane_stride = (size_t)rp.width * (size_t)rp.height * YAFGPU_FILM_CHANNELS;
 	for(uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x; pl < a.n_pixels; pl += gridDim.x * blockDim.x)
 	{
-		int px, py;
-		wf_pixel_of(a, pl, px, py);
+		const uint32_t xy = a.pix_xy[pl];
+		const int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
 		const uint32_t sampling_offs = fnv32a((uint32_t)py * fnv32a((uint32_t)px));
 		if(a.ra.wide_filter)
 		{	// general footprint: table weights, neighbours through float atomics on plane 0 (their order is the only
@@ -990,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 			float own[YAFGPU_FILM_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f};
 			for(int s = 0; s < spp; ++s)
 			{
-				const float4 r = a.results[(size_t)pl * (size_t)spp + (size_t)s];
+				const float4 r = wf_clamped(a.results[(size_t)pl * (size_t)spp + (size_t)s], rp.aa_clamp_samples);
 				float dx, dy;
 				wf_sample_offsets(a, s, sampling_offs, dx, dy);
 				const int dx_0 = max(cx0 - px, round2int((double)dx - fw)), dx_1 = min(cx1 - px - 1, round2int((double)dx + fw - 1.0));
@@ -1021,14 +1049,15 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 			for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) atomicAdd(dst + c, own[c]);
 			continue;
 		}
+		const size_t pix = ((size_t)(py - rp.ystart) * (size_t)rp.width + (size_t)(px - rp.xstart)) * YAFGPU_FILM_CHANNELS;
 		float acc[YAFGPU_FILM_PLANES][YAFGPU_FILM_CHANNELS];
 #pragma unroll
 		for(int k = 0; k < YAFGPU_FILM_PLANES; ++k)
 #pragma unroll
-			for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) acc[k][c] = 0.f;
+			for(int c = 0; c < YAFGPU_FILM_CHANNELS; ++c) acc[k][c] = rp.accumulate ? a.ra.planes[(size_t)k * plane_stride + pix + c] : 0.f;   // a later pass carries the running sums on
 		for(int s = 0; s < spp; ++s)
 		{
-			const float4 r = a.results[(size_t)pl * (size_t)spp + (size_t)s];
+			const float4 r = wf_clamped(a.results[(size_t)pl * (size_t)spp + (size_t)s], rp.aa_clamp_samples);
 			float dx, dy;
 			wf_sample_offsets(a, s, sampling_offs, dx, dy);
 			const int dx_1 = min(cx1 - px - 1, round2int((double)dx + (double)a.ra.filterw - 1.0));
@@ -1038,7 +1067,6 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 			if(dy_1 >= 1) { acc[2][0] += r.x; acc[2][1] += r.y; acc[2][2] += r.z; acc[2][3] += r.w; acc[2][4] += 1.f; }
 			if(dx_1 >= 1 && dy_1 >= 1) { acc[3][0] += r.x; acc[3][1] += r.y; acc[3][2] += r.z; acc[3][3] += r.w; acc[3][4] += 1.f; }
 		}
-		const size_t pix = ((size_t)(py - rp.ystart) * (size_t)rp.width + (size_t)(px - rp.xstart)) * YAFGPU_FILM_CHANNELS;
 #pragma unroll
 		for(int k = 0; k < YAFGPU_FILM_PLANES; ++k)
 		{

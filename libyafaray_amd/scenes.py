@@ -156,10 +156,13 @@ def load_scene(yi, scene, render):
         rs["background_name"] = "world_background"
     for k in ("width", "height", "xstart", "ystart", "AA_passes", "AA_minsamples", "filter_type", "tile_size",
               "adv_base_sampling_offset", "adv_computer_node", "adv_auto_shadow_bias_enabled",
-              "adv_auto_min_raydist_enabled", "threads"):
+              "adv_auto_min_raydist_enabled", "threads", "AA_inc_samples", "AA_detect_color_noise", "AA_dark_detection_type",
+              "AA_variance_edge_size", "AA_variance_pixels"):
         if k in render:
             rs[k] = render[k]
-    for k in ("AA_pixelwidth", "adv_shadow_bias_value", "adv_min_raydist_value"):
+    for k in ("AA_pixelwidth", "adv_shadow_bias_value", "adv_min_raydist_value", "AA_threshold", "AA_resampled_floor",
+              "AA_sample_multiplier_factor", "AA_light_sample_multiplier_factor", "AA_indirect_sample_multiplier_factor",
+              "AA_dark_threshold_factor", "AA_clamp_samples", "AA_clamp_indirect"):
         if k in render:
             rs[k] = float(render[k])
     yi.paramsSet(rs)

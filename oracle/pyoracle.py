@@ -61,6 +61,11 @@ class RenderDesc(C.Structure):
         ("min_raydist", C.c_float), ("aa_light_sample_multiplier", C.c_float),
         ("background", f3), ("has_background", C.c_int32), ("tile_seed_rand", C.c_uint32),
         ("n_threads", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+        ("aa_inc_samples", C.c_int32), ("aa_threshold", C.c_float), ("aa_resampled_floor", C.c_float),
+        ("aa_sample_multiplier_factor", C.c_float), ("aa_light_sample_multiplier_factor", C.c_float),
+        ("aa_indirect_sample_multiplier_factor", C.c_float), ("aa_detect_color_noise", C.c_int32),
+        ("aa_dark_detection_type", C.c_int32), ("aa_dark_threshold_factor", C.c_float),
+        ("aa_variance_edge_size", C.c_int32), ("aa_variance_pixels", C.c_int32), ("aa_clamp_samples", C.c_float),
     ]
 
 
@@ -252,6 +257,19 @@ def render_desc(r):
     d.n_threads = r.get("oracle_threads", 1)
     d.shard_index = r.get("shard_index", 0)
     d.shard_count = r.get("shard_count", 1)
+    # multi-pass anti-aliasing: defaults of environment.cc:682-695
+    d.aa_inc_samples = r.get("AA_inc_samples", d.aa_minsamples)
+    d.aa_threshold = r.get("AA_threshold", 0.05)
+    d.aa_resampled_floor = r.get("AA_resampled_floor", 0.0)
+    d.aa_sample_multiplier_factor = r.get("AA_sample_multiplier_factor", 1.0)
+    d.aa_light_sample_multiplier_factor = r.get("AA_light_sample_multiplier_factor", 1.0)
+    d.aa_indirect_sample_multiplier_factor = r.get("AA_indirect_sample_multiplier_factor", 1.0)
+    d.aa_detect_color_noise = int(r.get("AA_detect_color_noise", False))
+    d.aa_dark_detection_type = {"none": 0, "linear": 1, "curve": 2}[r.get("AA_dark_detection_type", "none")]
+    d.aa_dark_threshold_factor = r.get("AA_dark_threshold_factor", 0.0)
+    d.aa_variance_edge_size = r.get("AA_variance_edge_size", 10)
+    d.aa_variance_pixels = r.get("AA_variance_pixels", 0)
+    d.aa_clamp_samples = r.get("AA_clamp_samples", 0.0)
     return d
 
 

@@ -1598,6 +1598,7 @@ typedef struct
 	int include_lights;
 	mwc_t *prng;
 	unsigned correlative_sample_number; /* integrator_tiled.h:91, per thread */
+	float light_mult;                   /* aa_light_sample_multiplier_ of the current pass (integrator_tiled.cc:139,215) */
 } rstate_t;
 
 /* MonteCarloIntegrator::doLightEstimation, integrator_montecarlo.cc:78-345 (render passes disabled,
@@ -1631,7 +1632,7 @@ static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *s
 	{	/* :149-342 */
 		halton_t hal_2, hal_3;
 		halton_init(&hal_2, 2); halton_init(&hal_3, 3);
-		int n = (int)ceilf((float)light->samples * st->rd->aa_light_sample_multiplier);
+		int n = (int)ceilf((float)light->samples * st->light_mult);
 		float inv_ns = 1.f / (float)n;
 		unsigned offs = (unsigned)n * st->pixel_sample + st->sampling_offs + l_offs;
 		rgb ccol = C(0, 0, 0);
@@ -1838,7 +1839,25 @@ typedef struct
 	float filterw, table_scale;
 	float table[FILTER_TABLE_SIZE * FILTER_TABLE_SIZE];
 	float *pix; /* h*w*5 */
+	float clamp_samples;              /* aa_clamp_samples_ */
+	const unsigned char *flags;       /* adaptive passes: doMoreSamples (imagefilm.cc:917-920), NULL = every pixel */
 } film_t;
+
+/* Rgb::clampProportionalRgb, color.h:412-445 */
+static void clamp_proportional_rgb(float c[3], float max_value)
+{
+	if(max_value > 0.f)
+	{
+		float max_rgb = fmaxf_(c[0], fmaxf_(c[1], c[2]));
+		float proportional_adjustment = max_value / max_rgb;
+		if(max_rgb > max_value)
+		{
+			if(c[0] >= max_rgb) { c[0] = max_value; c[1] *= proportional_adjustment; c[2] *= proportional_adjustment; }
+			else if(c[1] >= max_rgb) { c[1] = max_value; c[0] *= proportional_adjustment; c[2] *= proportional_adjustment; }
+			else { c[2] = max_value; c[0] *= proportional_adjustment; c[1] *= proportional_adjustment; }
+		}
+	}
+}
 
 static float filt_box(float dx, float dy) { (void)dx; (void)dy; return 1.f; }
 static float filt_mitchell(float dx, float dy) /* :85-97 */
@@ -1889,6 +1908,8 @@ static void film_init(film_t *f, const yor_render_desc *rd, float *pix)
 			*tp++ = ffunc((x + .5f) * scale, (y + .5f) * scale);
 	f->table_scale = (float)(0.9999 * FILTER_TABLE_SIZE / (double)f->filterw);
 	f->pix = pix;
+	f->clamp_samples = rd->aa_clamp_samples;
+	f->flags = NULL;
 }
 
 typedef struct { int x, y; float c[4]; float wt; } splat_t;
@@ -1897,9 +1918,11 @@ typedef struct { splat_t *v; size_t n, cap; } splat_list;
 /* addSample :925-1015, combined pass only, aa_clamp_samples_ = 0, premult false.
  * own_only != NULL: contributions to pixels other than (x,y) are deferred into the list (used by
  * the multi-threaded mode so that tiles never write each other's pixels concurrently). */
-static void film_add_sample(film_t *f, const float col[4], int x, int y, float dx, float dy, splat_list *deferred)
+static void film_add_sample(film_t *f, const float col_in[4], int x, int y, float dx, float dy, splat_list *deferred)
 {
 	int dx_0, dx_1, dy_0, dy_1, x_0, x_1, y_0, y_1;
+	float col[4] = {col_in[0], col_in[1], col_in[2], col_in[3]};
+	clamp_proportional_rgb(col, f->clamp_samples);            /* :975 (the same for every pixel of the footprint) */
 	dx_0 = round2int((double)dx - (double)f->filterw); if(f->cx0 - x > dx_0) dx_0 = f->cx0 - x;
 	dx_1 = round2int((double)dx + (double)f->filterw - 1.0); if(f->cx1 - x - 1 < dx_1) dx_1 = f->cx1 - x - 1;
 	dy_0 = round2int((double)dy - (double)f->filterw); if(f->cy0 - y > dy_0) dy_0 = f->cy0 - y;
@@ -1951,6 +1974,8 @@ typedef struct
 	int *next_tile;
 	counters_t cn; uint64_t camera_samples;
 	splat_list deferred;
+	/* the pass being rendered: renderPass(samples, offset, adaptive) (integrator_tiled.cc:261-307) */
+	int pass_samples, pass_offset, pass_adaptive; float light_mult;
 } worker_t;
 
 static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
@@ -1961,8 +1986,8 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 	int end_x = ax + rd->tile_size, end_y = ay + rd->tile_size;
 	if(end_x > rd->xstart + rd->width) end_x = rd->xstart + rd->width;
 	if(end_y > rd->ystart + rd->height) end_y = rd->ystart + rd->height;
-	int n_samples = rd->aa_minsamples;
-	int offset = (int)rd->base_sampling_offset; /* renderPass(samples, offset=0) + base offset, :203,263 */
+	int n_samples = wk->pass_samples;
+	int offset = wk->pass_offset + (int)rd->base_sampling_offset; /* renderPass(samples, offset) + base offset, :203,263 */
 	int x = cam->resx;
 	float dx = 0.5, dy = 0.5, d_1 = (float)(1.0 / (double)(float)n_samples);
 	float wt;
@@ -1975,11 +2000,17 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 	{
 		for(int j = ax; j < end_x; ++j)
 		{
+			if(wk->pass_adaptive && wk->film->flags && !wk->film->flags[(size_t)(i - rd->ystart) * (size_t)rd->width + (size_t)(j - rd->xstart)]) continue; /* :355 */
 			st->sampling_offs = yor_fnv32a((uint32_t)i * yor_fnv32a((uint32_t)j)); /* :379 */
 			for(int sample = 0; sample < n_samples; ++sample)
 			{
 				st->pixel_sample = (unsigned)(pass_offs + sample);
-				if(n_samples > 1)
+				if(rd->aa_passes > 1)
+				{	/* :394-398: scrambled van der Corput / Sobol for multi-pass AA */
+					dx = yor_ri_vdc(st->pixel_sample, st->sampling_offs);
+					dy = yor_ri_s(st->pixel_sample, st->sampling_offs);
+				}
+				else if(n_samples > 1)
 				{	/* :399-403 (aa_passes_ == 1) */
 					dx = (float)((0.5 + (double)(float)sample) * (double)d_1);
 					dy = yor_ri_lp((uint32_t)sample + st->sampling_offs, 0);
@@ -2006,6 +2037,7 @@ static void *worker_main(void *arg)
 	st.s = wk->s; st.rd = rd;
 	st.shadow_bias = rd->shadow_bias_auto ? (float)YAF_SHADOW_BIAS : rd->shadow_bias;   /* scene.cc:825 */
 	st.ray_min_dist = rd->min_raydist_auto ? (float)MIN_RAYDIST : rd->min_raydist;      /* scene.cc:826 */
+	st.light_mult = wk->light_mult;
 	int n_tiles = wk->n_tiles_x * wk->n_tiles_y;
 	int shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
 	if(wk->n_threads == 1)
@@ -2030,30 +2062,134 @@ static void *worker_main(void *arg)
 	return NULL;
 }
 
-int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_stats *stats)
+/* ImageFilm::darkThresholdCurveInterpolate, imagefilm.cc:1312-1328 */
+static float dark_threshold_curve(float b)
 {
-	if(rd->aa_passes != 1) return -1;
-	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
-	if(s->cam.aperture != 0.f) return -3;
-	for(int i = 0; i < s->n_mats; ++i)
-		if(s->mats[i].flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace not restated */
-	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
-	struct timespec t0, t1;
-	memset(film_out, 0, sizeof(float) * 5 * (size_t)rd->width * (size_t)rd->height);
-	film_t film;
-	film_init(&film, rd, film_out);
-	int ntx = (rd->width + rd->tile_size - 1) / rd->tile_size, nty = (rd->height + rd->tile_size - 1) / rd->tile_size;
-	int nthreads = rd->n_threads > 0 ? rd->n_threads : 1;
-	worker_t *wk = (worker_t *)calloc((size_t)nthreads, sizeof(worker_t));
-	pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+	if(b <= 0.10f) return 0.0001f;
+	else if(b > 0.10f && b <= 0.20f) return (0.0001f + (b - 0.10f) * (0.0010f - 0.0001f) / 0.10f);
+	else if(b > 0.20f && b <= 0.30f) return (0.0010f + (b - 0.20f) * (0.0020f - 0.0010f) / 0.10f);
+	else if(b > 0.30f && b <= 0.40f) return (0.0020f + (b - 0.30f) * (0.0035f - 0.0020f) / 0.10f);
+	else if(b > 0.40f && b <= 0.50f) return (0.0035f + (b - 0.40f) * (0.0055f - 0.0035f) / 0.10f);
+	else if(b > 0.50f && b <= 0.60f) return (0.0055f + (b - 0.50f) * (0.0075f - 0.0055f) / 0.10f);
+	else if(b > 0.60f && b <= 0.70f) return (0.0075f + (b - 0.60f) * (0.0100f - 0.0075f) / 0.10f);
+	else if(b > 0.70f && b <= 0.80f) return (0.0100f + (b - 0.70f) * (0.0150f - 0.0100f) / 0.10f);
+	else if(b > 0.80f && b <= 0.90f) return (0.0150f + (b - 0.80f) * (0.0250f - 0.0150f) / 0.10f);
+	else if(b > 0.90f && b <= 1.00f) return (0.0250f + (b - 0.90f) * (0.0400f - 0.0250f) / 0.10f);
+	else if(b > 1.00f && b <= 1.20f) return (0.0400f + (b - 1.00f) * (0.0800f - 0.0400f) / 0.20f);
+	else if(b > 1.20f && b <= 1.40f) return (0.0800f + (b - 1.20f) * (0.0950f - 0.0800f) / 0.20f);
+	else if(b > 1.40f && b <= 1.80f) return (0.0950f + (b - 1.40f) * (0.1000f - 0.0950f) / 0.40f);
+	else return 0.1000f;
+}
+
+/* Pixel::normalized (util_image_buffers.h:39-43) with Rgba / float (color.h:310-314: multiply by the rounded reciprocal) */
+static void pixel_normalized(const float *p, float out[4])
+{
+	float w = p[4];
+	if(w != 0.f) { float f = (float)(1.0 / (double)w); out[0] = p[0] * f; out[1] = p[1] * f; out[2] = p[2] * f; out[3] = p[3] * f; }
+	else { out[0] = out[1] = out[2] = out[3] = 0.f; }
+}
+/* Rgba::colorDifference, color.h:447-464 */
+static float color_difference(const float a[4], const float b[4], int use_rgb)
+{
+	float bri_a = 0.2126f * a[0] + 0.7152f * a[1] + 0.0722f * a[2];
+	float bri_b = 0.2126f * b[0] + 0.7152f * b[1] + 0.0722f * b[2];
+	float d = fabsf(bri_b - bri_a);
+	if(use_rgb)
+	{
+		float rd = fabsf(b[0] - a[0]), gd = fabsf(b[1] - a[1]), bd = fabsf(b[2] - a[2]), ad = fabsf(b[3] - a[3]);
+		if(d < rd) d = rd;
+		if(d < gd) d = gd;
+		if(d < bd) d = bd;
+		if(d < ad) d = ad;
+	}
+	return d;
+}
+
+/* ImageFilm::nextPass, imagefilm.cc:270-480: which pixels get more samples.  Returns their number.
+ * (no sampling-factor pass, not interactive) */
+static int film_next_pass(const film_t *f, const yor_render_desc *rd, float aa_thesh, unsigned char *flags)
+{
+	const int w = f->w, h = f->h;
+	memset(flags, 0, (size_t)w * (size_t)h);
+	if(!(aa_thesh > 0.f)) { memset(flags, 1, (size_t)w * (size_t)h); return h * w; }   /* :319,460; doMoreSamples :919 */
+	const int variance_half_edge = rd->aa_variance_edge_size / 2;
+	float aa_thresh_scaled = aa_thesh;
+#define PIX(x, y) (f->pix + 5 * ((size_t)(y) * (size_t)w + (size_t)(x)))
+#define SET(x, y) flags[(size_t)(y) * (size_t)w + (size_t)(x)] = 1
+	for(int y = 0; y < h - 1; ++y)
+	{
+		for(int x = 0; x < w - 1; ++x)
+		{
+			if(PIX(x, y)[4] <= 0.f) SET(x, y);                                              /* :335 */
+			float pix_col[4], other[4];
+			pixel_normalized(PIX(x, y), pix_col);
+			float pix_col_bri = 0.2126f * fabsf(pix_col[0]) + 0.7152f * fabsf(pix_col[1]) + 0.0722f * fabsf(pix_col[2]);
+			if(rd->aa_dark_detection_type == 1 && rd->aa_dark_threshold_factor > 0.f)
+				aa_thresh_scaled = aa_thesh * ((1.f - rd->aa_dark_threshold_factor) + (pix_col_bri * rd->aa_dark_threshold_factor));
+			else if(rd->aa_dark_detection_type == 2) aa_thresh_scaled = dark_threshold_curve(pix_col_bri);
+			pixel_normalized(PIX(x + 1, y), other);
+			if(color_difference(pix_col, other, rd->aa_detect_color_noise) >= aa_thresh_scaled) { SET(x, y); SET(x + 1, y); }
+			pixel_normalized(PIX(x, y + 1), other);
+			if(color_difference(pix_col, other, rd->aa_detect_color_noise) >= aa_thresh_scaled) { SET(x, y); SET(x, y + 1); }
+			pixel_normalized(PIX(x + 1, y + 1), other);
+			if(color_difference(pix_col, other, rd->aa_detect_color_noise) >= aa_thresh_scaled) { SET(x, y); SET(x + 1, y + 1); }
+			if(x > 0)
+			{
+				pixel_normalized(PIX(x - 1, y + 1), other);
+				if(color_difference(pix_col, other, rd->aa_detect_color_noise) >= aa_thresh_scaled) { SET(x, y); SET(x - 1, y + 1); }
+			}
+			if(rd->aa_variance_pixels > 0)
+			{
+				int variance_x = 0, variance_y = 0;
+				for(int xd = -variance_half_edge; xd < variance_half_edge - 1; ++xd)
+				{
+					int xi = x + xd;
+					if(xi < 0) xi = 0; else if(xi >= w - 1) xi = w - 2;
+					float c0[4], c1[4];
+					pixel_normalized(PIX(xi, y), c0); pixel_normalized(PIX(xi + 1, y), c1);
+					if(color_difference(c0, c1, rd->aa_detect_color_noise) >= aa_thresh_scaled) ++variance_x;
+				}
+				for(int yd = -variance_half_edge; yd < variance_half_edge - 1; ++yd)
+				{
+					int yi = y + yd;
+					if(yi < 0) yi = 0; else if(yi >= h - 1) yi = h - 2;
+					float c0[4], c1[4];
+					pixel_normalized(PIX(x, yi), c0); pixel_normalized(PIX(x, yi + 1), c1);
+					if(color_difference(c0, c1, rd->aa_detect_color_noise) >= aa_thresh_scaled) ++variance_y;
+				}
+				if(variance_x + variance_y >= rd->aa_variance_pixels)
+				{
+					for(int xd = -variance_half_edge; xd < variance_half_edge; ++xd)
+						for(int yd = -variance_half_edge; yd < variance_half_edge; ++yd)
+						{
+							int xi = x + xd; if(xi < 0) xi = 0; else if(xi >= w) xi = w - 1;
+							int yi = y + yd; if(yi < 0) yi = 0; else if(yi >= h) yi = h - 1;
+							SET(xi, yi);
+						}
+				}
+			}
+		}
+	}
+#undef PIX
+#undef SET
+	int n = 0;
+	for(size_t i = 0; i < (size_t)w * (size_t)h; ++i) n += flags[i];
+	return n;
+}
+
+/* one renderPass (integrator_tiled.cc:261-307): all tiles, then the deferred cross-pixel splats */
+static void run_pass(yor_scene *s, const yor_render_desc *rd, film_t *film, worker_t *wk, pthread_t *th, int nthreads,
+                     int samples, int offset, int adaptive, float light_mult)
+{
 	int next_tile = 0;
-	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for(int i = 0; i < nthreads; ++i)
 	{
 		wk[i].next_tile = &next_tile;
-		wk[i].s = s; wk[i].rd = rd; wk[i].film = &film; wk[i].n_tiles_x = ntx; wk[i].n_tiles_y = nty;
-		wk[i].thread_id = i; wk[i].n_threads = nthreads;
+		wk[i].pass_samples = samples; wk[i].pass_offset = offset; wk[i].pass_adaptive = adaptive; wk[i].light_mult = light_mult;
+		wk[i].deferred.v = NULL; wk[i].deferred.n = 0; wk[i].deferred.cap = 0;
+		memset(&wk[i].cn, 0, sizeof wk[i].cn);
 	}
+	(void)s;
 	if(nthreads == 1) worker_main(&wk[0]);
 	else
 	{
@@ -2066,23 +2202,90 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 			for(size_t k = 0; k < wk[i].deferred.n; ++k)
 			{
 				splat_t *sp = &wk[i].deferred.v[k];
-				float *p = film.pix + 5 * ((size_t)(sp->y - film.cy0) * (size_t)film.w + (size_t)(sp->x - film.cx0));
+				float *p = film->pix + 5 * ((size_t)(sp->y - film->cy0) * (size_t)film->w + (size_t)(sp->x - film->cx0));
 				p[0] += sp->c[0] * sp->wt; p[1] += sp->c[1] * sp->wt; p[2] += sp->c[2] * sp->wt; p[3] += sp->c[3] * sp->wt;
 				p[4] += sp->wt;
 			}
 			free(wk[i].deferred.v);
+			wk[i].deferred.v = NULL;
 		}
 	}
+	(void)rd;
+}
+
+int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_stats *stats)
+{
+	if(rd->aa_passes < 1) return -1;
+	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
+	if(s->cam.aperture != 0.f) return -3;
+	for(int i = 0; i < s->n_mats; ++i)
+		if(s->mats[i].flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace not restated */
+	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
+	if(rd->aa_passes > 1 && rd->shard_count > 1) return -6; /* the noise detection needs the whole frame */
+	struct timespec t0, t1;
+	memset(film_out, 0, sizeof(float) * 5 * (size_t)rd->width * (size_t)rd->height);
+	film_t film;
+	film_init(&film, rd, film_out);
+	int ntx = (rd->width + rd->tile_size - 1) / rd->tile_size, nty = (rd->height + rd->tile_size - 1) / rd->tile_size;
+	int nthreads = rd->n_threads > 0 ? rd->n_threads : 1;
+	worker_t *wk = (worker_t *)calloc((size_t)nthreads, sizeof(worker_t));
+	pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+	counters_t total; memset(&total, 0, sizeof total);
+	uint64_t camera_samples = 0;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for(int i = 0; i < nthreads; ++i)
+	{
+		wk[i].s = s; wk[i].rd = rd; wk[i].film = &film; wk[i].n_tiles_x = ntx; wk[i].n_tiles_y = nty;
+		wk[i].thread_id = i; wk[i].n_threads = nthreads;
+	}
+#define TALLY() do { for(int i = 0; i < nthreads; ++i) { total.rays_closest += wk[i].cn.rays_closest; total.rays_shadow += wk[i].cn.rays_shadow; \
+	total.interior += wk[i].cn.interior; total.leaves += wk[i].cn.leaves; total.tests += wk[i].cn.tests; camera_samples += wk[i].camera_samples; wk[i].camera_samples = 0; } } while(0)
+	/* TiledIntegrator::render, integrator_tiled.cc:116-258 */
+	const int aa_samples = rd->aa_minsamples > 1 ? rd->aa_minsamples : 1;
+	const int aa_inc_samples = rd->aa_inc_samples > 0 ? rd->aa_inc_samples : aa_samples;            /* scene.cc:765 */
+	float aa_threshold = rd->aa_threshold;
+	float aa_sample_multiplier = 1.f, aa_light_sample_multiplier = 1.f;
+	const int aa_resampled_floor_pixels = (int)floorf(rd->aa_resampled_floor * (float)(rd->width * rd->height) / 100.f);
+	run_pass(s, rd, &film, wk, th, nthreads, aa_samples, 0, 0, rd->aa_passes > 1 ? aa_light_sample_multiplier : rd->aa_light_sample_multiplier);
+	TALLY();
+	unsigned char *flags = NULL;
+	if(rd->aa_passes > 1) flags = (unsigned char *)malloc((size_t)rd->width * (size_t)rd->height);
+	int acum_aa_samples = aa_samples;
+	int aa_threshold_changed = 1, resampled_pixels = 0;
+	for(int i = 1; i < rd->aa_passes; ++i)
+	{
+		aa_sample_multiplier *= rd->aa_sample_multiplier_factor;
+		aa_light_sample_multiplier *= rd->aa_light_sample_multiplier_factor;
+		if(resampled_pixels <= 0 && !aa_threshold_changed) { /* :222-226: pass skipped */ }
+		else
+		{
+			resampled_pixels = film_next_pass(&film, rd, aa_threshold, flags);
+			aa_threshold_changed = 0;
+		}
+		int aa_samples_mult = (int)ceilf((float)aa_inc_samples * aa_sample_multiplier);
+		if(resampled_pixels > 0)
+		{
+			film.flags = (aa_threshold > 0.f) ? flags : NULL;
+			run_pass(s, rd, &film, wk, th, nthreads, aa_samples_mult, acum_aa_samples, 1, aa_light_sample_multiplier);
+			TALLY();
+		}
+		acum_aa_samples += aa_samples_mult;
+		if(resampled_pixels < aa_resampled_floor_pixels)
+		{
+			float aa_variation_ratio = fminf_(8.f, ((float)aa_resampled_floor_pixels / (float)resampled_pixels));
+			aa_threshold *= (1.f - 0.1f * aa_variation_ratio);
+			if(aa_threshold > 0.f) aa_threshold_changed = 1;
+		}
+	}
+#undef TALLY
+	free(flags);
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	if(stats)
 	{
 		memset(stats, 0, sizeof *stats);
-		for(int i = 0; i < nthreads; ++i)
-		{
-			stats->rays_closest += wk[i].cn.rays_closest; stats->rays_shadow += wk[i].cn.rays_shadow;
-			stats->interior_steps += wk[i].cn.interior; stats->leaves += wk[i].cn.leaves; stats->tri_tests += wk[i].cn.tests;
-			stats->camera_samples += wk[i].camera_samples;
-		}
+		stats->rays_closest = total.rays_closest; stats->rays_shadow = total.rays_shadow;
+		stats->interior_steps = total.interior; stats->leaves = total.leaves; stats->tri_tests = total.tests;
+		stats->camera_samples = camera_samples;
 		stats->kd_nodes = s->n_nodes; stats->kd_leaf_refs = s->n_refs;
 		stats->build_seconds = s->build_seconds;
 		stats->render_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);

@@ -100,7 +100,7 @@ typedef struct yor_render_desc
 	int32_t bg_transp;
 	int32_t bg_transp_refract;
 	int32_t width, height, xstart, ystart;
-	int32_t aa_passes;         /* only 1 is supported */
+	int32_t aa_passes;         /* > 1: the adaptive multi-pass schedule of TiledIntegrator::render (fields at the end) */
 	int32_t aa_minsamples;
 	float aa_pixelwidth;
 	int32_t filter_type;
@@ -117,6 +117,16 @@ typedef struct yor_render_desc
 	int32_t n_threads;         /* oracle worker threads (1 = reference's single-thread linear order) */
 	/* tile subset for sharded renders: tile t is rendered iff (t % shard_count) == shard_index */
 	int32_t shard_index, shard_count;
+	/* multi-pass anti-aliasing (Scene::setAntialiasing, scene.cc:761-778; defaults environment.cc:682-695) */
+	int32_t aa_inc_samples;            /* <= 0: aa_minsamples */
+	float aa_threshold;                /* 0: every pixel is resampled in every pass (imagefilm.cc:319,460) */
+	float aa_resampled_floor;          /* percent of the image */
+	float aa_sample_multiplier_factor, aa_light_sample_multiplier_factor, aa_indirect_sample_multiplier_factor;
+	int32_t aa_detect_color_noise;
+	int32_t aa_dark_detection_type;    /* 0 none, 1 linear, 2 curve */
+	float aa_dark_threshold_factor;
+	int32_t aa_variance_edge_size, aa_variance_pixels;
+	float aa_clamp_samples;            /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975) */
 } yor_render_desc;
 
 typedef struct yor_stats

@@ -69,8 +69,8 @@ def test_fastmath_and_qmc(gold, probe_scene):
     ab = np.stack([u2f(g["fm_pow_a"]), u2f(g["fm_pow_b"])], axis=1)
     exact(yi.probe(2, ab, 1)[:, 0], g["fm_pow"], "fPow__")
     br = np.stack([u2f(g["q_bits"]), u2f(g["q_r"])], axis=1)
-    o = yi.probe(3, br, 3)
-    exact(o[:, 0], g["q_vdc"], "riVdC__"); exact(o[:, 1], g["q_rilp"], "riLp__")
+    o = yi.probe(3, br, 4)
+    exact(o[:, 0], g["q_vdc"], "riVdC__"); exact(o[:, 1], g["q_rilp"], "riLp__"); exact(o[:, 3], g["q_ris"], "riS__")
     assert np.array_equal(o[:, 2].view(np.uint32), g["q_fnv"].astype(np.uint32))
     dn = np.stack([u2f(g["sh_dim"]), u2f(g["sh_n"])], axis=1)
     o = yi.probe(4, dn, 3)

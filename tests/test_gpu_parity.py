@@ -287,3 +287,38 @@ def test_full_size_c4_one_light_against_oracle_windows(pipeline):
     if pipeline == "megakernel":
         pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
     _full_size_against_crops("c4", [(300, 800), (640, 400)], 16, lights=1)
+
+
+# ---- multi-pass anti-aliasing: TiledIntegrator::render's pass schedule + ImageFilm::nextPass ----------------
+@pytest.mark.parametrize("aa", [
+    dict(AA_passes=3, AA_inc_samples=3, AA_threshold=0.0),                                    # every pixel, every pass
+    dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02),                                   # adaptive
+    dict(AA_passes=4, AA_inc_samples=2, AA_threshold=0.01, AA_sample_multiplier_factor=1.5,
+         AA_light_sample_multiplier_factor=2.0, AA_detect_color_noise=True, AA_dark_detection_type="linear",
+         AA_dark_threshold_factor=0.5, AA_variance_edge_size=6, AA_variance_pixels=3, AA_resampled_floor=60.0),
+    dict(AA_passes=2, AA_inc_samples=4, AA_threshold=0.005, AA_dark_detection_type="curve", AA_clamp_samples=0.6),
+])
+def test_multi_pass_anti_aliasing(aa, pipeline):
+    """integrator_tiled.cc:116-258 (pass schedule, sample / light multipliers, threshold decay under the resampled
+    floor), :394-398 (riVdC / riS sub-pixel positions), imagefilm.cc:270-480 (noise detection), :975 (sample clamp).
+    The set of resampled pixels shows in the film weights, which must match the oracle's exactly."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline renders single-pass films only")
+    from libyafaray_amd import interface
+    sc = scenes.cornell_soup(700, seed=21, res=(56, 44))
+    rd = scenes.render_settings(56, 44, 3, bounces=2, background=(0.05, 0.1, 0.2), **aa)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(56, 44), yi.getRenderStats()
+    # riVdC(1, r) == riS(1, r): sample 1 of every pixel sits on the pixel's diagonal, and in this symmetric box such a
+    # camera ray can run exactly into the edge two walls share — an exact tie in t between two triangles of different
+    # materials, which TriKdTree::intersect resolves by visiting order (kdtree_triangle.cc:782), i.e. by tree
+    # topology.  The oracle therefore walks the same tree as the device here; everywhere else it builds its own.
+    osc = po.OracleScene(sc)
+    osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4)[:3])
+    ofilm, ost = osc.render(rd)
+    assert st.camera_samples == ost.camera_samples
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    assert film[..., 4].min() >= 3 and len(np.unique(np.round(film[..., 4]))) >= (1 if aa["AA_threshold"] == 0.0 else 2)
+    compare_films(film, ofilm, f"multi-pass {aa}")

@@ -76,6 +76,13 @@ typedef struct yafgpu_camera
 	float position[3], vto[3], vup[3], vright[3];
 	float near_p[3], near_n[3], far_p[3], far_n[3];
 	int32_t resx, resy;
+	/* depth of field (camera_perspective.cc:33-54,60-74): aperture 0 = pinhole */
+	float aperture, dof_distance;
+	int32_t bokeh_type;            /* BokehType: 0 disk1, 1 disk2, 3 triangle, 4 square, 5 pentagon, 6 hexagon, 7 ring */
+	int32_t bokeh_bias;            /* 0 none, 1 center, 2 edge */
+	float bokeh_rotation;          /* degrees */
+	float dof_rt[3], dof_up[3];    /* aperture * cam_x, aperture * cam_y */
+	float ls[16];                  /* polygon corner table; filled by yafgpu_scene_create from bokeh_type / bokeh_rotation */
 } yafgpu_camera;
 
 typedef struct yafgpu_scene_desc

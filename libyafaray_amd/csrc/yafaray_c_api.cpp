@@ -272,7 +272,9 @@ bool make_camera(yafaray_interface *yi, const ParamMap &p, yafgpu_camera &c)
 	int resx = 320, resy = 200; float aspect = 1, dfocal = 1, apt = 0, near_clip = 0.f, far_clip = -1.f;
 	p.getPoint("from", from); p.getPoint("to", to); p.getPoint("up", up); p.get("resx", resx); p.get("resy", resy);
 	p.get("focal", dfocal); p.get("aperture", apt); p.get("aspect_ratio", aspect); p.get("nearClip", near_clip); p.get("farClip", far_clip);
-	if(apt != 0.f) return fail(yi, "perspective camera: depth of field (aperture != 0) is not supported by the GPU path");
+	float dofd = 0.f, bkhrot = 0.f; std::string bkhtype = "disk1", bkhbias = "uniform";
+	p.get("dof_distance", dofd); p.get("bokeh_type", bkhtype); p.get("bokeh_bias", bkhbias); p.get("bokeh_rotation", bkhrot);
+	(void)yi;
 	const float aspect_ratio = aspect * (float)resy / (float)resx;
 	float cy[3], cz[3], cx[3];
 	for(int k = 0; k < 3; ++k) { cy[k] = up[k] - from[k]; cz[k] = to[k] - from[k]; }
@@ -290,7 +292,12 @@ bool make_camera(yafaray_interface *yi, const ParamMap &p, yafgpu_camera &c)
 		c.vto[k] = (dfocal * cz[k]) - 0.5f * (vup + vright);
 		c.vup[k] = vup / (float)resy;
 		c.vright[k] = vright / (float)resx;
+		c.dof_rt[k] = apt * cx[k]; c.dof_up[k] = apt * cy[k];         // setAxis, :66-67
 	}
+	c.aperture = apt; c.dof_distance = dofd; c.bokeh_rotation = bkhrot;
+	c.bokeh_type = bkhtype == "disk2" ? 1 : bkhtype == "triangle" ? 3 : bkhtype == "square" ? 4 : bkhtype == "pentagon" ? 5
+	             : bkhtype == "hexagon" ? 6 : bkhtype == "ring" ? 7 : 0;
+	c.bokeh_bias = bkhbias == "center" ? 1 : bkhbias == "edge" ? 2 : 0;
 	return true;
 }
 

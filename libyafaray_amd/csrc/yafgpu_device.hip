@@ -853,7 +853,8 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 		case 7:
 		{
 			V3 f, d; float t0, t1;
-			camera_shoot(sc.cam, x[0], x[1], f, d, t0, t1);
+			if(n_in >= 4) camera_shoot(sc.cam, x[0], x[1], x[2], x[3], f, d, t0, t1);
+			else camera_shoot(sc.cam, x[0], x[1], f, d, t0, t1);
 			o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = t0; o[7] = t1; o[8] = 1.f;
 			break;
 		}
@@ -913,6 +914,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 // host side of the narrow ABI
 using namespace yafgpu;
 
+static float host_fsin(float x);
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return fail(-100, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
@@ -1095,6 +1097,22 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	dv.n_lights = d->n_lights; dv.n_tris = d->n_tris; dv.n_nodes = (uint32_t)s->tree.nodes.size();
 	for(int k = 0; k < 3; ++k) { dv.blo[k] = s->tree.bound_lo[k]; dv.bhi[k] = s->tree.bound_hi[k]; }
 	dv.cam = d->camera;
+	{	// PerspectiveCamera ctor, camera_perspective.cc:42-54: corner table of the polygonal bokeh shapes
+		for(float &v : dv.cam.ls) v = 0.f;
+		int ns = dv.cam.bokeh_type;
+		if(ns >= 3 && ns <= 6)
+		{
+			float w = (float)((double)dv.cam.bokeh_rotation * 0.01745329251994329576922);
+			const float wi = (float)(6.28318530717958647692 / (double)(float)ns);
+			ns = (ns + 2) * 2;
+			for(int i = 0; i < ns; i += 2)
+			{
+				dv.cam.ls[i] = host_fsin(w + (float)1.57079632679489661923);     // fCos__
+				dv.cam.ls[i + 1] = host_fsin(w);
+				w += wi;
+			}
+		}
+	}
 	s->mats.assign(d->materials, d->materials + d->n_materials);
 	s->n_lights = d->n_lights;
 	s->h_lights.assign(d->lights, d->lights + d->n_lights);
@@ -1433,6 +1451,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		const bool mega = pl && std::strcmp(pl, "megakernel") == 0;
 		if(!mega) return render_wavefront(s, ra, stream, stats);
 		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
+		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)
 			return fail(-15, "the one-kernel pipeline renders single-pass films only; use the wavefront pipeline");
 	}

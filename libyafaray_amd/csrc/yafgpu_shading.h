@@ -466,13 +466,82 @@ YG_DEV bool pointlight_illuminate(const yafgpu_light &l, V3 sp_p, Col &col, V3 &
 	return true;
 }
 
-// PerspectiveCamera::shootRay (aperture 0), camera_perspective.cc:133-156; rayPlaneIntersection__ util_geometry.h:34-37
-YG_DEV void camera_shoot(const yafgpu_camera &c, float px, float py, V3 &from, V3 &dir, float &tmin, float &tmax)
+// PerspectiveCamera::biasDist, camera_perspective.cc:75-89
+YG_DEV float camera_bias_dist(const yafgpu_camera &c, float r)
+{
+	if(c.bokeh_bias == 1) return f_sqrt(f_sqrt(r) * r);
+	if(c.bokeh_bias == 2) return f_sqrt(1.0f - r * r);
+	return f_sqrt(r);
+}
+// shirleyDisk__, vector.cc:155-190 (the angle is formed in double and narrowed)
+YG_DEV void shirley_disk(float r_1, float r_2, float &u, float &v)
+{
+	constexpr double kPi4 = 0.78539816339744830962;
+	float phi = 0.f, r = 0.f;
+	const float a = 2.f * r_1 - 1.f, b = 2.f * r_2 - 1.f;
+	if(a > -b)
+	{
+		if(a > b) { r = a; phi = (float)(kPi4 * (double)(b / a)); }
+		else { r = b; phi = (float)(kPi4 * (double)(2.f - a / b)); }
+	}
+	else
+	{
+		if(a < b) { r = -a; phi = (float)(kPi4 * (double)(4.f + b / a)); }
+		else
+		{
+			r = -b;
+			phi = (b != 0.f) ? (float)(kPi4 * (double)(6.f - a / b)) : 0.f;
+		}
+	}
+	u = r * f_cos(phi);
+	v = r * f_sin(phi);
+}
+// PerspectiveCamera::getLensUv / sampleTsd, camera_perspective.cc:91-131
+YG_DEV void camera_lens_uv(const yafgpu_camera &c, float r_1, float r_2, float &u, float &v)
+{
+	const int bt = c.bokeh_type;
+	if(bt >= 3 && bt <= 6)
+	{
+		const float fn = (float)bt;
+		int idx = (int)(r_1 * fn);
+		r_1 = (r_1 - ((float)idx) / fn) * fn;
+		r_1 = camera_bias_dist(c, r_1);
+		const float b_1 = r_1 * r_2;
+		const float b_0 = r_1 - b_1;
+		idx <<= 1;
+		u = c.ls[idx] * b_0 + c.ls[idx + 2] * b_1;
+		v = c.ls[idx + 1] * b_0 + c.ls[idx + 3] * b_1;
+	}
+	else if(bt == 1 || bt == 7)
+	{
+		const float w = (float)6.28318530717958647692 * r_2;
+		if(bt == 7) r_1 = f_sqrt((float)0.707106781 + (float)0.292893218);
+		else r_1 = camera_bias_dist(c, r_1);
+		u = r_1 * f_cos(w);
+		v = r_1 * f_sin(w);
+	}
+	else shirley_disk(r_1, r_2, u, v);
+}
+
+// PerspectiveCamera::shootRay, camera_perspective.cc:133-156; rayPlaneIntersection__ util_geometry.h:34-37
+YG_DEV void camera_shoot(const yafgpu_camera &c, float px, float py, float lu, float lv, V3 &from, V3 &dir, float &tmin, float &tmax)
 {
 	from = vec3(c.position);
 	dir = normalize(vec3(c.vright) * px + vec3(c.vup) * py + vec3(c.vto));
 	tmin = dot(vec3(c.near_n), vec3(c.near_p) - from) / dot(dir, vec3(c.near_n));
 	tmax = dot(vec3(c.far_n), vec3(c.far_p) - from) / dot(dir, vec3(c.far_n));
+	if(c.aperture != 0.f)
+	{
+		float u, v;
+		camera_lens_uv(c, lu, lv, u, v);
+		const V3 li = vec3(c.dof_rt) * u + vec3(c.dof_up) * v;
+		from = from + li;
+		dir = normalize(dir * c.dof_distance - li);
+	}
+}
+YG_DEV void camera_shoot(const yafgpu_camera &c, float px, float py, V3 &from, V3 &dir, float &tmin, float &tmax)
+{
+	camera_shoot(c, px, py, 0.5f, 0.5f, from, dir, tmin, tmax);
 }
 
 } // namespace yafgpu

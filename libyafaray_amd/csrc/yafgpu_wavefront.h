@@ -639,7 +639,17 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 		float dx, dy;
 		wf_sample_offsets(a, sample, sampling_offs, dx, dy);
 		V3 from, dir; float tmin, tmax;
-		camera_shoot(a.ra.sc.cam, (float)px + dx, (float)py + dy, from, dir, tmin, tmax);
+		float lens_u = 0.5f, lens_v = 0.5f;
+		if(a.ra.sc.cam.aperture != 0.f)
+		{	// integrator_tiled.cc:382-383,405-409: Halton(3) / Halton(5) started at pass_offs + sampling_offs per pixel and
+			// advanced once per sample; the incremental sequence is replayed up to this sample (its roundings are its own)
+			Halton hal_u, hal_v;
+			hal_u.init(3u); hal_v.init(5u);
+			const uint32_t start = a.ra.rp.base_sampling_offset + a.ra.rp.pass_offset + sampling_offs;
+			hal_u.set_start(start); hal_v.set_start(start);
+			for(int k = 0; k <= sample; ++k) { lens_u = hal_u.next(); lens_v = hal_v.next(); }
+		}
+		camera_shoot(a.ra.sc.cam, (float)px + dx, (float)py + dy, lens_u, lens_v, from, dir, tmin, tmax);
 		float4 *b = a.state + slot; const size_t c = a.cap;
 		b[0 * c] = f4(from, tmin);
 		b[1 * c] = f4(dir, tmax);

@@ -47,6 +47,7 @@ class CameraDesc(C.Structure):
         ("from_", f3), ("to", f3), ("up", f3), ("resx", C.c_int32), ("resy", C.c_int32),
         ("focal", C.c_float), ("aspect_ratio", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
         ("aperture", C.c_float), ("pad0", C.c_float),
+        ("dof_distance", C.c_float), ("bokeh_type", C.c_int32), ("bokeh_bias", C.c_int32), ("bokeh_rotation", C.c_float),
     ]
 
 
@@ -129,6 +130,7 @@ def lib():
     L.yor_bound_cross.restype = C.c_int
     L.yor_bound_cross.argtypes = [fp, fp, fp, fp, C.c_float, fp, fp]
     L.yor_camera_shoot.argtypes = [C.POINTER(CameraDesc), C.c_float, C.c_float, fp]
+    L.yor_camera_shoot_lens.argtypes = [C.POINTER(CameraDesc), C.c_float, C.c_float, C.c_float, C.c_float, fp]
     L.yor_arealight_illum_sample.restype = C.c_int
     L.yor_arealight_illum_sample.argtypes = [C.POINTER(LightDesc), fp, C.c_float, C.c_float, fp]
     L.yor_arealight_intersect.restype = C.c_int
@@ -210,6 +212,9 @@ def light_desc(l):
     return d
 
 
+BOKEH_TYPES = {"disk1": 0, "disk2": 1, "triangle": 3, "square": 4, "pentagon": 5, "hexagon": 6, "ring": 7}   # BokehType
+
+
 def camera_desc(c):
     d = CameraDesc()
     d.from_ = f3(*c.get("from", (0, 1, 0)))
@@ -222,6 +227,10 @@ def camera_desc(c):
     d.near_clip = c.get("nearClip", 0.0)
     d.far_clip = c.get("farClip", -1.0)
     d.aperture = c.get("aperture", 0.0)
+    d.dof_distance = c.get("dof_distance", 0.0)
+    d.bokeh_type = BOKEH_TYPES[c.get("bokeh_type", "disk1")]
+    d.bokeh_bias = {"uniform": 0, "center": 1, "edge": 2}.get(c.get("bokeh_bias", "uniform"), 0)
+    d.bokeh_rotation = c.get("bokeh_rotation", 0.0)
     return d
 
 

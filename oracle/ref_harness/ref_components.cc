@@ -284,6 +284,43 @@ static void sec_camera(Json &j)
 	j.arr_u32("cam_cfg12", cam_in); j.arr_u32("cam_pxy", pxy); j.arr_u32("cam_ray9", out);
 }
 
+// depth of field: lens sampling for every bokeh shape and bias (camera_perspective.cc:75-156)
+static void sec_camera_dof(Json &j)
+{
+	std::vector<uint32_t> cfg, in4, out;
+	const char *types[7] = {"disk1", "disk2", "triangle", "square", "pentagon", "hexagon", "ring"};
+	const char *biases[3] = {"uniform", "center", "edge"};
+	for(int t = 0; t < 7; ++t)
+		for(int b = 0; b < 3; ++b)
+		{
+			ParamMap pm;
+			Point3 from(0.3f, -4.f, 1.f), to(0.f, 0.1f, 0.2f), up(0.3f, -4.f, 2.f);
+			int resx = 320, resy = 200;
+			float focal = 1.1f, apt = 0.05f + 0.01f * t, dofd = 3.5f + 0.25f * b, rot = 10.f * t + 3.f * b;
+			pm["from"] = Parameter(from); pm["to"] = Parameter(to); pm["up"] = Parameter(up);
+			pm["resx"] = Parameter(resx); pm["resy"] = Parameter(resy); pm["focal"] = Parameter(focal);
+			pm["aperture"] = Parameter(apt); pm["dof_distance"] = Parameter(dofd);
+			pm["bokeh_type"] = Parameter(std::string(types[t])); pm["bokeh_bias"] = Parameter(std::string(biases[b]));
+			pm["bokeh_rotation"] = Parameter(rot);
+			Camera *cam = PerspectiveCamera::factory(pm, fake_env());
+			pushp(cfg, from); pushp(cfg, to); pushp(cfg, up);
+			cfg.push_back((uint32_t)resx); cfg.push_back((uint32_t)resy); cfg.push_back(f2u(focal));
+			cfg.push_back(f2u(apt)); cfg.push_back(f2u(dofd)); cfg.push_back((uint32_t)t); cfg.push_back((uint32_t)b); cfg.push_back(f2u(rot));
+			for(int k = 0; k < 40; ++k)
+			{
+				float px = urand() * resx, py = urand() * resy, lu = urand(), lv = urand();
+				if(k == 0) { lu = 0.5f; lv = 0.5f; }
+				if(k == 1) { lu = 0.f; lv = 0.f; }
+				if(k == 2) { lu = 0.999999f; lv = 0.25f; }
+				float wt;
+				Ray r = cam->shootRay(px, py, lu, lv, wt);
+				in4.push_back(f2u(px)); in4.push_back(f2u(py)); in4.push_back(f2u(lu)); in4.push_back(f2u(lv));
+				pushp(out, r.from_); pushv(out, r.dir_); out.push_back(f2u(r.tmin_)); out.push_back(f2u(r.tmax_)); out.push_back(f2u(wt));
+			}
+		}
+	j.arr_u32("camd_cfg17", cfg); j.arr_u32("camd_in4", in4); j.arr_u32("camd_ray9", out);
+}
+
 static void sec_lights(Json &j)
 {
 	// one area light, many surface points
@@ -472,6 +509,7 @@ int main()
 	sec_qmc(j);
 	sec_geom(j);
 	sec_camera(j);
+	sec_camera_dof(j);
 	sec_lights(j);
 	sec_materials(j);
 	j.s += "\n}\n";

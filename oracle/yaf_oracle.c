@@ -20,6 +20,7 @@
 /* ------------------------------------------------------------------ constants */
 #define Y_M_PI     3.14159265358979323846
 #define Y_M_PI_2   1.57079632679489661923
+#define Y_M_PI_4   0.78539816339744830962
 #define Y_M_1_PI   0.31830988618379067154
 #define Y_M_2PI    6.28318530717958647692  /* util_math_optimizations.h:84 */
 #define Y_M_1_2PI  0.15915494309189533577  /* :86 */
@@ -438,6 +439,8 @@ typedef struct
 	v3 near_p, near_n, far_p, far_n;
 	int resx, resy;
 	float aspect_ratio, focal, aperture;
+	/* depth of field */
+	float dof_distance; int bkhtype, bkhbias; v3 dof_rt, dof_up; float ls[16];
 } camera_t;
 
 typedef struct { union { float split; uint32_t first; } u; uint32_t flags; } kdnode_t; /* kdtree_triangle.h:48-86, pointers -> indices */
@@ -1509,11 +1512,90 @@ static void camera_configure(camera_t *c, const yor_camera_desc *d)
 	c->vto = vsub(vmul(c->cam_z, c->focal), vmul(vadd(c->vup, c->vright), 0.5f));
 	c->vup = V(c->vup.x / (float)c->resy, c->vup.y / (float)c->resy, c->vup.z / (float)c->resy);
 	c->vright = V(c->vright.x / (float)c->resx, c->vright.y / (float)c->resx, c->vright.z / (float)c->resx);
+	/* :42-54, :66-67 */
+	c->dof_distance = d->dof_distance; c->bkhtype = d->bokeh_type; c->bkhbias = d->bokeh_bias;
+	c->dof_rt = vmul(c->cam_x, c->aperture);
+	c->dof_up = vmul(c->cam_y, c->aperture);
+	memset(c->ls, 0, sizeof c->ls);
+	int ns = c->bkhtype;
+	if((ns >= 3) && (ns <= 6))
+	{
+		float w = (float)((double)d->bokeh_rotation * 0.01745329251994329576922), wi = (float)(6.28318530717958647692 / (double)(float)ns);
+		ns = (ns + 2) * 2;
+		for(int i = 0; i < ns; i += 2)
+		{
+			c->ls[i] = yor_fcos(w);
+			c->ls[i + 1] = yor_fsin(w);
+			w += wi;
+		}
+	}
+}
+/* PerspectiveCamera::biasDist, :75-89 */
+static void camera_bias_dist(const camera_t *c, float *r)
+{
+	switch(c->bkhbias)
+	{
+		case 1: *r = yor_fsqrt(yor_fsqrt(*r) * *r); break;
+		case 2: *r = yor_fsqrt((float)1.0 - *r * *r); break;
+		default: *r = yor_fsqrt(*r);
+	}
+}
+/* shirleyDisk__, vector.cc:155-190 */
+static void shirley_disk(float r_1, float r_2, float *u, float *v)
+{
+	float phi = 0, r = 0, a = 2 * r_1 - 1, b = 2 * r_2 - 1;
+	if(a > -b)
+	{
+		if(a > b) { r = a; phi = (float)(Y_M_PI_4 * (double)(b / a)); }
+		else { r = b; phi = (float)(Y_M_PI_4 * (double)(2 - a / b)); }
+	}
+	else
+	{
+		if(a < b) { r = -a; phi = (float)(Y_M_PI_4 * (double)(4 + b / a)); }
+		else
+		{
+			r = -b;
+			if(b != 0) phi = (float)(Y_M_PI_4 * (double)(6 - a / b));
+			else phi = 0;
+		}
+	}
+	*u = r * yor_fcos(phi);
+	*v = r * yor_fsin(phi);
+}
+/* PerspectiveCamera::getLensUv / sampleTsd, :91-131 */
+static void camera_lens_uv(const camera_t *c, float r_1, float r_2, float *u, float *v)
+{
+	switch(c->bkhtype)
+	{
+		case 3: case 4: case 5: case 6:
+		{
+			float fn = (float)c->bkhtype;
+			int idx = (int)(r_1 * fn);
+			r_1 = (r_1 - ((float)idx) / fn) * fn;
+			camera_bias_dist(c, &r_1);
+			float b_1 = r_1 * r_2;
+			float b_0 = r_1 - b_1;
+			idx <<= 1;
+			*u = c->ls[idx] * b_0 + c->ls[idx + 2] * b_1;
+			*v = c->ls[idx + 1] * b_0 + c->ls[idx + 3] * b_1;
+			break;
+		}
+		case 1: case 7:
+		{
+			float w = (float)6.28318530717958647692 * r_2;
+			if(c->bkhtype == 7) r_1 = yor_fsqrt((float)0.707106781 + (float)0.292893218);
+			else camera_bias_dist(c, &r_1);
+			*u = r_1 * yor_fcos(w);
+			*v = r_1 * yor_fsin(w);
+			break;
+		}
+		default: shirley_disk(r_1, r_2, u, v);
+	}
 }
 /* rayPlaneIntersection__, util_geometry.h:34-37 */
 static inline float ray_plane(v3 from, v3 dir, v3 pp, v3 pn) { return vdot(pn, vsub(pp, from)) / vdot(dir, pn); }
-/* shootRay, camera_perspective.cc:133-156 (aperture == 0) */
-static void camera_shoot(const camera_t *c, float px, float py, v3 *from, v3 *dir, float *tmin, float *tmax, float *wt)
+/* shootRay, camera_perspective.cc:133-156 */
+static void camera_shoot_lens(const camera_t *c, float px, float py, float lu, float lv, v3 *from, v3 *dir, float *tmin, float *tmax, float *wt)
 {
 	*wt = 1;
 	*from = c->position;
@@ -1521,6 +1603,19 @@ static void camera_shoot(const camera_t *c, float px, float py, v3 *from, v3 *di
 	*dir = vnormalize(*dir);
 	*tmin = ray_plane(*from, *dir, c->near_p, c->near_n);
 	*tmax = ray_plane(*from, *dir, c->far_p, c->far_n);
+	if(c->aperture != 0)
+	{
+		float u, v;
+		camera_lens_uv(c, lu, lv, &u, &v);
+		v3 li = vadd(vmul(c->dof_rt, u), vmul(c->dof_up, v));
+		*from = vadd(*from, li);
+		*dir = vsub(vmul(*dir, c->dof_distance), li);
+		*dir = vnormalize(*dir);
+	}
+}
+static void camera_shoot(const camera_t *c, float px, float py, v3 *from, v3 *dir, float *tmin, float *tmax, float *wt)
+{
+	camera_shoot_lens(c, px, py, 0.5f, 0.5f, from, dir, tmin, tmax, wt);
 }
 
 /* ------------------------------------------------------------------ scene create */
@@ -2002,6 +2097,11 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 		{
 			if(wk->pass_adaptive && wk->film->flags && !wk->film->flags[(size_t)(i - rd->ystart) * (size_t)rd->width + (size_t)(j - rd->xstart)]) continue; /* :355 */
 			st->sampling_offs = yor_fnv32a((uint32_t)i * yor_fnv32a((uint32_t)j)); /* :379 */
+			halton_t hal_u, hal_v;                                                  /* :337-338, :382-383 */
+			halton_init(&hal_u, 3); halton_init(&hal_v, 5);
+			halton_set_start(&hal_u, (uint32_t)pass_offs + st->sampling_offs);
+			halton_set_start(&hal_v, (uint32_t)pass_offs + st->sampling_offs);
+			float lens_u = 0.5f, lens_v = 0.5f;
 			for(int sample = 0; sample < n_samples; ++sample)
 			{
 				st->pixel_sample = (unsigned)(pass_offs + sample);
@@ -2016,7 +2116,8 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 					dy = yor_ri_lp((uint32_t)sample + st->sampling_offs, 0);
 				}
 				v3 from, dir; float tmin, tmax;
-				camera_shoot(cam, j + dx, i + dy, &from, &dir, &tmin, &tmax, &wt);
+				if(cam->aperture != 0) { lens_u = halton_next(&hal_u); lens_v = halton_next(&hal_v); }   /* :405-409 */
+				camera_shoot_lens(cam, j + dx, i + dy, lens_u, lens_v, &from, &dir, &tmin, &tmax, &wt);
 				wk->camera_samples++;
 				float c[4];
 				integrate(st, from, dir, tmin, tmax, c);
@@ -2217,7 +2318,6 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 {
 	if(rd->aa_passes < 1) return -1;
 	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
-	if(s->cam.aperture != 0.f) return -3;
 	for(int i = 0; i < s->n_mats; ++i)
 		if(s->mats[i].flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace not restated */
 	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
@@ -2333,6 +2433,13 @@ void yor_camera_shoot(const yor_camera_desc *cam, float px, float py, float out9
 	camera_t c; camera_configure(&c, cam);
 	v3 f, d; float tmin, tmax, wt;
 	camera_shoot(&c, px, py, &f, &d, &tmin, &tmax, &wt);
+	out9[0] = f.x; out9[1] = f.y; out9[2] = f.z; out9[3] = d.x; out9[4] = d.y; out9[5] = d.z; out9[6] = tmin; out9[7] = tmax; out9[8] = wt;
+}
+void yor_camera_shoot_lens(const yor_camera_desc *cam, float px, float py, float lu, float lv, float out9[9])
+{
+	camera_t c; camera_configure(&c, cam);
+	v3 f, d; float tmin, tmax, wt;
+	camera_shoot_lens(&c, px, py, lu, lv, &f, &d, &tmin, &tmax, &wt);
 	out9[0] = f.x; out9[1] = f.y; out9[2] = f.z; out9[3] = d.x; out9[4] = d.y; out9[5] = d.z; out9[6] = tmin; out9[7] = tmax; out9[8] = wt;
 }
 int yor_arealight_illum_sample(const yor_light_desc *ld, const float p[3], float s1, float s2, float out8[8])

@@ -86,8 +86,13 @@ typedef struct yor_camera_desc
 	float focal;
 	float aspect_ratio;
 	float near_clip, far_clip;
-	float aperture;            /* must be 0 (pinhole) */
+	float aperture;            /* 0: pinhole */
 	float pad0;
+	/* depth of field (PerspectiveCamera::factory, camera_perspective.cc:200-240) */
+	float dof_distance;
+	int32_t bokeh_type;        /* 0 disk1, 1 disk2, 3 triangle, 4 square, 5 pentagon, 6 hexagon, 7 ring (BokehType) */
+	int32_t bokeh_bias;        /* 0 none ("uniform"), 1 center, 2 edge */
+	float bokeh_rotation;      /* degrees */
 } yor_camera_desc;
 
 typedef struct yor_render_desc
@@ -187,6 +192,7 @@ void yor_create_cs(const float n[3], float u[3], float v[3]);
 void yor_sample_cos_hemisphere(const float n[3], const float ru[3], const float rv[3], float s1, float s2, float out[3]);
 int yor_bound_cross(const float a[3], const float g[3], const float from[3], const float dir[3], float dist, float *enter, float *leave);
 void yor_camera_shoot(const yor_camera_desc *cam, float px, float py, float out9[9]);
+void yor_camera_shoot_lens(const yor_camera_desc *cam, float px, float py, float lu, float lv, float out9[9]);
 int yor_arealight_illum_sample(const yor_light_desc *l, const float p[3], float s1, float s2, float out8[8]);
 int yor_arealight_intersect(const yor_light_desc *l, const float from[3], const float dir[3], float out5[5]);
 int yor_pointlight_illuminate(const yor_light_desc *l, const float p[3], float out7[7]);

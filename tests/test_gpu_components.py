@@ -102,6 +102,25 @@ def test_camera(gold, probe_scene):
         exact(yi.probe(7, pxy[c], 9), want[c], f"PerspectiveCamera::shootRay cfg {c}")
 
 
+def test_camera_depth_of_field(gold, probe_scene):
+    """lens sampling for every bokeh shape and bias, against the reference's own camera (camera_perspective.cc:75-156)"""
+    g = gold
+    sc, names = probe_scene
+    s2 = dict(sc); s2["materials"] = [sc["materials"][0]]
+    types = ["disk1", "disk2", "triangle", "square", "pentagon", "hexagon", "ring"]
+    biases = ["uniform", "center", "edge"]
+    cfg = g["camd_cfg17"].reshape(-1, 17)
+    in4 = u2f(g["camd_in4"]).reshape(len(cfg), -1, 4)
+    want = g["camd_ray9"].reshape(len(cfg), -1, 9)
+    for c in range(len(cfg)):
+        fl = u2f(cfg[c])
+        cam = {"type": "perspective", "from": tuple(fl[0:3]), "to": tuple(fl[3:6]), "up": tuple(fl[6:9]), "resx": int(cfg[c][9]),
+               "resy": int(cfg[c][10]), "focal": float(fl[11]), "aperture": float(fl[12]), "dof_distance": float(fl[13]),
+               "bokeh_type": types[int(cfg[c][14])], "bokeh_bias": biases[int(cfg[c][15])], "bokeh_rotation": float(fl[16])}
+        yi = make_iface(s2, cam)
+        exact(yi.probe(7, in4[c], 9), want[c], f"PerspectiveCamera::shootRay with lens, cfg {c}")
+
+
 def test_lights(gold, probe_scene):
     g = gold
     sc, names = probe_scene

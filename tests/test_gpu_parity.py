@@ -322,3 +322,21 @@ def test_multi_pass_anti_aliasing(aa, pipeline):
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     assert film[..., 4].min() >= 3 and len(np.unique(np.round(film[..., 4]))) >= (1 if aa["AA_threshold"] == 0.0 else 2)
     compare_films(film, ofilm, f"multi-pass {aa}")
+
+
+@pytest.mark.parametrize("bokeh", [dict(bokeh_type="disk1"), dict(bokeh_type="hexagon", bokeh_bias="edge", bokeh_rotation=20.0),
+                                   dict(bokeh_type="ring"), dict(bokeh_type="disk2", bokeh_bias="center")])
+def test_depth_of_field(bokeh, pipeline):
+    """aperture != 0: per-pixel Halton(3) / Halton(5) lens coordinates (integrator_tiled.cc:382-383,405-409) through
+    PerspectiveCamera::getLensUv (camera_perspective.cc:91-131)"""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has the pinhole camera only")
+    sc = scenes.cornell_soup(600, seed=8, res=(52, 40))
+    sc["camera"] = dict(sc["camera"], aperture=0.08, dof_distance=3.7, **bokeh)
+    rd = scenes.render_settings(52, 40, 9, bounces=2, background=(0.1, 0.1, 0.1), adv_base_sampling_offset=5)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"depth of field {bokeh}")
+    pin = dict(sc); pin["camera"] = dict(sc["camera"], aperture=0.0)
+    pfilm, _ = po.OracleScene(pin).render(rd)
+    assert not np.allclose(po.film_to_rgb(pfilm), po.film_to_rgb(ofilm), rtol=1e-3), "the lens changes the image"

@@ -141,6 +141,27 @@ def test_cs_hemisphere_bound(gold):
     check(variant, outs, np.array(want, dtype=np.uint32), "Bound::cross")
 
 
+def test_camera_depth_of_field(gold):
+    """PerspectiveCamera with aperture != 0: lens sampling for every bokeh shape and bias (camera_perspective.cc:75-156)"""
+    variant, g = gold
+    L = po.lib()
+    types = ["disk1", "disk2", "triangle", "square", "pentagon", "hexagon", "ring"]
+    biases = ["uniform", "center", "edge"]
+    cfg = g["camd_cfg17"].reshape(-1, 17)
+    in4 = f32(g["camd_in4"]).reshape(len(cfg), -1, 4)
+    got = []
+    for c in range(len(cfg)):
+        fl = f32(cfg[c])
+        cam = po.camera_desc({"from": fl[0:3], "to": fl[3:6], "up": fl[6:9], "resx": int(cfg[c][9]), "resy": int(cfg[c][10]),
+                              "focal": float(fl[11]), "aperture": float(fl[12]), "dof_distance": float(fl[13]),
+                              "bokeh_type": types[int(cfg[c][14])], "bokeh_bias": biases[int(cfg[c][15])], "bokeh_rotation": float(fl[16])})
+        out = np.zeros(9, np.float32)
+        for k in range(in4.shape[1]):
+            L.yor_camera_shoot_lens(C.byref(cam), in4[c, k, 0], in4[c, k, 1], in4[c, k, 2], in4[c, k, 3], po.fptr(out))
+            got.extend(out.tolist())
+    check(variant, got, g["camd_ray9"], "PerspectiveCamera::shootRay (depth of field)")
+
+
 def test_camera(gold):
     variant, g = gold
     L = po.lib()

@@ -59,7 +59,6 @@ def test_factories_fail_loudly_outside_scope():
         ("material", {"type": "glass"}, "scope"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
         ("material", {"type": "glossy", "anisotropic": True}, "anisotropic"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
-        ("camera", {"type": "perspective", "aperture": 0.1}, "aperture"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
         ("integrator", {"type": "pathtracing", "transpShad": True}, "transparent shadows"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),

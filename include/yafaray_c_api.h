@@ -71,6 +71,8 @@ int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z);   
 void yafaray_addNormal(yafaray_interface_t *yi, double nx, double ny, double nz);/* :68 */
 yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c, const yafaray_material_t *mat); /* :69 */
 yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle); /* :72 */
+/* extension (test support): the per-triangle-corner normals smoothMesh computed, n_tris*9 floats; an all-zero triple = geometric normal */
+yafaray_bool_t yafaray_getMeshCornerNormals(yafaray_interface_t *yi, unsigned int id, float *out, int n_floats);
 /* extension (not in the reference): bulk form of addVertex/addTriangle for large meshes;
  * verts = n_verts*3 floats, indices = n_tris*3 ints, one material for all triangles */
 yafaray_bool_t yafaray_addTriangles(yafaray_interface_t *yi, int n_verts, const float *verts, int n_tris, const int *indices,

@@ -86,7 +86,7 @@ struct yafaray_interface
 	// scene state (scene.cc:110-131): 0 ready, 1 geometry, 2 object
 	int state = -1;
 	std::map<unsigned int, Mesh> meshes;
-	Mesh *cur = nullptr;
+	Mesh *cur = nullptr, *last = nullptr;   // last: Scene's cur_obj_ outlives endTriMesh (smoothMesh(0, angle))
 	unsigned int next_id = 1;
 	bool geometry_changed = true;
 	// render
@@ -320,7 +320,7 @@ const char *yafaray_getVersion(void) { return "yafgpu-0.1 (MI355X path-tracing c
 yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type)
 {
 	if(type != 0) return fail(yi, "startScene: only scene type 0 (\"triangle\") is supported (import_xml.cc:339-347)");
-	yi->state = 0; yi->meshes.clear(); yi->cur = nullptr; yi->geometry_changed = true; yi->prepared = false;
+	yi->state = 0; yi->meshes.clear(); yi->cur = nullptr; yi->last = nullptr; yi->geometry_changed = true; yi->prepared = false;
 	return 1;
 }
 yafaray_bool_t yafaray_startGeometry(yafaray_interface_t *yi) { if(yi->state != 0) return fail(yi, "startGeometry: wrong state"); yi->state = 1; return 1; }
@@ -337,7 +337,7 @@ yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, in
 	m = Mesh();
 	m.visible = !(type & 0x0100); m.base = (type & 0x0200) != 0;
 	m.points.reserve((size_t)std::max(vertices, 0) * 3); m.tri.reserve((size_t)std::max(triangles, 0) * 3); m.tri_mat.reserve((size_t)std::max(triangles, 0));
-	yi->cur = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
+	yi->cur = &m; yi->last = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
 	return 1;
 }
 yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi) { if(yi->state != 2) return fail(yi, "endTriMesh: wrong state"); yi->state = 1; yi->cur = nullptr; return 1; }
@@ -383,10 +383,145 @@ yafaray_bool_t yafaray_addTriangles(yafaray_interface_t *yi, int n_verts, const 
 	m.tri_mat.insert(m.tri_mat.end(), (size_t)n_tris, mat->index);
 	return 1;
 }
-yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle)
+// Scene::smoothMesh, scene.cc:383-543.  Vertex normals per triangle corner; a corner left without one (all-zero
+// triple) uses the geometric normal, as Triangle::getSurface does for a negative normal index (triangle.cc:38-40).
+// Parity unpinned: scene.cc does not build outside the reference's own build system; restated, and checked against an
+// independent restatement in tests/test_host_api.py.
+namespace {
+inline void sub3(const float *a, const float *b, float *o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+inline float len3(const float *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }   // Vec3::length, vector.h (fSqrt__ = sqrt)
+inline float sin_from_vectors(const float *a, const float *b)   // Vec3::sinFromVectors, vector.h:263-270
 {
-	(void)id; (void)angle;
-	return fail(yi, "smoothMesh: angle-based normal smoothing is not implemented; export vertex normals with addNormal");
+	const float div = (len3(a) * len3(b)) * 0.99999f + 0.00001f;
+	float c[3]; cross3(a, b, c);
+	float arg = (len3(c) / div) * 0.99999f;
+	if(arg > 1.f) arg = 1.f;
+	return (float)std::asin((double)arg);
+}
+inline float host_fsin_poly(float x)   // fSin__ with FAST_TRIG, util_math_optimizations.h:219-244
+{
+	const double k2Pi = 6.28318530717958647692, kPi = 3.14159265358979323846;
+	if((double)x > k2Pi || (double)x < -k2Pi) x -= ((int)(x * (float)0.15915494309189533577)) * (float)k2Pi;
+	if((double)x < -kPi) x += (float)k2Pi;
+	else if((double)x > kPi) x -= (float)k2Pi;
+	x = ((float)1.27323954473516268615 * x) - ((float)0.40528473456935108578 * x * std::fabs(x));
+	const float result = 0.225f * (x * std::fabs(x) - x) + x;
+	if(result <= -1.0f) return -1.0f;
+	if(result >= 1.0f) return 1.0f;
+	return result;
+}
+}
+yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle_d)
+{
+	if(yi->state != 1) return fail(yi, "smoothMesh: wrong state (call it between endTriMesh and endGeometry)");
+	Mesh *mp = nullptr;
+	if(id) { auto it = yi->meshes.find(id); if(it == yi->meshes.end()) return fail(yi, "smoothMesh: no such mesh"); mp = &it->second; }
+	else { mp = yi->last; if(!mp) return fail(yi, "smoothMesh: no current mesh"); }
+	Mesh &m = *mp;
+	const float angle = (float)angle_d;
+	const size_t nv = m.points.size() / 3, nt = m.tri.size() / 3;
+	yi->geometry_changed = true; yi->prepared = false;
+	if(m.normals_exported && m.normals.size() == m.points.size()) { m.smooth = true; return 1; }      // :402-406
+	m.smooth_normals.assign(nt * 9, 0.f);
+	// face normals: Triangle::recNormal, triangle.h:295-302
+	std::vector<float> fn(nt * 3);
+	for(size_t t = 0; t < nt; ++t)
+	{
+		const float *a = &m.points[3 * (size_t)m.tri[3 * t]], *b = &m.points[3 * (size_t)m.tri[3 * t + 1]], *c = &m.points[3 * (size_t)m.tri[3 * t + 2]];
+		float e1[3], e2[3]; sub3(b, a, e1); sub3(c, a, e2);
+		cross3(e1, e2, &fn[3 * t]);
+		normalize3(&fn[3 * t]);
+	}
+	auto corner_alpha = [&](size_t t, int q, int v1, int v2) {
+		const float *pq = &m.points[3 * (size_t)m.tri[3 * t + (size_t)q]], *p1 = &m.points[3 * (size_t)m.tri[3 * t + (size_t)v1]], *p2 = &m.points[3 * (size_t)m.tri[3 * t + (size_t)v2]];
+		float e1[3], e2[3]; sub3(p1, pq, e1); sub3(p2, pq, e2);      // PREPARE_EDGES, :383-384
+		return sin_from_vectors(e1, e2);
+	};
+	auto normal_normalize = [](float *v) {   // Normal::normalize, vector.h:272-283
+		float len = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+		if(len != 0.f) { len = (float)(1.0 / (double)std::sqrt(len)); v[0] *= len; v[1] *= len; v[2] *= len; }
+	};
+	if(angle >= 180.f)
+	{	// :420-448
+		std::vector<float> vn(nv * 3, 0.f);
+		for(size_t t = 0; t < nt; ++t)
+		{
+			const int order[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
+			for(int k = 0; k < 3; ++k)
+			{
+				const float alpha = corner_alpha(t, order[k][0], order[k][1], order[k][2]);
+				float *dst = &vn[3 * (size_t)m.tri[3 * t + (size_t)k]];
+				for(int c = 0; c < 3; ++c) dst[c] += fn[3 * t + (size_t)c] * alpha;
+			}
+		}
+		for(size_t v = 0; v < nv; ++v) normal_normalize(&vn[3 * v]);
+		for(size_t t = 0; t < nt; ++t)
+			for(int k = 0; k < 3; ++k)
+				for(int c = 0; c < 3; ++c) m.smooth_normals[9 * t + 3 * (size_t)k + (size_t)c] = vn[3 * (size_t)m.tri[3 * t + (size_t)k] + (size_t)c];
+	}
+	else if(angle > 0.1f)
+	{	// :450-538 angle dependent smoothing
+		const float thresh = host_fsin_poly((float)((double)angle * 0.01745329251994329576922) + (float)1.57079632679489661923);   // fCos__(DEG_TO_RAD(angle))
+		std::vector<std::vector<uint32_t>> vface(nv);
+		std::vector<std::vector<float>> alphas(nv);
+		for(size_t t = 0; t < nt; ++t)
+		{
+			const int order[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
+			for(int k = 0; k < 3; ++k)
+			{
+				const size_t v = (size_t)m.tri[3 * t + (size_t)k];
+				alphas[v].push_back(corner_alpha(t, order[k][0], order[k][1], order[k][2]));
+				vface[v].push_back((uint32_t)t);
+			}
+		}
+		std::vector<float> vnormals;      // the distinct normals found so far at this vertex
+		for(size_t i = 0; i < nv; ++i)
+		{
+			const std::vector<uint32_t> &tris = vface[i];
+			vnormals.clear();
+			for(size_t j = 0; j < tris.size(); ++j)
+			{
+				const uint32_t f = tris[j];
+				bool smooth = false;
+				float vnorm[3] = {fn[3 * f] * alphas[i][j], fn[3 * f + 1] * alphas[i][j], fn[3 * f + 2] * alphas[i][j]};
+				for(size_t k = 0; k < tris.size(); ++k)
+				{
+					const uint32_t f2 = tris[k];
+					if(f2 == f) continue;                                   // Triangle::operator== compares indices (triangle.h:76-79)
+					const float *n2 = &fn[3 * f2];
+					if((fn[3 * f] * n2[0] + fn[3 * f + 1] * n2[1] + fn[3 * f + 2] * n2[2]) > thresh)
+					{
+						smooth = true;
+						for(int c = 0; c < 3; ++c) vnorm[c] += n2[c] * alphas[i][k];
+					}
+				}
+				if(!smooth) continue;                                       // n_idx = -1: the corner keeps the geometric normal
+				normalize3(vnorm);
+				const float *use = nullptr;
+				for(size_t l = 0; l + 2 < vnormals.size(); l += 3)
+					if((double)(vnorm[0] * vnormals[l] + vnorm[1] * vnormals[l + 1] + vnorm[2] * vnormals[l + 2]) > 0.999) { use = &vnormals[l]; break; }
+				float chosen[3];
+				if(use) { chosen[0] = use[0]; chosen[1] = use[1]; chosen[2] = use[2]; }
+				else { chosen[0] = vnorm[0]; chosen[1] = vnorm[1]; chosen[2] = vnorm[2]; vnormals.insert(vnormals.end(), vnorm, vnorm + 3); }
+				// :526-528: the first corner of f that is vertex i
+				int corner = -1;
+				for(int c = 0; c < 3; ++c) if((size_t)m.tri[3 * (size_t)f + (size_t)c] == i) { corner = c; break; }
+				if(corner < 0) return fail(yi, "smoothMesh: mesh smoothing error");
+				for(int c = 0; c < 3; ++c) m.smooth_normals[9 * (size_t)f + 3 * (size_t)corner + (size_t)c] = chosen[c];
+			}
+		}
+	}
+	m.smooth = true;
+	return 1;
+}
+yafaray_bool_t yafaray_getMeshCornerNormals(yafaray_interface_t *yi, unsigned int id, float *out, int n_floats)
+{
+	auto it = yi->meshes.find(id);
+	if(it == yi->meshes.end()) return fail(yi, "getMeshCornerNormals: no such mesh");
+	const Mesh &m = it->second;
+	if(m.smooth_normals.empty() || (int)m.smooth_normals.size() != n_floats) return fail(yi, "getMeshCornerNormals: the mesh has no smoothed normals of that size");
+	std::memcpy(out, m.smooth_normals.data(), m.smooth_normals.size() * sizeof(float));
+	return 1;
 }
 
 void yafaray_paramsSetPoint(yafaray_interface_t *yi, const char *name, double x, double y, double z) { Param p; p.type = Param::Point; p.v[0] = (float)x; p.v[1] = (float)y; p.v[2] = (float)z; set_param(yi, name, p); }
@@ -598,7 +733,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(yi->state != 0) return fail(yi, "render: scene is not in the ready state (missing endGeometry?)");
 	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
 	std::vector<float> verts; std::vector<int32_t> tri_mat; std::vector<float> vnormals; bool any_normals = false;
-	for(auto &kv : yi->meshes) if(kv.second.normals_exported) any_normals = true;
+	for(auto &kv : yi->meshes) if(kv.second.normals_exported || (kv.second.smooth && !kv.second.smooth_normals.empty())) any_normals = true;
 	for(auto &kv : yi->meshes)
 	{
 		const Mesh &m = kv.second;
@@ -612,7 +747,9 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 				verts.push_back(m.points[3 * (size_t)vi]); verts.push_back(m.points[3 * (size_t)vi + 1]); verts.push_back(m.points[3 * (size_t)vi + 2]);
 				if(any_normals)
 				{
-					if(m.normals_exported && m.normals.size() >= 3 * ((size_t)vi + 1))
+					if(m.smooth && !m.smooth_normals.empty())
+					{ for(int q = 0; q < 3; ++q) vnormals.push_back(m.smooth_normals[9 * t + 3 * (size_t)c + (size_t)q]); }
+					else if(m.normals_exported && m.normals.size() >= 3 * ((size_t)vi + 1))
 					{ vnormals.push_back(m.normals[3 * (size_t)vi]); vnormals.push_back(m.normals[3 * (size_t)vi + 1]); vnormals.push_back(m.normals[3 * (size_t)vi + 2]); }
 					else { vnormals.push_back(0.f); vnormals.push_back(0.f); vnormals.push_back(0.f); }
 				}

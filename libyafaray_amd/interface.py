@@ -47,7 +47,7 @@ C_API_SYMBOLS = [
     "yafaray_createInterface", "yafaray_destroyInterface", "yafaray_getLastError", "yafaray_getVersion",
     "yafaray_startScene", "yafaray_startGeometry", "yafaray_endGeometry", "yafaray_getNextFreeId",
     "yafaray_startTriMesh", "yafaray_endTriMesh", "yafaray_addVertex", "yafaray_addNormal", "yafaray_addTriangle",
-    "yafaray_smoothMesh", "yafaray_addTriangles",
+    "yafaray_smoothMesh", "yafaray_getMeshCornerNormals", "yafaray_addTriangles",
     "yafaray_paramsSetPoint", "yafaray_paramsSetString", "yafaray_paramsSetBool", "yafaray_paramsSetInt",
     "yafaray_paramsSetFloat", "yafaray_paramsSetColor", "yafaray_paramsClearAll", "yafaray_paramsStartList",
     "yafaray_paramsPushList", "yafaray_paramsEndList",
@@ -84,6 +84,7 @@ def load():
         "yafaray_startTriMesh": (ci, [vp, C.c_uint, ci, ci, ci, ci, ci, ci]), "yafaray_endTriMesh": (ci, [vp]),
         "yafaray_addVertex": (ci, [vp, cd, cd, cd]), "yafaray_addNormal": (None, [vp, cd, cd, cd]),
         "yafaray_addTriangle": (ci, [vp, ci, ci, ci, vp]), "yafaray_smoothMesh": (ci, [vp, C.c_uint, cd]),
+        "yafaray_getMeshCornerNormals": (ci, [vp, C.c_uint, C.POINTER(cf), ci]),
         "yafaray_addTriangles": (ci, [vp, ci, C.POINTER(cf), ci, C.POINTER(ci), vp]),
         "yafaray_paramsSetPoint": (None, [vp, cp, cd, cd, cd]), "yafaray_paramsSetString": (None, [vp, cp, cp]),
         "yafaray_paramsSetBool": (None, [vp, cp, ci]), "yafaray_paramsSetInt": (None, [vp, cp, ci]),
@@ -194,6 +195,11 @@ class Interface:
 
     def smoothMesh(self, id, angle):
         return self._ok(self._L.yafaray_smoothMesh(self._h, id, angle), "smoothMesh")
+
+    def getMeshCornerNormals(self, id, n_tris):
+        out = np.zeros((n_tris, 3, 3), dtype=np.float32)
+        self._ok(self._L.yafaray_getMeshCornerNormals(self._h, id, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "getMeshCornerNormals")
+        return out
 
     # -- params
     def paramsSetPoint(self, name, x, y, z):

@@ -148,6 +148,8 @@ def load_scene(yi, scene, render):
             yi.addTriangles(verts[start:end].reshape(-1, 3), idx, handles[int(tri_mat[start])])
             start = end
         yi.endTriMesh()
+    if scene.get("smooth_angle") is not None:
+        yi.smoothMesh(0, float(scene["smooth_angle"]))      # Interface::smoothMesh on the mesh just closed
     yi.endGeometry()
 
     yi.paramsClearAll()

@@ -340,3 +340,74 @@ def test_depth_of_field(bokeh, pipeline):
     pin = dict(sc); pin["camera"] = dict(sc["camera"], aperture=0.0)
     pfilm, _ = po.OracleScene(pin).render(rd)
     assert not np.allclose(po.film_to_rgb(pfilm), po.film_to_rgb(ofilm), rtol=1e-3), "the lens changes the image"
+
+
+@pytest.mark.parametrize("angle", [181.0, 40.0])
+def test_smooth_mesh_render(angle, pipeline):
+    """Interface::smoothMesh (scene.cc:383-543): vertex normals computed on the host from the shared-vertex mesh,
+    interpolated by Triangle::getSurface on the device.  The oracle gets the same corner normals."""
+    sc = scenes.cornell_soup(40, seed=5, res=(48, 40))
+    n_lat, n_lon, radius, centre = 8, 12, 0.5, np.array([0.0, 0.1, -0.35], np.float32)
+    pts = [centre + radius * np.array([0, 0, 1], np.float32)]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            pts.append(centre + radius * np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], np.float32))
+    pts.append(centre - radius * np.array([0, 0, 1], np.float32))
+    pts = np.array(pts, np.float32)
+    ring = lambda i, j: 1 + (i - 1) * n_lon + (j % n_lon)
+    tris = []
+    for j in range(n_lon):
+        tris.append((0, ring(1, j), ring(1, j + 1)))
+        tris.append((len(pts) - 1, ring(n_lat - 1, j + 1), ring(n_lat - 1, j)))
+        for i in range(1, n_lat - 1):
+            tris += [(ring(i, j), ring(i + 1, j), ring(i, j + 1)), (ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1))]
+    tris = np.array(tris, np.int32)
+    # one shared-vertex mesh: the sphere through addVertex / addTriangle so that smoothMesh sees the sharing
+    yi = Interface()
+    yi.startScene(0)
+    handles = []
+    for i, m in enumerate(sc["materials"]):
+        yi.paramsClearAll(); yi.paramsSet({k: (("color",) + tuple(float(x) for x in v) + (1.0,) if k in ("color", "mirror_color", "diffuse_color") else v) for k, v in m.items()})
+        handles.append(yi.createMaterial(f"mat{i}"))
+    for i, l in enumerate(sc["lights"]):
+        yi.paramsClearAll(); yi.paramsSet({k: (("color",) + tuple(float(x) for x in v) + (1.0,) if k == "color" else v) for k, v in l.items()})
+        yi.createLight(f"light{i}")
+    yi.paramsClearAll(); yi.paramsSet(dict(sc["camera"], type="perspective")); yi.createCamera("cam")
+    yi.paramsClearAll(); yi.paramsSet({"type": "pathtracing", "path_samples": 1, "bounces": 2, "russian_roulette_min_bounces": 2, "caustic_type": "none"}); yi.createIntegrator("default")
+    yi.paramsClearAll(); yi.paramsSet({"type": "none"}); yi.createIntegrator("volintegr")
+    yi.startGeometry()
+    walls = np.asarray(sc["verts"], np.float32).reshape(-1, 3, 3)
+    wid = yi.getNextFreeId()
+    yi.startTriMesh(wid, 3 * len(walls), len(walls), False, False, 0)
+    for t in range(len(walls)):
+        yi.addTriangles(walls[t], np.arange(3, dtype=np.int32), handles[int(sc["tri_mat"][t])])
+    yi.endTriMesh()
+    sid = yi.getNextFreeId()
+    yi.startTriMesh(sid, len(pts), len(tris), False, False, 0)
+    for p in pts:
+        yi.addVertex(float(p[0]), float(p[1]), float(p[2]))
+    for t in tris:
+        yi.addTriangle(int(t[0]), int(t[1]), int(t[2]), handles[0])
+    yi.endTriMesh()
+    assert yi.smoothMesh(sid, angle)
+    corner = yi.getMeshCornerNormals(sid, len(tris))
+    yi.endGeometry()
+    rd = scenes.render_settings(48, 40, 6, bounces=2)
+    yi.paramsClearAll()
+    yi.paramsSet({"camera_name": "cam", "integrator_name": "default", "volintegrator_name": "volintegr", "width": 48, "height": 40,
+                  "AA_passes": 1, "AA_minsamples": 6, "AA_pixelwidth": 1.0, "filter_type": "box", "tile_size": 32})
+    yi.render()
+    film, st = yi.getFilm(48, 40), yi.getRenderStats()
+    osc_scene = dict(sc)
+    osc_scene["verts"] = np.concatenate([walls, pts[tris]], axis=0)
+    osc_scene["tri_mat"] = np.concatenate([np.asarray(sc["tri_mat"], np.int32), np.zeros(len(tris), np.int32)])
+    osc_scene["vnormals"] = np.concatenate([np.zeros_like(walls), corner], axis=0)
+    ofilm, ost = po.OracleScene(osc_scene).render(rd)
+    assert st.n_triangles == len(walls) + len(tris)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"smoothMesh {angle}")
+    flat = dict(osc_scene); flat["vnormals"] = None
+    ffilm, _ = po.OracleScene(flat).render(rd)
+    assert not np.allclose(po.film_to_rgb(ffilm), po.film_to_rgb(ofilm), rtol=1e-3), "smoothing changes the shading"

@@ -135,3 +135,112 @@ def test_no_cpu_fallback_without_a_gpu():
     scenes.load_scene(yi, scenes.cornell_soup(12, seed=1), scenes.render_settings(8, 8, 1))
     assert not yi.render()
     assert yi.getLastError() != ""
+
+
+def _smooth_mesh_restated(points, tris, angle):
+    """Independent restatement of Scene::smoothMesh (scene.cc:383-543) in float32 scalar arithmetic."""
+    f = np.float32
+    P = points.astype(np.float32)
+    nt = len(tris)
+
+    def sub(a, b): return np.array([f(a[0] - b[0]), f(a[1] - b[1]), f(a[2] - b[2])], np.float32)
+    def cross(a, b): return np.array([f(f(a[1] * b[2]) - f(a[2] * b[1])), f(f(a[2] * b[0]) - f(a[0] * b[2])), f(f(a[0] * b[1]) - f(a[1] * b[0]))], np.float32)
+    def dot(a, b): return f(f(f(a[0] * b[0]) + f(a[1] * b[1])) + f(a[2] * b[2]))
+    def length(a): return f(np.sqrt(dot(a, a)))
+    def normalize(a):
+        l = dot(a, a)
+        if l != 0:
+            inv = f(f(1.0) / f(np.sqrt(l)))
+            a = np.array([f(a[0] * inv), f(a[1] * inv), f(a[2] * inv)], np.float32)
+        return a
+    def sin_from(a, b):
+        div = f(f(f(length(a) * length(b)) * f(0.99999)) + f(0.00001))
+        arg = f(f(length(cross(a, b)) / div) * f(0.99999))
+        if arg > 1: arg = f(1)
+        return f(np.arcsin(np.float64(arg)))
+    fn = np.array([normalize(cross(sub(P[t[1]], P[t[0]]), sub(P[t[2]], P[t[0]]))) for t in tris], np.float32)
+    orders = [(0, 1, 2), (1, 0, 2), (2, 0, 1)]
+    alpha = np.array([[sin_from(sub(P[t[o[1]]], P[t[o[0]]]), sub(P[t[o[2]]], P[t[o[0]]])) for o in orders] for t in tris], np.float32)
+    out = np.zeros((nt, 3, 3), np.float32)
+    if angle >= 180:
+        vn = np.zeros_like(P)
+        for ti, t in enumerate(tris):
+            for k in range(3):
+                for c in range(3):
+                    vn[t[k], c] = f(vn[t[k], c] + f(fn[ti, c] * alpha[ti, k]))
+        vn = np.array([normalize(v) for v in vn], np.float32)
+        for ti, t in enumerate(tris):
+            for k in range(3):
+                out[ti, k] = vn[t[k]]
+        return out
+    if not angle > 0.1:
+        return out
+    from oracle import pyoracle as po
+    thresh = f(po.lib().yor_fcos(f(np.float64(f(angle)) * 0.01745329251994329576922)))
+    vface = [[] for _ in P]
+    for ti, t in enumerate(tris):
+        for k in range(3):
+            vface[t[k]].append((ti, alpha[ti, k]))
+    for i, lst in enumerate(vface):
+        found = []
+        for (fi, a_j) in lst:
+            vnorm = np.array([f(fn[fi, c] * a_j) for c in range(3)], np.float32)
+            smooth = False
+            for (f2, a_k) in lst:
+                if f2 == fi:
+                    continue
+                if dot(fn[fi], fn[f2]) > thresh:
+                    smooth = True
+                    vnorm = np.array([f(vnorm[c] + f(fn[f2, c] * a_k)) for c in range(3)], np.float32)
+            if not smooth:
+                continue
+            vnorm = normalize(vnorm)
+            use = None
+            for v in found:
+                if np.float64(dot(vnorm, v)) > 0.999:
+                    use = v
+                    break
+            if use is None:
+                found.append(vnorm)
+                use = vnorm
+            corner = list(tris[fi]).index(i)
+            out[fi, corner] = use
+    return out
+
+
+@pytest.mark.parametrize("angle", [181.0, 60.0, 25.0, 0.05])
+def test_smooth_mesh(angle):
+    """Interface::smoothMesh on a faceted cylinder + cap: the C++ host code against the Python restatement"""
+    from oracle import pyoracle as po
+    po.lib().yor_fcos.restype = __import__("ctypes").c_float
+    po.lib().yor_fcos.argtypes = [__import__("ctypes").c_float]
+    n = 10
+    ring0 = [(np.cos(2 * np.pi * k / n), np.sin(2 * np.pi * k / n), 0.0) for k in range(n)]
+    ring1 = [(np.cos(2 * np.pi * k / n), np.sin(2 * np.pi * k / n), 1.3) for k in range(n)]
+    pts = np.array(ring0 + ring1 + [(0.0, 0.0, 1.3)], np.float32)
+    tris = []
+    for k in range(n):
+        a, b = k, (k + 1) % n
+        tris += [(a, b, n + a), (b, n + b, n + a), (n + a, n + b, 2 * n)]
+    yi = fresh()
+    yi.startScene(0)
+    yi.paramsClearAll(); yi.paramsSet({"type": "shinydiffusemat"})
+    mat = yi.createMaterial("m")
+    yi.startGeometry()
+    mid = yi.getNextFreeId()
+    yi.startTriMesh(mid, len(pts), len(tris), False, False, 0)
+    for p in pts:
+        yi.addVertex(float(p[0]), float(p[1]), float(p[2]))
+    for t in tris:
+        yi.addTriangle(t[0], t[1], t[2], mat)
+    yi.endTriMesh()
+    assert yi.smoothMesh(0, angle)
+    got = yi.getMeshCornerNormals(mid, len(tris))
+    want = _smooth_mesh_restated(pts, tris, angle)
+    assert np.array_equal((np.abs(got).sum(axis=-1) == 0), (np.abs(want).sum(axis=-1) == 0)), "which corners keep the geometric normal"
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+    if angle >= 180:
+        assert np.all(np.abs(np.linalg.norm(got, axis=-1) - 1) < 1e-6)
+    if angle == 25.0:     # 36 degrees between the cylinder's facets: nothing is smoothed across them, but each quad's two triangles are
+        assert (np.abs(got).sum(axis=-1) == 0).any() and (np.abs(got).sum(axis=-1) != 0).any()
+    assert yi.endGeometry()

@@ -55,7 +55,7 @@ struct IntegratorCfg
 {
 	std::string type;
 	int path_samples = 32, bounces = 3, rr_min_bounces = 0, raydepth = 5;
-	bool no_recursive = false, bg_transp = false, bg_transp_refract = false;
+	bool no_recursive = false, bg_transp = false, bg_transp_refract = false, transp_shad = false;
 };
 
 struct CameraCfg { yafgpu_camera cam; };
@@ -620,7 +620,7 @@ yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const ch
 		std::string c_method;
 		p.get("raydepth", c.raydepth); p.get("transpShad", transp_shad); p.get("do_AO", do_ao);
 		p.get("bg_transp", c.bg_transp); p.get("bg_transp_refract", c.bg_transp_refract);
-		if(transp_shad) { fail(yi, "createIntegrator: transparent shadows (transpShad) are not supported by the GPU path"); return nullptr; }
+		c.transp_shad = transp_shad;     // checked against the materials at render time (TriKdTree::intersectTs, row K3)
 		if(do_ao) { fail(yi, "createIntegrator: ambient occlusion is not supported by the GPU path"); return nullptr; }
 		if(type == "pathtracing")
 		{	// PathIntegrator::factory, integrator_path_tracer.cc:349-422
@@ -715,6 +715,13 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(premult) return fail(yi, "render: premultiplied alpha is not supported by the GPU path");
 	(void)clamp_indirect;   // only clamps caustic-photon estimates (integrator_path_tracer.cc:160-165), which this path does not have
 	const IntegratorCfg &ic = inte->second->c;
+	if(ic.transp_shad)
+	{	// TriKdTree::intersectTs (kdtree_triangle.cc:983-1162) filters the light through materials that say isTransparent();
+		// with none in the scene it is the any-hit query, which is what runs
+		for(auto *m : yi->material_order)
+			if(m->m.type == YAFGPU_MAT_SHINYDIFFUSE && m->m.is_transparent)   // Material::isTransparent, material_shiny_diffuse.h:53
+				return fail(yi, "render: transparent shadows (transpShad) through a transparent material are not supported by the GPU path");
+	}
 	yafgpu_render_params &rp = yi->rp;
 	std::memset(&rp, 0, sizeof rp);
 	rp.integrator = ic.type == "pathtracing" ? YAFGPU_INTEGRATOR_PATH : YAFGPU_INTEGRATOR_DIRECT;

@@ -411,3 +411,48 @@ def test_smooth_mesh_render(angle, pipeline):
     flat = dict(osc_scene); flat["vnormals"] = None
     ffilm, _ = po.OracleScene(flat).render(rd)
     assert not np.allclose(po.film_to_rgb(ffilm), po.film_to_rgb(ofilm), rtol=1e-3), "smoothing changes the shading"
+
+
+def test_chunked_frames(pipeline, monkeypatch):
+    """A frame larger than one wavefront chunk (YAFGPU_WF_CHUNK caps the paths in flight): pixel tables, masks of the
+    adaptive passes, lens streams and film accumulation must not depend on where the chunk borders fall."""
+    if pipeline == "megakernel":
+        pytest.skip("chunks belong to the wavefront pipeline")
+    sc = scenes.cornell_soup(500, seed=17, res=(100, 90))
+    sc["camera"] = dict(sc["camera"], aperture=0.05, dof_distance=3.9, bokeh_type="pentagon")
+    rd = scenes.render_settings(100, 90, 12, bounces=2, AA_passes=3, AA_inc_samples=9, AA_threshold=0.03, background=(0.1, 0.2, 0.3))
+    def render():
+        yi = Interface()
+        scenes.load_scene(yi, sc, rd)
+        yi.render()
+        return yi.getFilm(100, 90), yi.getRenderStats()
+    whole, st_w = render()
+    monkeypatch.setenv("YAFGPU_WF_CHUNK", "65536")          # 100*90*12 = 108000 paths: two chunks in pass 0
+    parts, st_p = render()
+    assert st_w.camera_samples == st_p.camera_samples and st_w.rays_closest == st_p.rays_closest and st_w.rays_shadow == st_p.rays_shadow
+    assert np.array_equal(whole, parts), "chunked render differs from the one-chunk render"
+    assert len(np.unique(np.round(whole[..., 4]))) >= 2      # the adaptive passes did resample a subset
+
+
+def test_transparent_shadows_flag_with_opaque_materials(pipeline):
+    """transpShad = true selects TriKdTree::intersectTs (kdtree_triangle.cc:983-1162); with no transparent material in
+    the scene it answers like intersectS, so the film equals the transpShad = false one.  With a transparent material
+    the request is refused."""
+    sc = scenes.cornell_soup(200, seed=4, res=(32, 24))
+    rd = scenes.render_settings(32, 24, 4, bounces=2)
+    def render(scene, transp):
+        yi = Interface()
+        scenes.load_scene(yi, scene, rd)
+        yi.paramsClearAll()
+        yi.paramsSet({"type": "pathtracing", "path_samples": 1, "bounces": 2, "russian_roulette_min_bounces": 2, "caustic_type": "none", "transpShad": transp})
+        yi.createIntegrator("ts")
+        yi.paramsClearAll()
+        yi.paramsSet({"camera_name": "cam", "integrator_name": "ts", "volintegrator_name": "volintegr", "width": 32, "height": 24,
+                      "AA_passes": 1, "AA_minsamples": 4, "AA_pixelwidth": 1.0, "filter_type": "box"})
+        yi.render()
+        return yi.getFilm(32, 24)
+    assert np.array_equal(render(sc, True), render(sc, False))
+    glassy = dict(sc); glassy["materials"] = [dict(m) for m in sc["materials"]]
+    glassy["materials"][0]["transparency"] = 0.4
+    with pytest.raises(Exception, match="transparent"):
+        render(glassy, True)

@@ -60,7 +60,6 @@ def test_factories_fail_loudly_outside_scope():
         ("material", {"type": "glossy", "anisotropic": True}, "anisotropic"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
-        ("integrator", {"type": "pathtracing", "transpShad": True}, "transparent shadows"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),
     ]:
         yi.paramsClearAll(); yi.paramsSet(params)

@@ -121,6 +121,8 @@ typedef struct yafgpu_render_params
 	uint32_t pass_offset;          /* samples per pixel taken by the earlier passes (renderPass's `offset`) */
 	int32_t accumulate;            /* add to the planes instead of starting from zero */
 	float aa_clamp_samples;        /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975); 0 = off */
+	int32_t raydepth;              /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791): levels of perfect specular
+	                                  reflection / filtered transmission followed from a camera hit; at most 7 */
 	const uint8_t *resample_mask;  /* HOST pointer, width*height bytes, row-major in window coordinates: the pixels that
 	                                  get samples in this pass (ImageFilm::doMoreSamples, imagefilm.cc:917-920); NULL = all */
 } yafgpu_render_params;

@@ -733,6 +733,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.shadow_bias_auto = auto_bias; rp.shadow_bias = shadow_bias; rp.min_raydist_auto = auto_dist; rp.min_raydist = min_raydist;
 	rp.aa_light_sample_multiplier = 1.f;
 	rp.aa_clamp_samples = clamp_samples;
+	rp.raydepth = ic.raydepth;
 	if(bg) { rp.has_background = 1; for(int k = 0; k < 3; ++k) rp.background[k] = bg->color[k]; }
 	rp.shard_index = yi->shard_index; rp.shard_count = yi->shard_count;
 

@@ -904,6 +904,22 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			o[14] = em.r; o[15] = em.g; o[16] = em.b;
 			break;
 		}
+		case 12:
+		{	// Material::getSpecular + getAlpha: x = material index, n, ng, wo
+			const yafgpu_material &m = sc.mats[__float_as_uint(x[0])];
+			SurfPt sp; sp.n = mk(x[1], x[2], x[3]); sp.ng = mk(x[4], x[5], x[6]); sp.p = mk(0.f, 0.f, 0.f); sp.mat = 0;
+			create_cs(sp.n, sp.nu, sp.nv);
+			const V3 wo = mk(x[7], x[8], x[9]);
+			BsdfDat d;
+			mat_init_bsdf(m, d);
+			bool refl, refr; V3 d0, d1; Col c0, c1;
+			mat_get_specular(m, d, sp, wo, refl, refr, d0, c0, d1, c1);
+			o[0] = __uint_as_float((refl ? 1u : 0u) | (refr ? 2u : 0u));
+			o[1] = d0.x; o[2] = d0.y; o[3] = d0.z; o[4] = c0.r; o[5] = c0.g; o[6] = c0.b;
+			o[7] = d1.x; o[8] = d1.y; o[9] = d1.z; o[10] = c1.r; o[11] = c1.g; o[12] = c1.b;
+			o[13] = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, d, sp, wo) : 1.f;
+			break;
+		}
 		default: break;
 	}
 }
@@ -936,6 +952,7 @@ struct yafgpu_scene
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
+	bool has_specular = false; int wf_frames = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
@@ -1004,11 +1021,13 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if(d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(-3, "triangle material index out of range");
 	for(int i = 0; i < d->n_materials; ++i)
 	{
-		// recursiveRaytrace (integrator_montecarlo.cc:782-1028) is not on the device path yet (row N3)
-		if(d->materials[i].bsdf_flags & (kSpecular | kGlossy | kFilter | kDispersive))
-			return fail(-4, "material with specular/glossy/filter lobes needs recursiveRaytrace, which the GPU path does not implement");
+		// recursiveRaytrace (integrator_montecarlo.cc:782-1028): the perfect specular branch is on the device path (shinydiffuse's
+		// mirror and transparency); its glossy and dispersive branches are not (row N3)
+		if(d->materials[i].bsdf_flags & (kGlossy | kDispersive))
+			return fail(-4, "material with glossy-recursive / dispersive lobes needs recursiveRaytrace branches the GPU path does not implement");
 	}
 	auto *s = new yafgpu_scene();
+	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
 	const auto t0 = std::chrono::steady_clock::now();
 	build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
 	s->info.build_seconds = s->tree.build_seconds;
@@ -1275,7 +1294,10 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(65536u, (uint32_t)std::strtoul(e, nullptr, 10));
 	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
 	const uint32_t cap = chunk_pixels * spp;
-	if(cap > s->wf_cap)
+	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
+	const int frames = (s->has_specular && rp.raydepth > 0) ? rp.raydepth : 0;
+	if(frames > 7) return fail(-17, "raydepth > 7 with mirror / transparent materials: the device path keeps at most 7 recursion frames per sample");
+	if(cap > s->wf_cap || frames > s->wf_frames)
 	{
 		if(s->wf_state) (void)hipFree(s->wf_state);
 		if(s->wf_results) (void)hipFree(s->wf_results);
@@ -1283,7 +1305,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 		if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
 		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_verdict = nullptr; s->wf_pix_xy = nullptr; s->wf_cap = 0;
-		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)kWfRecs * cap * sizeof(float4)));
+		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)(kWfRecs + 5 * frames) * cap * sizeof(float4)));
+		s->wf_frames = frames;
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
 		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
 		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
@@ -1329,7 +1352,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	{
 		WfArgs a{};
 		a.ra = ra;
-		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results;
+		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results; a.frames = frames;
 		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
 		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy; a.pix_listed = masked ? 1 : 0;
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + pb, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -1345,8 +1368,20 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		int rc;
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
 		int cur = 0;
-		for(int it = 0; it < iters; ++it)
+		// Without recursion the number of queries per path is bounded a priori (iters) and the loop never asks the
+		// device anything.  With recursiveRaytrace a sample may visit up to 2^raydepth levels, so past that bound the
+		// loop runs on while any queue is non-empty (one 20-byte read-back per iteration).
+		const int iter_cap = iters * (frames > 0 ? (1 << (frames + 1)) : 1);
+		for(int it = 0; it < iter_cap; ++it)
 		{
+			if(frames > 0 && it >= iters)
+			{
+				uint32_t pending[5];
+				HIP_OK(hipMemcpyAsync(pending, a.cnt_in, sizeof pending, hipMemcpyDeviceToHost, stream));
+				HIP_OK(hipStreamSynchronize(stream));
+				if(pending[0] == 0u && pending[1] == 0u && pending[4] == 0u) break;
+			}
+			else if(frames == 0 && it >= iters) break;
 			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 8 * sizeof(uint32_t), stream));
 			if((rc = timed(0, [&] {
 				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
@@ -1452,6 +1487,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(!mega) return render_wavefront(s, ra, stream, stats);
 		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
 		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
+		if(s->has_specular && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent materials");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)
 			return fail(-15, "the one-kernel pipeline renders single-pass films only; use the wavefront pipeline");
 	}

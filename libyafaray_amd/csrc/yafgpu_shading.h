@@ -240,6 +240,43 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 	return 1.f - (1.f - d.c0 * kr) * d.c1;
 }
 
+// ShinyDiffuseMaterial::getSpecular, material_shiny_diffuse.cc:474-528 (no shader nodes, no wireframe): the perfect
+// reflection and the filtered straight-through transmission recursiveRaytrace follows.  Every other material of this
+// path keeps Material::getSpecular's default (neither).
+YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, bool &do_reflect, bool &do_refract,
+                             V3 &dir_reflect, Col &col_reflect, V3 &dir_refract, Col &col_refract)
+{
+	do_reflect = false; do_refract = false;
+	dir_reflect = mk(0.f, 0.f, 0.f); dir_refract = dir_reflect; col_reflect = mkc(0.f, 0.f, 0.f); col_refract = col_reflect;
+	if(m.type != YAFGPU_MAT_SHINYDIFFUSE) return;
+	const bool backface = dot(wo, sp.ng) < 0.f;
+	const V3 n = backface ? -sp.n : sp.n;
+	const V3 ng = backface ? -sp.ng : sp.ng;
+	const float kr = sd_fresnel(m, wo, n);
+	if(m.is_transparent)
+	{
+		do_refract = true;
+		dir_refract = -wo;
+		const float f = m.transmit_filter;
+		const Col tcol = col3(m.diffuse_color) * f + mkc(1.f - f, 1.f - f, 1.f - f);
+		col_refract = tcol * ((1.f - d.c0 * kr) * d.c1);
+	}
+	if(m.is_mirror)
+	{
+		do_reflect = true;
+		const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);        // Vec3::reflect, vector.h:291-298
+		V3 r = mk(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+		const float cos_wi_ng = dot(r, ng);
+		if((double)cos_wi_ng < 0.01)
+		{
+			const float k = (float)(0.01 - (double)cos_wi_ng);
+			r = normalize(r + ng * k);
+		}
+		dir_reflect = r;
+		col_reflect = col3(m.mirror_color) * (d.c0 * kr);
+	}
+}
+
 // Material::sample — material_shiny_diffuse.cc:308-408, material_glossy.cc:176-357 (Blinn branch),
 // material_simple.cc:41-46
 YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)

@@ -28,6 +28,7 @@ struct WfArgs
 	float4 *results;                  // final rgba per path
 	uint32_t n_paths, pixel_begin, n_pixels;
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
+	int frames;                       // levels of recursiveRaytrace frames behind the kWfRecs records (0: none allocated)
 	int pix_listed;                   // the chunk's pixels are given by pix_xy (a resample mask picked them), not by the tile list
 	uint32_t *pix_xy;                 // px | py << 16 per pixel of the chunk: written by wf_generate, so that resuming a path
 	                                  // costs one load instead of a binary search over the tile prefix (9 dependent loads)
@@ -154,19 +155,20 @@ YG_DEV float4 &wf_rec(const WfArgs &a, int k, uint32_t slot)
 }
 #define REC(k) wf_rec(a, (k), slot)
 
-struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i; };
-YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.depth << 8) | ((uint32_t)c.path_i << 16); }
+struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl; };   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_
+YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.incl << 16) | ((uint32_t)c.path_i << 17); }
 YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 {
 	const float4 r = REC(13);
 	const uint32_t w = ubits(r.w);
 	Ctl c; c.col = c3(r);
-	c.pc = (int)(w & 3u); c.stage = (int)((w >> 2) & 3u); c.dl_on_sp0 = (int)((w >> 4) & 1u); c.depth = (int)((w >> 8) & 0xffu); c.path_i = (int)(w >> 16);
+	c.pc = (int)(w & 3u); c.stage = (int)((w >> 2) & 3u); c.dl_on_sp0 = (int)((w >> 4) & 1u); c.level = (int)((w >> 5) & 7u);
+	c.depth = (int)((w >> 8) & 0xffu); c.incl = (int)((w >> 16) & 1u); c.path_i = (int)(w >> 17);
 	return c;
 }
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
 
-enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
+enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECURSE, W_RETURN, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
 
 // register-resident copies of records 11, 12, 14, 18 (and, with YAFGPU_HOT_ACC, the accumulators 15..17) during
 // one advance (see wf_advance); the other records of the 11..18 range go straight to memory
@@ -239,8 +241,9 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		{
 			if(rp.has_background && !rp.bg_transp_refract) c.col = c.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
 			REC(19) = make_float4(0.f, 0.f, 0.f, alpha);
-			return W_FINISH;
+			return W_RETURN;
 		}
+		if(c.level == 0) c.incl = 1;                                                         // integrator_path_tracer.cc:129-135
 		const float4 r0 = REC(0), r1 = REC(1);
 		const V3 dir = v3(r1);
 		SurfPt sp0;
@@ -249,7 +252,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		BsdfDat dat0;
 		const uint32_t bsdfs0 = mat_init_bsdf(m, dat0);
 		const V3 wo0 = -dir;
-		if(bsdfs0 & kEmit) c.col = c.col + mat_emit(m, sp0, wo0, true);                       // :152 (include_lights_ :133)
+		if(bsdfs0 & kEmit) c.col = c.col + mat_emit(m, sp0, wo0, c.incl != 0);                // :152 (include_lights_ :133)
 		alpha = 1.f;
 		if(rp.bg_transp_refract)
 		{
@@ -413,7 +416,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 		const uint32_t bsdfs0 = ubits(REC(5).w);
 		if(bsdfs0 & kDiffuse) c.col = c.col + total;                                            // :156
 		const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
-		if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) return W_FINISH;
+		if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) return W_RECURSE;
 		c.path_i = 0;
 		return W_START_PATH;
 	}
@@ -490,7 +493,8 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
-	if(c.path_i >= n_paths) { c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_FINISH; } // :297
+	if(c.path_i >= n_paths) { c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
+	c.incl = 0;                                                                                   // :211 state.include_lights_ = false
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
 	const V3 wo0 = v3(REC(6));
@@ -514,6 +518,80 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	c.stage = kStFirst;
 	return W_PARK_CLOSEST;
 }
+
+// recursiveRaytrace, integrator_montecarlo.cc:782-1028 — the perfect specular branch (:971-1025): the level's own
+// radiance is complete; follow the reflected and the (filtered, straight-through) transmitted ray with a full
+// integrate() each, one level deeper.  The call stack is a frame per level behind the working records:
+//   F0 colour so far | alpha without a transmitted ray     F1 transmission weight | material alpha
+//   F2 hit point | flags (1: transmitted ray still to go, 2: it is the one out now)
+//   F3 transmitted direction                                 F4 reflection weight
+#define FREC(L, j) wf_rec(a, kWfRecs + 5 * (L) + (j), slot)
+YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
+{
+	REC(0) = f4(p, a.ra.ray_min_dist); REC(1) = f4(dir, -1.f);      // DiffRay(sp.p_, dir, scene_->ray_min_dist_)
+	c.stage = kStPrimary; c.depth = 0; c.path_i = 0; c.dl_on_sp0 = 0;
+}
+YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	if(c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
+	const float4 r5 = REC(5);
+	if(!(ubits(r5.w) & (kSpecular | kFilter))) return W_RETURN;
+	const float4 p = REC(3);
+	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(r5), (int)ubits(p.w), sp0);
+	const V3 wo0 = v3(REC(6));
+	const yafgpu_material &m = sc.mats[sp0.mat];
+	BsdfDat dat0; mat_init_bsdf(m, dat0);
+	c.incl = 1;                                                                       // :973
+	bool refl, refr; V3 d_refl, d_refr; Col c_refl, c_refr;
+	mat_get_specular(m, dat0, sp0, wo0, refl, refr, d_refl, c_refl, d_refr, c_refr);
+	if(!refl && !refr) return W_RETURN;
+	const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+	const int L = c.level;
+	FREC(L, 0) = f4(c.col, REC(19).w);
+	FREC(L, 1) = f4(c_refr, m_alpha);
+	FREC(L, 2) = f4(sp0.p, fbits(refl ? (refr ? 1u : 0u) : 2u));
+	FREC(L, 3) = f4(d_refr, 0.f);
+	FREC(L, 4) = f4(c_refl, 0.f);
+	wf_start_level(a, slot, c, sp0.p, refl ? d_refl : d_refr);
+	c.level = L + 1;
+	return W_PARK_CLOSEST;
+}
+// an integrate() ends with (c.col, alpha): hand it to the level above, which either sends its transmitted ray or ends too
+YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const yafgpu_render_params &rp = a.ra.rp;
+	float alpha = REC(19).w;
+	for(;;)
+	{
+		if(rp.bg_transp) alpha = smax(alpha, 0.f);      // EmptyVolumeIntegrator: transmittance 1 (integrator_path_tracer.cc:336-344)
+		if(c.level == 0) { REC(19) = make_float4(0.f, 0.f, 0.f, alpha); return W_FINISH; }
+		const int P = c.level - 1;
+		const float4 f0 = FREC(P, 0), f2 = FREC(P, 2);
+		const uint32_t flags = ubits(f2.w);
+		const Col integ = c.col;
+		if(!(flags & 2u))
+		{	// :980-990 the reflected ray is back
+			const Col col_p = c3(f0) + integ * c3(FREC(P, 4));
+			if(flags & 1u)
+			{	// :991-1023 now the transmitted one, at the same level
+				FREC(P, 0) = f4(col_p, f0.w);
+				FREC(P, 2) = f4(v3(f2), fbits(2u));
+				wf_start_level(a, slot, c, v3(f2), v3(FREC(P, 3)));
+				return W_PARK_CLOSEST;
+			}
+			c.col = col_p; alpha = f0.w;
+		}
+		else
+		{
+			const float4 f1 = FREC(P, 1);
+			c.col = c3(f0) + integ * c3(f1);
+			alpha = rp.bg_transp_refract ? f1.w + (1.f - f1.w) * alpha : 1.f;             // :1022 alpha = integ.a_, then integrator_path_tracer.cc:321-326
+		}
+		c.level = P;
+	}
+}
+#undef FREC
 
 // Resume a parked path and run it to its next kd-tree query (or to its end).
 YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4], int &out_mask)
@@ -542,6 +620,8 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
 	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs);
+	if(where == W_RECURSE) where = st_recurse(a, slot, c);
+	if(where == W_RETURN) where = st_return(a, slot, c);
 	if(where != W_FINISH) hot_flush(a, slot, h);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }

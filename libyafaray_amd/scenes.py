@@ -109,6 +109,7 @@ def load_scene(yi, scene, render):
         yi.createBackground("world_background")
     yi.paramsClearAll()
     integ = {"type": render.get("integrator", "pathtracing")}
+    integ["raydepth"] = 5      # MonteCarloIntegrator's default r_depth_, spelled out so that oracle and device agree
     for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth"):
         if k in render:
             integ[k] = render[k]

@@ -391,8 +391,8 @@ static void run_material(Json &j, const char *prefix, Material *mat, int n_cases
 	RenderState state(nullptr);
 	state.userdata_ = (void *)userdata;
 	state.include_lights_ = true;
-	std::vector<uint32_t> in, ev, sm, pd;
-	std::vector<int> flags_out, sflags_in, sflags_out;
+	std::vector<uint32_t> in, ev, sm, pd, spec, alph;
+	std::vector<int> flags_out, sflags_in, sflags_out, spec_flags;
 	for(int i = 0; i < n_cases; ++i)
 	{
 		SurfacePoint sp;
@@ -425,12 +425,24 @@ static void run_material(Json &j, const char *prefix, Material *mat, int n_cases
 		sflags_in.push_back((int)sf);
 		sflags_out.push_back((int)s.sampled_flags_);
 		pushc(sm, sc); pushv(sm, wi); sm.push_back(f2u(s.pdf_)); sm.push_back(f2u(w));
+		// perfect specular directions and weights for recursiveRaytrace, and the alpha of transparent materials
+		bool refl = false, refr = false;
+		Vec3 sdir[2] = {Vec3(0.f), Vec3(0.f)};
+		Rgb scol[2] = {Rgb(0.f), Rgb(0.f)};
+		mat->initBsdf(state, sp, bsdfs);
+		mat->getSpecular(state, sp, wo, refl, refr, sdir, scol);
+		spec_flags.push_back((refl ? 1 : 0) | (refr ? 2 : 0));
+		if(!refl) { sdir[0] = Vec3(0.f); scol[0] = Rgb(0.f); }
+		if(!refr) { sdir[1] = Vec3(0.f); scol[1] = Rgb(0.f); }
+		pushv(spec, sdir[0]); pushc(spec, scol[0]); pushv(spec, sdir[1]); pushc(spec, scol[1]);
+		alph.push_back(f2u(mat->getAlpha(state, sp, wo)));
 	}
 	std::string p(prefix);
 	j.arr_u32((p + "_in14").c_str(), in); j.arr_i32((p + "_flags").c_str(), flags_out);
 	j.arr_u32((p + "_eval3").c_str(), ev); j.arr_u32((p + "_pdf").c_str(), pd);
 	j.arr_i32((p + "_sflags_in").c_str(), sflags_in); j.arr_i32((p + "_sflags_out").c_str(), sflags_out);
 	j.arr_u32((p + "_sample8").c_str(), sm);
+	j.arr_i32((p + "_specflags").c_str(), spec_flags); j.arr_u32((p + "_spec12").c_str(), spec); j.arr_u32((p + "_alpha").c_str(), alph);
 }
 
 static void sec_materials(Json &j)
@@ -451,6 +463,21 @@ static void sec_materials(Json &j)
 		pm["emit"] = Parameter(0.1f);
 		Material *m = ShinyDiffuseMaterial::factory(pm, no_nodes, fake_env());
 		run_material(j, "sd1", m, 240, true);
+	}
+	{	// sd3: mirror without fresnel over a diffuse base
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.6f, 0.6f, 0.7f, 1.f)); pm["mirror_color"] = Parameter(Rgba(0.9f, 0.8f, 0.7f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.7f); pm["specular_reflect"] = Parameter(0.45f);
+		Material *m = ShinyDiffuseMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "sd3", m, 160, true);
+	}
+	{	// sd4: transparent + mirror with fresnel, no translucency
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.5f, 0.8f, 0.6f, 1.f)); pm["mirror_color"] = Parameter(Rgba(1.f, 1.f, 1.f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.6f); pm["specular_reflect"] = Parameter(0.5f); pm["transparency"] = Parameter(0.6f);
+		pm["fresnel_effect"] = Parameter(true); pm["IOR"] = Parameter(1.33f); pm["transmit_filter"] = Parameter(0.4f);
+		Material *m = ShinyDiffuseMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "sd4", m, 160, true);
 	}
 	{	// sd2: oren-nayar
 		ParamMap pm;

@@ -1214,6 +1214,42 @@ static float sd_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 	return 1.f;
 }
 
+/* ShinyDiffuseMaterial::getSpecular, material_shiny_diffuse.cc:474-528 (no shader nodes, no wireframe);
+ * every other material of this path keeps Material::getSpecular's default: neither */
+static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, int *do_reflect, int *do_refract, v3 wi[2], rgb col[2])
+{
+	*do_reflect = 0; *do_refract = 0;
+	if(m->type != YOR_MAT_SHINYDIFFUSE) return;
+	const int backface = vdot(wo, sp->ng) < 0.f;
+	const v3 n = backface ? vneg(sp->n) : sp->n;
+	const v3 ng = backface ? vneg(sp->ng) : sp->ng;
+	float kr = sd_fresnel(m, wo, n);
+	if(m->is_transparent)
+	{
+		*do_refract = 1;
+		wi[1] = vneg(wo);
+		float f = m->transmit_filter;
+		rgb tcol = cadd(cscale(m->diffuse_color, f), C(1.f - f, 1.f - f, 1.f - f));
+		col[1] = cscale(tcol, (1.f - dat->component[0] * kr) * dat->component[1]);
+	}
+	if(m->is_mirror)
+	{
+		*do_reflect = 1;
+		/* Vec3::reflect, vector.h:291-298 */
+		const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);
+		v3 r = V(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+		float cos_wi_ng = vdot(r, ng);
+		if((double)cos_wi_ng < 0.01)
+		{
+			float k = (float)(0.01 - (double)cos_wi_ng);
+			r = vadd(r, vmul(ng, k));
+			r = vnormalize(r);
+		}
+		wi[0] = r;
+		col[0] = cscale(m->mirror_color, dat->component[0] * kr);
+	}
+}
+
 static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 *wi, sample_t *s, float *w)
 {
 	if(m->type == YOR_MAT_SHINYDIFFUSE)
@@ -1824,7 +1860,7 @@ static rgb estimate_one_direct_light(rstate_t *st, const sp_t *sp, const mat_t *
 
 /* PathIntegrator::integrate, integrator_path_tracer.cc:112-347 (raylevel 0, no caustics, no
  * recursive raytrace: materials with specular/glossy/filter lobes are rejected by yor_render) */
-static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, float out_rgba[4])
+static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, float out_rgba[4])
 {
 	const yor_scene *s = st->s;
 	const yor_render_desc *rd = st->rd;
@@ -1836,7 +1872,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, flo
 	else alpha = 1.0f;
 	if(scene_intersect(s, from, dir, tmin, &tmax, &sp, &st->cn))
 	{
-		st->include_lights = 1; /* raylevel_ == 0, :131-135 */
+		if(raylevel == 0) st->include_lights = 1; /* :129-135 */
 		unsigned bsdfs;
 		bsdf_dat dat0;
 		const mat_t *material = &s->mats[sp.mat];
@@ -1907,6 +1943,28 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, flo
 				}
 			}
 			col = cadd(col, cdiv(path_col, (float)n_samples));
+		}
+		/* recursiveRaytrace, integrator_montecarlo.cc:782-1028: the perfect specular branch (:971-1025); no dispersive
+		 * or glossy-recursive materials on this path, additional depth and transparent bias 0 */
+		if(raylevel + 1 <= rd->raydepth && (bsdfs & (BSDF_SPECULAR | BSDF_FILTER)) && raylevel + 1 < 20)
+		{
+			st->include_lights = 1;
+			int reflect = 0, refract = 0;
+			v3 sdir[2]; rgb rcol[2];
+			mat_get_specular(material, &dat0, &sp, wo, &reflect, &refract, sdir, rcol);
+			if(reflect)
+			{
+				float integ[4];
+				integrate(st, sp.p, sdir[0], st->ray_min_dist, -1.0f, raylevel + 1, integ);
+				col = cadd(col, cmul(C(integ[0], integ[1], integ[2]), rcol[0]));
+			}
+			if(refract)
+			{
+				float integ[4];
+				integrate(st, sp.p, sdir[1], st->ray_min_dist, -1.0f, raylevel + 1, integ);
+				col = cadd(col, cmul(C(integ[0], integ[1], integ[2]), rcol[1]));
+				alpha = integ[3];
+			}
 		}
 		if(rd->bg_transp_refract)
 		{
@@ -2120,7 +2178,7 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 				camera_shoot_lens(cam, j + dx, i + dy, lens_u, lens_v, &from, &dir, &tmin, &tmax, &wt);
 				wk->camera_samples++;
 				float c[4];
-				integrate(st, from, dir, tmin, tmax, c);
+				integrate(st, from, dir, tmin, tmax, 0, c);
 				if(c[3] > 1.f) c[3] = 1.f;                 /* :459 */
 				c[0] *= wt; c[1] *= wt; c[2] *= wt; c[3] *= wt; /* :512 */
 				film_add_sample(wk->film, c, j, i, dx, dy, wk->n_threads > 1 ? &wk->deferred : NULL);
@@ -2319,7 +2377,7 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 	if(rd->aa_passes < 1) return -1;
 	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
 	for(int i = 0; i < s->n_mats; ++i)
-		if(s->mats[i].flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace not restated */
+		if(s->mats[i].flags & (BSDF_GLOSSY | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace: only the perfect specular branch is restated */
 	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
 	if(rd->aa_passes > 1 && rd->shard_count > 1) return -6; /* the noise detection needs the whole frame */
 	struct timespec t0, t1;
@@ -2487,6 +2545,24 @@ void yor_material_probe(const yor_material_desc *md, const float in14[14], int32
 	rgb sc = mat_sample(&m, &dat, &sp, wo, &wi, &s, &w);
 	*sampled_flags = (int32_t)s.sampled_flags;
 	sample8[0] = sc.r; sample8[1] = sc.g; sample8[2] = sc.b; sample8[3] = wi.x; sample8[4] = wi.y; sample8[5] = wi.z; sample8[6] = s.pdf; sample8[7] = w;
+}
+void yor_material_specular(const yor_material_desc *md, const float in14[14], int32_t *flags, float out12[12], float *alpha)
+{
+	mat_t m; mat_configure(&m, md);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.n = V(in14[0], in14[1], in14[2]); sp.ng = V(in14[3], in14[4], in14[5]);
+	create_cs(sp.n, &sp.nu, &sp.nv);
+	v3 wo = V(in14[6], in14[7], in14[8]);
+	bsdf_dat dat; unsigned bf;
+	mat_init_bsdf(&m, &dat, &bf);
+	int refl = 0, refr = 0; v3 d[2] = {V(0, 0, 0), V(0, 0, 0)}; rgb c[2] = {C(0, 0, 0), C(0, 0, 0)};
+	mat_get_specular(&m, &dat, &sp, wo, &refl, &refr, d, c);
+	*flags = (refl ? 1 : 0) | (refr ? 2 : 0);
+	if(!refl) { d[0] = V(0, 0, 0); c[0] = C(0, 0, 0); }
+	if(!refr) { d[1] = V(0, 0, 0); c[1] = C(0, 0, 0); }
+	out12[0] = d[0].x; out12[1] = d[0].y; out12[2] = d[0].z; out12[3] = c[0].r; out12[4] = c[0].g; out12[5] = c[0].b;
+	out12[6] = d[1].x; out12[7] = d[1].y; out12[8] = d[1].z; out12[9] = c[1].r; out12[10] = c[1].g; out12[11] = c[1].b;
+	*alpha = (m.type == YOR_MAT_SHINYDIFFUSE) ? sd_alpha(&m, &dat, &sp, wo) : 1.f;
 }
 void yor_lightmat_emit(const yor_material_desc *md, const float n[3], const float wo[3], int include_lights, float out3[3])
 {

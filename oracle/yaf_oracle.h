@@ -132,6 +132,7 @@ typedef struct yor_render_desc
 	float aa_dark_threshold_factor;
 	int32_t aa_variance_edge_size, aa_variance_pixels;
 	float aa_clamp_samples;            /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975) */
+	int32_t raydepth;                  /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791); 0 behaves like "no recursion" */
 } yor_render_desc;
 
 typedef struct yor_stats
@@ -197,6 +198,8 @@ int yor_arealight_illum_sample(const yor_light_desc *l, const float p[3], float 
 int yor_arealight_intersect(const yor_light_desc *l, const float from[3], const float dir[3], float out5[5]);
 int yor_pointlight_illuminate(const yor_light_desc *l, const float p[3], float out7[7]);
 /* in14 = n, ng, wo, wl, s1, s2 ; outputs as in the harness */
+/* Material::getSpecular + getAlpha: flags bit0 reflect, bit1 refract; out12 = dir0, col0, dir1, col1 */
+void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t *flags, float out12[12], float *alpha);
 void yor_material_probe(const yor_material_desc *m, const float in14[14], int32_t sample_flags,
                         int32_t *bsdf_flags, float eval3[3], float *pdf, int32_t *sampled_flags, float sample8[8]);
 void yor_lightmat_emit(const yor_material_desc *m, const float n[3], const float wo[3], int include_lights, float out3[3]);

@@ -138,8 +138,6 @@ def test_lights(gold, probe_scene):
 @pytest.mark.parametrize("name", sorted(MATERIALS))
 def test_materials(gold, probe_scene, name):
     g = gold
-    if name == "sd1":
-        pytest.skip("sd1 has mirror/transparent lobes, which the GPU path rejects at scene creation (row N3)")
     sc, names = probe_scene
     s2 = dict(sc); s2["materials"] = [MATERIALS[name]]
     yi = make_iface(s2)
@@ -152,3 +150,8 @@ def test_materials(gold, probe_scene, name):
     exact(o[:, 4], g[f"{name}_pdf"], f"{name} pdf")
     assert np.array_equal(o[:, 5].view(np.uint32), g[f"{name}_sflags_out"].astype(np.uint32)), "sampled flags"
     exact(o[:, 6:14], g[f"{name}_sample8"], f"{name} sample")
+    # Material::getSpecular (recursiveRaytrace's perfect reflection / filtered transmission) and getAlpha
+    s = yi.probe(12, x[:, :10], 14)
+    assert np.array_equal(s[:, 0].view(np.uint32), g[f"{name}_specflags"].astype(np.uint32)), "getSpecular flags"
+    exact(s[:, 1:13], g[f"{name}_spec12"], f"{name} getSpecular")
+    exact(s[:, 13], g[f"{name}_alpha"], f"{name} getAlpha")

@@ -456,3 +456,25 @@ def test_transparent_shadows_flag_with_opaque_materials(pipeline):
     glassy["materials"][0]["transparency"] = 0.4
     with pytest.raises(Exception, match="transparent"):
         render(glassy, True)
+
+
+@pytest.mark.parametrize("raydepth,integrator", [(1, "pathtracing"), (3, "pathtracing"), (5, "pathtracing"), (4, "directlighting")])
+def test_recursive_raytrace_mirror_and_transparency(raydepth, integrator, pipeline):
+    """recursiveRaytrace's perfect specular branch (integrator_montecarlo.cc:971-1025) for shinydiffusemat's mirror
+    (with and without Fresnel) and transparency (filtered, straight through): a full integrate() per followed ray, one
+    level deeper, alpha from the transmitted ray.  Frames per level behind the parked records; the iteration loop
+    runs until the queues are empty."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(260, seed=13, res=(48, 40))
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"][0].update({"specular_reflect": 0.5, "mirror_color": (0.9, 0.9, 1.0)})
+    sc["materials"][1].update({"transparency": 0.5, "transmit_filter": 0.6, "specular_reflect": 0.3, "fresnel_effect": True, "IOR": 1.4})
+    sc["materials"][2].update({"transparency": 0.7, "transmit_filter": 0.2})
+    rd = scenes.render_settings(48, 40, 4, bounces=2, integrator=integrator, raydepth=raydepth, background=(0.2, 0.3, 0.4),
+                                bg_transp=True, bg_transp_refract=True)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"recursive raytrace depth {raydepth} {integrator}")
+    flat, _ = po.OracleScene(sc).render(dict(rd, raydepth=0))
+    assert not np.allclose(po.film_to_rgb(flat), po.film_to_rgb(ofilm), rtol=1e-3), "the recursion changes the image"

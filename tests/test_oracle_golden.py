@@ -224,6 +224,9 @@ MATERIALS = {
             "specular_reflect": 0.3, "transparency": 0.2, "translucency": 0.25, "fresnel_effect": True, "IOR": 1.45,
             "transmit_filter": 0.7, "emit": 0.1},
     "sd2": {"type": "shinydiffusemat", "color": (0.5, 0.7, 0.4), "diffuse_reflect": 1.0, "diffuse_brdf": "oren_nayar", "sigma": 0.35},
+    "sd3": {"type": "shinydiffusemat", "color": (0.6, 0.6, 0.7), "mirror_color": (0.9, 0.8, 0.7), "diffuse_reflect": 0.7, "specular_reflect": 0.45},
+    "sd4": {"type": "shinydiffusemat", "color": (0.5, 0.8, 0.6), "mirror_color": (1.0, 1.0, 1.0), "diffuse_reflect": 0.6,
+            "specular_reflect": 0.5, "transparency": 0.6, "fresnel_effect": True, "IOR": 1.33, "transmit_filter": 0.4},
     "gl0": {"type": "glossy", "color": (0.9, 0.85, 0.8), "diffuse_color": (0.4, 0.5, 0.6), "diffuse_reflect": 0.4,
             "glossy_reflect": 0.6, "exponent": 50.0, "as_diffuse": True},
     "gl1": {"type": "glossy", "color": (1, 1, 1), "glossy_reflect": 0.8, "exponent": 500.0, "as_diffuse": True},
@@ -255,6 +258,16 @@ def test_materials(gold, name):
         same = np.array(sfo) == g[f"{name}_sflags_out"]
         assert same.mean() > 0.98  # a lobe pick exactly on a threshold may flip under -ffast-math
         check(variant, np.array(sm, np.float32).reshape(-1, 8)[same], g[f"{name}_sample8"].reshape(-1, 8)[same], f"{name} sample")
+    # Material::getSpecular (recursiveRaytrace's perfect reflection / filtered transmission) and getAlpha
+    sf, sp12, al = [], [], []
+    o12 = np.zeros(12, np.float32)
+    for i in range(inp.shape[0]):
+        f = C.c_int32(); a = C.c_float()
+        L.yor_material_specular(C.byref(md), po.fptr(inp[i]), C.byref(f), po.fptr(o12), C.byref(a))
+        sf.append(f.value); sp12.extend(o12.tolist()); al.append(a.value)
+    assert sf == [int(v) for v in g[f"{name}_specflags"]]
+    check(variant, sp12, g[f"{name}_spec12"], f"{name} getSpecular")
+    check(variant, al, g[f"{name}_alpha"], f"{name} getAlpha")
 
 
 def test_light_material(gold):

@@ -28,7 +28,7 @@ extern "C" {
 #define YAFGPU_FILM_CHANNELS 5   /* r,g,b,a,weight : Pixel, include/utility/util_image_buffers.h:36-48 */
 #define YAFGPU_FILM_PLANES   4   /* own, right, down, diagonal splat planes */
 
-enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2 };
+enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2, YAFGPU_MAT_GLASS = 3, YAFGPU_MAT_MIRROR = 4 };
 enum { YAFGPU_LIGHT_AREA = 0, YAFGPU_LIGHT_POINT = 1 };
 enum { YAFGPU_INTEGRATOR_PATH = 0, YAFGPU_INTEGRATOR_DIRECT = 1 };
 enum { YAFGPU_FILTER_BOX = 0, YAFGPU_FILTER_MITCHELL = 1, YAFGPU_FILTER_GAUSS = 2, YAFGPU_FILTER_LANCZOS = 3 };
@@ -56,7 +56,12 @@ typedef struct yafgpu_material
 	/* light material */
 	float light_col[3];
 	int32_t double_sided;
-	int32_t pad[7];
+	/* glass (material_glass.cc:32-49; mirror_color = specular reflection colour) and mirror (mirror_color = colour * reflect) */
+	float glass_ior;
+	float filter_color[3];         /* transmit_filter * filter_color + (1 - transmit_filter) */
+	int32_t fake_shadow;
+	uint32_t tm_flags;             /* the transmission lobe: Filter|Transmit with fake shadows, else Specular|Transmit */
+	int32_t pad[1];
 } yafgpu_material;
 
 /* A light after its constructor ran on the host (light_area.cc:34-52, light_point.cc:28-36) */

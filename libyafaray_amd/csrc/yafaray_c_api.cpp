@@ -229,6 +229,42 @@ bool make_lightmat(const ParamMap &p, yafgpu_material &m)
 	return true;
 }
 
+// GlassMaterial::factory + ctor, material_glass.cc:340-443, :32-49 (no dispersion, absorption or shader nodes)
+bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+{
+	double ior = 1.4, filt = 0.0, disp = 0.0; float fcol[3] = {1, 1, 1}, scol[3] = {1, 1, 1}, absorp[3] = {1, 1, 1}, wire = 0.f;
+	bool fake = false, recv = true; std::string vis = "normal"; int add_depth = 0;
+	p.get("IOR", ior); p.getColor("filter_color", fcol); p.get("transmit_filter", filt); p.getColor("mirror_color", scol);
+	p.get("dispersion_power", disp); p.get("fake_shadows", fake); p.get("receive_shadows", recv); p.get("visibility", vis);
+	p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire); p.getColor("absorption", absorp);
+	if(disp > 0.0) return fail(yi, "glass: dispersion is not supported by the GPU path (recursiveRaytrace's dispersive branch)");
+	if(absorp[0] < 1.f || absorp[1] < 1.f || absorp[2] < 1.f) return fail(yi, "glass: absorption (a volume handler) is not supported by the GPU path");
+	if(add_depth != 0) return fail(yi, "glass: additionaldepth is not supported by the GPU path");
+	if(wire != 0.f) return fail(yi, "glass: wireframe shading is not supported by the GPU path");
+	if(!yi->eparams.empty()) return fail(yi, "glass: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_GLASS; m.receive_shadows = recv; m.visibility = visibility_from(vis);
+	m.glass_ior = (float)ior;
+	const float ff = (float)filt, fc = (float)(1.f - filt);       // filt * filt_col + Rgb(1.f - filt)
+	for(int k = 0; k < 3; ++k) { m.filter_color[k] = ff * fcol[k] + fc; m.mirror_color[k] = scol[k]; }
+	m.fake_shadow = fake;
+	m.bsdf_flags = 0x1u | 0x10u | 0x20u;                         // BsdfAllSpecular
+	if(fake) m.bsdf_flags |= 0x40u;
+	m.tm_flags = fake ? (0x40u | 0x20u) : (0x1u | 0x20u);
+	return true;
+}
+// MirrorMaterial::factory + ctor, material_glass.cc:486-493, material_glass.h:74-79
+bool make_mirror(const ParamMap &p, yafgpu_material &m)
+{
+	float col[3] = {1, 1, 1}, refl = 1.f;
+	p.getColor("color", col); p.get("reflect", refl);
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_MIRROR; m.receive_shadows = 1;
+	for(int k = 0; k < 3; ++k) m.mirror_color[k] = col[k] * refl;
+	m.bsdf_flags = 0x1u;
+	return true;
+}
+
 // AreaLight::factory + ctor, light_area.cc:169-205, :34-52
 bool make_arealight(const ParamMap &p, yafgpu_light &l)
 {
@@ -549,7 +585,9 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m);
 	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
-	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, light_mat)"); return nullptr; }
+	else if(type == "glass") ok = make_glass(yi, yi->params, m->m);
+	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
+	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, light_mat, glass, mirror)"); return nullptr; }
 	if(!ok) return nullptr;
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();
@@ -719,7 +757,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	{	// TriKdTree::intersectTs (kdtree_triangle.cc:983-1162) filters the light through materials that say isTransparent();
 		// with none in the scene it is the any-hit query, which is what runs
 		for(auto *m : yi->material_order)
-			if(m->m.type == YAFGPU_MAT_SHINYDIFFUSE && m->m.is_transparent)   // Material::isTransparent, material_shiny_diffuse.h:53
+			if((m->m.type == YAFGPU_MAT_SHINYDIFFUSE && m->m.is_transparent) || (m->m.type == YAFGPU_MAT_GLASS && m->m.fake_shadow))   // Material::isTransparent
 				return fail(yi, "render: transparent shadows (transpShad) through a transparent material are not supported by the GPU path");
 	}
 	yafgpu_render_params &rp = yi->rp;

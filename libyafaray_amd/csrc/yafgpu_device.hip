@@ -482,7 +482,7 @@ YG_DEV void integrate(const RenderArgs &ra, LaneStack &stk, V3 from, V3 dir, flo
 			alpha = 1.f;
 			if(rp.bg_transp_refract)
 			{
-				const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+				const float m_alpha = mat_alpha(m, dat0, sp0, wo0);
 				alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
 			}
 			const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
@@ -913,11 +913,11 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			BsdfDat d;
 			mat_init_bsdf(m, d);
 			bool refl, refr; V3 d0, d1; Col c0, c1;
-			mat_get_specular(m, d, sp, wo, refl, refr, d0, c0, d1, c1);
+			mat_get_specular(m, d, sp, wo, (n_in >= 11) ? (int)x[10] : 1, refl, refr, d0, c0, d1, c1);
 			o[0] = __uint_as_float((refl ? 1u : 0u) | (refr ? 2u : 0u));
 			o[1] = d0.x; o[2] = d0.y; o[3] = d0.z; o[4] = c0.r; o[5] = c0.g; o[6] = c0.b;
 			o[7] = d1.x; o[8] = d1.y; o[9] = d1.z; o[10] = c1.r; o[11] = c1.g; o[12] = c1.b;
-			o[13] = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, d, sp, wo) : 1.f;
+			o[13] = mat_alpha(m, d, sp, wo);
 			break;
 		}
 		default: break;

@@ -240,14 +240,96 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 	return 1.f - (1.f - d.c0 * kr) * d.c1;
 }
 
+// refract__, vector.cc:86-108
+YG_DEV bool refract_dir(V3 n, V3 wi, V3 &wo, float ior)
+{
+	V3 N = n;
+	float eta = ior;
+	const V3 i = -wi;
+	float cos_v_n = dot(wi, n);
+	if(cos_v_n < 0.f) { N = -n; cos_v_n = -cos_v_n; }
+	else eta = (float)(1.0 / (double)ior);
+	const float k = 1.f - eta * eta * (1.f - cos_v_n * cos_v_n);
+	if(k <= 0.f) return false;
+	wo = normalize(i * eta + N * (eta * cos_v_n - f_sqrt(k)));
+	return true;
+}
+// fresnel__, vector.cc:110-142 (kr is formed in double)
+YG_DEV void fresnel_dielectric(V3 i, V3 n, float ior, float &kr, float &kt)
+{
+	const float eta = ior;
+	const V3 N = (dot(i, n) < 0.f) ? -n : n;
+	const float c = dot(i, N);
+	float g = eta * eta + c * c - 1.f;
+	g = (g <= 0.f) ? 0.f : f_sqrt(g);
+	const float aux = c * (g + c);
+	kr = (float)(((0.5 * (double)(g - c) * (double)(g - c)) / (double)((g + c) * (g + c))) *
+	             (double)(1.f + ((aux - 1.f) * (aux - 1.f)) / ((aux + 1.f) * (aux + 1.f))));
+	kt = (kr < 1.0f) ? 1.f - kr : 0.f;
+}
+// the shading normal the glass uses, material_glass.cc:77-80, 263-271
+YG_DEV V3 glass_normal(const SurfPt &sp, V3 wo)
+{
+	const bool outside = dot(sp.ng, wo) > 0.f;
+	const float cos_wo_n = dot(sp.n, wo);
+	if(outside ? (cos_wo_n >= 0.f) : (cos_wo_n <= 0.f)) return sp.n;
+	const float f = (float)(1.00001 * (double)cos_wo_n);
+	return normalize(sp.n - wo * f);
+}
+YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
+{
+	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
+	return mk(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
+}
+// Material::getAlpha: ShinyDiffuse (:568-597), Glass (material_glass.cc:217-240), everything else 1
+YG_DEV float mat_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE) return sd_alpha(m, d, sp, wo);
+	if(m.type == YAFGPU_MAT_GLASS)
+	{
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		float kr, kt;
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		const Col t = col3(m.filter_color) * kt;
+		const float alpha = (float)(1.0 - (double)((t.r + t.g + t.b) * 0.333333f));
+		return alpha < 0.f ? 0.f : alpha;
+	}
+	return 1.f;
+}
+
 // ShinyDiffuseMaterial::getSpecular, material_shiny_diffuse.cc:474-528 (no shader nodes, no wireframe): the perfect
 // reflection and the filtered straight-through transmission recursiveRaytrace follows.  Every other material of this
 // path keeps Material::getSpecular's default (neither).
-YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, bool &do_reflect, bool &do_refract,
+// GlassMaterial::getSpecular (material_glass.cc:242-340, no dispersion) and MirrorMaterial::getSpecular (:475-484) too.
+// raylevel: RenderState::raylevel_ as getSpecular sees it — recursiveRaytrace has already incremented it.
+YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, int raylevel, bool &do_reflect, bool &do_refract,
                              V3 &dir_reflect, Col &col_reflect, V3 &dir_refract, Col &col_refract)
 {
 	do_reflect = false; do_refract = false;
 	dir_reflect = mk(0.f, 0.f, 0.f); dir_refract = dir_reflect; col_reflect = mkc(0.f, 0.f, 0.f); col_refract = col_reflect;
+	if(m.type == YAFGPU_MAT_GLASS)
+	{
+		const bool outside = dot(sp.ng, wo) > 0.f;
+		const V3 n = glass_normal(sp, wo);
+		V3 refdir;
+		if(refract_dir(n, wo, refdir, m.glass_ior))
+		{
+			float kr, kt;
+			fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+			col_refract = col3(m.filter_color) * kt; dir_refract = refdir; do_refract = true;
+			// the reflection of a ray leaving the glass is only followed near the top of the recursion (:324-332)
+			if(outside || raylevel < 3) { dir_reflect = vec_reflect(wo, n); col_reflect = col3(m.mirror_color) * kr; do_reflect = true; }
+		}
+		else { col_reflect = col3(m.mirror_color); dir_reflect = vec_reflect(wo, n); do_reflect = true; }      // total inner reflection
+		return;
+	}
+	if(m.type == YAFGPU_MAT_MIRROR)
+	{
+		col_reflect = col3(m.mirror_color);
+		dir_reflect = reflect_dir(face_forward(sp.ng, sp.n, wo), wo);
+		do_reflect = true;
+		return;
+	}
 	if(m.type != YAFGPU_MAT_SHINYDIFFUSE) return;
 	const bool backface = dot(wo, sp.ng) < 0.f;
 	const V3 n = backface ? -sp.n : sp.n;
@@ -281,6 +363,44 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 // material_simple.cc:41-46
 YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
 {
+	if(m.type == YAFGPU_MAT_GLASS)
+	{	// GlassMaterial::sample, material_glass.cc:65-215, the branch without dispersion (:143-213)
+		if(!(s.flags & kSpecular)) { s.pdf = 0.f; return mkc(0.f, 0.f, 0.f); }
+		const V3 n = glass_normal(sp, wo);
+		V3 refdir;
+		s.pdf = 1.f;
+		const uint32_t spec_refl = kSpecular | kReflect;
+		if(refract_dir(n, wo, refdir, m.glass_ior))
+		{
+			float kr, kt;
+			fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+			const float p_kr = (float)(0.01 + 0.99 * (double)kr), p_kt = (float)(0.01 + 0.99 * (double)kt);
+			if(s.s_1 < p_kt && ((s.flags & m.tm_flags) == m.tm_flags))
+			{
+				wi = refdir; s.pdf = p_kt; s.sampled = m.tm_flags; w = 1.f;
+				return col3(m.filter_color);
+			}
+			else if((s.flags & spec_refl) == spec_refl)
+			{
+				wi = vec_reflect(wo, n); s.pdf = p_kr; s.sampled = spec_refl; w = 1.f;
+				return col3(m.mirror_color);
+			}
+		}
+		else if((s.flags & spec_refl) == spec_refl)
+		{	// total inner reflection
+			wi = vec_reflect(wo, n); s.sampled = spec_refl; w = 1.f;
+			return mkc(1.f, 1.f, 1.f);
+		}
+		s.pdf = 0.f;
+		return mkc(0.f, 0.f, 0.f);
+	}
+	if(m.type == YAFGPU_MAT_MIRROR)
+	{	// MirrorMaterial::sample, material_glass.cc:467-473: flags ignored, pdf left at Sample's initial 0
+		wi = reflect_dir(sp.n, wo);
+		s.sampled = kSpecular | kReflect;
+		w = 1.f;
+		return col3(m.mirror_color) * (1.f / fabsf(dot(sp.n, wi)));
+	}
 	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
 	{
 		float acc[4];

@@ -256,7 +256,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		alpha = 1.f;
 		if(rp.bg_transp_refract)
 		{
-			const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+			const float m_alpha = mat_alpha(m, dat0, sp0, wo0);
 			alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
 		}
 		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
@@ -544,9 +544,9 @@ YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 	BsdfDat dat0; mat_init_bsdf(m, dat0);
 	c.incl = 1;                                                                       // :973
 	bool refl, refr; V3 d_refl, d_refr; Col c_refl, c_refr;
-	mat_get_specular(m, dat0, sp0, wo0, refl, refr, d_refl, c_refl, d_refr, c_refr);
+	mat_get_specular(m, dat0, sp0, wo0, c.level + 1, refl, refr, d_refl, c_refl, d_refr, c_refr);
 	if(!refl && !refr) return W_RETURN;
-	const float m_alpha = (m.type == YAFGPU_MAT_SHINYDIFFUSE) ? sd_alpha(m, dat0, sp0, wo0) : 1.f;
+	const float m_alpha = mat_alpha(m, dat0, sp0, wo0);
 	const int L = c.level;
 	FREC(L, 0) = f4(c.col, REC(19).w);
 	FREC(L, 1) = f4(c_refr, m_alpha);

@@ -138,7 +138,7 @@ def lib():
     L.yor_arealight_intersect.argtypes = [C.POINTER(LightDesc), fp, fp, fp]
     L.yor_pointlight_illuminate.restype = C.c_int
     L.yor_pointlight_illuminate.argtypes = [C.POINTER(LightDesc), fp, fp]
-    L.yor_material_specular.argtypes = [C.POINTER(MaterialDesc), fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_float)]
+    L.yor_material_specular.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, C.POINTER(C.c_float)]
     L.yor_material_probe.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, fp,
                                      C.POINTER(C.c_int32), fp]
     L.yor_lightmat_emit.argtypes = [C.POINTER(MaterialDesc), fp, fp, C.c_int, fp]
@@ -185,6 +185,20 @@ def material_desc(m):
         d.as_diffuse = int(m.get("as_diffuse", True))
         d.oren_nayar = int(m.get("diffuse_brdf", "") == "Oren-Nayar")
         d.sigma = m.get("sigma", 0.1)
+    elif t == "glass":
+        d.type = 3
+        d.color = f3(*m.get("filter_color", (1, 1, 1))[:3])
+        d.mirror_color = f3(*m.get("mirror_color", (1, 1, 1))[:3])
+        d.ior = m.get("IOR", 1.4)
+        d.sigma = m.get("transmit_filter", 0.0)          # a double parameter: filt * filt_col + (1 - filt)
+        d.fresnel_effect = int(m.get("fake_shadows", False))
+        for k in ("dispersion_power", "absorption"):
+            if k in m and m[k] not in (0, 0.0, (1, 1, 1), (1.0, 1.0, 1.0)):
+                raise ValueError("glass: dispersion / absorption are outside the restated path")
+    elif t == "mirror":
+        d.type = 4
+        d.color = f3(*m.get("color", (1, 1, 1))[:3])
+        d.specular_reflect = m.get("reflect", 1.0)
     elif t == "light_mat":
         d.type = MAT_LIGHT
         d.light_color = f3(*m.get("color", (1, 1, 1))[:3])

@@ -33,6 +33,7 @@
 #include "common/surface.h"
 #include "common/scene.h"
 #include "camera/camera_perspective.h"
+#include "material/material_glass.h"
 #include "light/light_area.h"
 #include "light/light_point.h"
 #include "material/material_shiny_diffuse.h"
@@ -385,12 +386,13 @@ static void sec_lights(Json &j)
 
 struct MatCase { const char *name; ParamMap pm; };
 
-static void run_material(Json &j, const char *prefix, Material *mat, int n_cases, bool with_flags_variants)
+static void run_material(Json &j, const char *prefix, Material *mat, int n_cases, bool with_flags_variants, int raylevel = 1)
 {
 	alignas(16) static unsigned char userdata[4096];
 	RenderState state(nullptr);
 	state.userdata_ = (void *)userdata;
 	state.include_lights_ = true;
+	state.raylevel_ = raylevel;      // recursiveRaytrace increments it before it asks for the specular directions
 	std::vector<uint32_t> in, ev, sm, pd, spec, alph;
 	std::vector<int> flags_out, sflags_in, sflags_out, spec_flags;
 	for(int i = 0; i < n_cases; ++i)
@@ -478,6 +480,28 @@ static void sec_materials(Json &j)
 		pm["fresnel_effect"] = Parameter(true); pm["IOR"] = Parameter(1.33f); pm["transmit_filter"] = Parameter(0.4f);
 		Material *m = ShinyDiffuseMaterial::factory(pm, no_nodes, fake_env());
 		run_material(j, "sd4", m, 160, true);
+	}
+	{	// gg0: glass, filtered transmission, tinted reflection (entering and leaving rays; raylevel 1 and 4: the
+		// reflection of a ray leaving the glass is only followed below level 3, material_glass.cc:327)
+		ParamMap pm;
+		pm["IOR"] = Parameter(1.52); pm["filter_color"] = Parameter(Rgba(0.6f, 0.9f, 0.7f, 1.f)); pm["transmit_filter"] = Parameter(0.8);
+		pm["mirror_color"] = Parameter(Rgba(0.95f, 0.9f, 1.f, 1.f));
+		Material *m = GlassMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "gg0", m, 200, true, 1);
+		run_material(j, "gg0d", m, 120, true, 4);
+	}
+	{	// gg1: glass with fake shadows (filter lobe instead of specular transmission), higher index
+		ParamMap pm;
+		pm["IOR"] = Parameter(2.1); pm["filter_color"] = Parameter(Rgba(1.f, 0.5f, 0.5f, 1.f)); pm["transmit_filter"] = Parameter(0.3);
+		pm["fake_shadows"] = Parameter(true);
+		Material *m = GlassMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "gg1", m, 160, true, 2);
+	}
+	{	// mi0: mirror
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.9f, 0.8f, 0.6f, 1.f)); pm["reflect"] = Parameter(0.85f);
+		Material *m = MirrorMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "mi0", m, 120, true, 1);
 	}
 	{	// sd2: oren-nayar
 		ParamMap pm;

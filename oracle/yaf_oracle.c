@@ -420,6 +420,9 @@ typedef struct
 	int as_diffuse, with_diffuse;
 	/* light mat */
 	rgb light_col; int double_sided;
+	/* glass (material_glass.cc:32-49) and mirror (material_glass.h:74-79) */
+	float ior; rgb filter_color, spec_refl_color; int fake_shadow; unsigned tm_flags;
+	rgb ref_col;
 } mat_t;
 
 typedef struct
@@ -975,6 +978,23 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 			m->use_oren = 1;
 		}
 	}
+	else if(d->type == YOR_MAT_GLASS)
+	{	/* GlassMaterial::factory + ctor, material_glass.cc:32-49, 340-388 (no dispersion, no absorption, no nodes) */
+		m->ior = d->ior;
+		const double filt = d->sigma;                                    /* transmit_filter, a double parameter */
+		const float ff = (float)filt, fc = (float)(1.f - filt);          /* filt * filt_col + Rgb(1.f - filt) */
+		m->filter_color = C(ff * d->color[0] + fc, ff * d->color[1] + fc, ff * d->color[2] + fc);
+		m->spec_refl_color = C(d->mirror_color[0], d->mirror_color[1], d->mirror_color[2]);
+		m->fake_shadow = d->fresnel_effect;
+		m->flags = BSDF_SPECULAR | BSDF_REFLECT | BSDF_TRANSMIT;          /* BsdfAllSpecular */
+		if(m->fake_shadow) m->flags |= BSDF_FILTER;
+		m->tm_flags = m->fake_shadow ? (BSDF_FILTER | BSDF_TRANSMIT) : (BSDF_SPECULAR | BSDF_TRANSMIT);
+	}
+	else if(d->type == YOR_MAT_MIRROR)
+	{	/* MirrorMaterial, material_glass.h:74-79, material_glass.cc:486-493 */
+		m->ref_col = cscale(C(d->color[0], d->color[1], d->color[2]), d->specular_reflect);
+		m->flags = BSDF_SPECULAR;
+	}
 	else
 	{
 		/* material_simple.cc:36-39,63-73: col * (float)power */
@@ -1037,6 +1057,50 @@ static float oren_nayar(float oren_a, float oren_b, v3 wi, v3 wo, v3 n)
 		tan_beta = yor_fsqrt(1.f - cos_ti * cos_ti) / ((cos_ti == 0.f) ? 1e-8f : cos_ti);
 	}
 	return fminf_(1.f, fmaxf_(0.f, (float)(oren_a + oren_b * maxcos_f * sin_alpha * tan_beta)));
+}
+
+/* refract__, vector.cc:86-108 */
+static int refract_dir(v3 n, v3 wi, v3 *wo, float ior)
+{
+	v3 N = n, i;
+	float eta = ior;
+	i = vneg(wi);
+	float cos_v_n = vdot(wi, n);
+	if((cos_v_n) < 0)
+	{
+		N = vneg(n);
+		cos_v_n = -cos_v_n;
+	}
+	else eta = (float)(1.0 / (double)ior);
+	float k = 1 - eta * eta * (1 - cos_v_n * cos_v_n);
+	if(k <= 0.f) return 0;
+	*wo = vadd(vmul(i, eta), vmul(N, eta * cos_v_n - yor_fsqrt(k)));
+	*wo = vnormalize(*wo);
+	return 1;
+}
+/* fresnel__, vector.cc:110-142 (kr is formed in double) */
+static void fresnel_dielectric(v3 i, v3 n, float ior, float *kr, float *kt)
+{
+	float eta = ior;
+	v3 N = (vdot(i, n) < 0) ? vneg(n) : n;
+	float c = vdot(i, N);
+	float g = eta * eta + c * c - 1;
+	if(g <= 0) g = 0;
+	else g = yor_fsqrt(g);
+	float aux = c * (g + c);
+	*kr = (float)(((0.5 * (double)(g - c) * (double)(g - c)) / (double)((g + c) * (g + c))) *
+	              (double)(1 + ((aux - 1) * (aux - 1)) / ((aux + 1) * (aux + 1))));
+	if(*kr < 1.0) *kt = 1 - *kr;
+	else *kt = 0;
+}
+/* the shading normal the glass uses, material_glass.cc:77-80, 263-271 */
+static v3 glass_normal(const sp_t *sp, v3 wo)
+{
+	int outside = vdot(sp->ng, wo) > 0;
+	float cos_wo_n = vdot(sp->n, wo);
+	if(outside ? (cos_wo_n >= 0) : (cos_wo_n <= 0)) return sp->n;
+	float f = (float)(1.00001 * (double)cos_wo_n);
+	return vnormalize(vsub(sp->n, vmul(wo, f)));
 }
 
 static void mat_init_bsdf(const mat_t *m, bsdf_dat *dat, unsigned *bsdf_types)
@@ -1216,9 +1280,51 @@ static float sd_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 
 /* ShinyDiffuseMaterial::getSpecular, material_shiny_diffuse.cc:474-528 (no shader nodes, no wireframe);
  * every other material of this path keeps Material::getSpecular's default: neither */
-static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, int *do_reflect, int *do_refract, v3 wi[2], rgb col[2])
+/* GlassMaterial::getTransparency / getAlpha, material_glass.cc:217-240 */
+static float glass_alpha(const mat_t *m, const sp_t *sp, v3 wo)
+{
+	v3 n = face_forward(sp->ng, sp->n, wo);
+	float kr, kt;
+	fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+	rgb t = cscale(m->filter_color, kt);
+	float alpha = (float)(1.0 - (double)((t.r + t.g + t.b) * 0.333333f));
+	if(alpha < 0.0f) alpha = 0.0f;
+	return alpha;
+}
+/* Material::getAlpha of the materials on this path */
+static float mat_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE) return sd_alpha(m, dat, sp, wo);
+	if(m->type == YOR_MAT_GLASS) return glass_alpha(m, sp, wo);
+	return 1.f;
+}
+/* raylevel: RenderState::raylevel_ as getSpecular sees it (recursiveRaytrace has already incremented it) */
+static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, int raylevel, int *do_reflect, int *do_refract, v3 wi[2], rgb col[2])
 {
 	*do_reflect = 0; *do_refract = 0;
+	if(m->type == YOR_MAT_GLASS)
+	{	/* GlassMaterial::getSpecular, material_glass.cc:242-340 (no dispersion) */
+		int outside = vdot(sp->ng, wo) > 0;
+		v3 n = glass_normal(sp, wo), refdir;
+		const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);
+		const v3 refl = V(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+		if(refract_dir(n, wo, &refdir, m->ior))
+		{
+			float kr, kt;
+			fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+			col[1] = cscale(m->filter_color, kt); wi[1] = refdir; *do_refract = 1;
+			if(outside || raylevel < 3) { wi[0] = refl; col[0] = cscale(m->spec_refl_color, kr); *do_reflect = 1; }
+		}
+		else { col[0] = m->spec_refl_color; wi[0] = refl; *do_reflect = 1; }
+		return;
+	}
+	if(m->type == YOR_MAT_MIRROR)
+	{	/* MirrorMaterial::getSpecular, material_glass.cc:475-484 */
+		col[0] = m->ref_col;
+		wi[0] = reflect_dir(face_forward(sp->ng, sp->n, wo), wo);
+		*do_reflect = 1;
+		return;
+	}
 	if(m->type != YOR_MAT_SHINYDIFFUSE) return;
 	const int backface = vdot(wo, sp->ng) < 0.f;
 	const v3 n = backface ? vneg(sp->n) : sp->n;
@@ -1252,6 +1358,47 @@ static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp
 
 static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 *wi, sample_t *s, float *w)
 {
+	if(m->type == YOR_MAT_GLASS)
+	{	/* GlassMaterial::sample, material_glass.cc:65-215, the branch without dispersion (:143-213) */
+		if(!(s->flags & BSDF_SPECULAR)) { s->pdf = 0.f; return C(0, 0, 0); }
+		v3 refdir, n = glass_normal(sp, wo);
+		s->pdf = 1.f;
+		const unsigned spec_refl = BSDF_SPECULAR | BSDF_REFLECT;
+		if(refract_dir(n, wo, &refdir, m->ior))
+		{
+			float kr, kt;
+			fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+			float p_kr = (float)(0.01 + 0.99 * (double)kr), p_kt = (float)(0.01 + 0.99 * (double)kt);
+			if(s->s_1 < p_kt && ((s->flags & m->tm_flags) == m->tm_flags))
+			{
+				*wi = refdir; s->pdf = p_kt; s->sampled_flags = m->tm_flags; *w = 1.f;
+				return m->filter_color;
+			}
+			else if((s->flags & spec_refl) == spec_refl)
+			{
+				const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);
+				*wi = V(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+				s->pdf = p_kr; s->sampled_flags = spec_refl; *w = 1.f;
+				return m->spec_refl_color;
+			}
+		}
+		else if((s->flags & spec_refl) == spec_refl)
+		{	/* total inner reflection */
+			const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);
+			*wi = V(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+			s->sampled_flags = spec_refl; *w = 1.f;
+			return C(1.f, 1.f, 1.f);
+		}
+		s->pdf = 0.f;
+		return C(0, 0, 0);
+	}
+	if(m->type == YOR_MAT_MIRROR)
+	{	/* MirrorMaterial::sample, material_glass.cc:467-473: flags ignored, pdf left at Sample's initial 0 */
+		*wi = reflect_dir(sp->n, wo);
+		s->sampled_flags = BSDF_SPECULAR | BSDF_REFLECT;
+		*w = 1.f;
+		return cscale(m->ref_col, 1.f / fabsf(vdot(sp->n, *wi)));
+	}
 	if(m->type == YOR_MAT_SHINYDIFFUSE)
 	{	/* material_shiny_diffuse.cc:308-408 */
 		float accum_c[4];
@@ -1951,7 +2098,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 			st->include_lights = 1;
 			int reflect = 0, refract = 0;
 			v3 sdir[2]; rgb rcol[2];
-			mat_get_specular(material, &dat0, &sp, wo, &reflect, &refract, sdir, rcol);
+			mat_get_specular(material, &dat0, &sp, wo, raylevel + 1, &reflect, &refract, sdir, rcol);
 			if(reflect)
 			{
 				float integ[4];
@@ -1968,7 +2115,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		}
 		if(rd->bg_transp_refract)
 		{
-			float m_alpha = (material->type == YOR_MAT_SHINYDIFFUSE) ? sd_alpha(material, &dat0, &sp, wo) : 1.f;
+			float m_alpha = mat_alpha(material, &dat0, &sp, wo);
 			alpha = m_alpha + (1.f - m_alpha) * alpha;
 		}
 		else alpha = 1.0f;
@@ -2546,7 +2693,7 @@ void yor_material_probe(const yor_material_desc *md, const float in14[14], int32
 	*sampled_flags = (int32_t)s.sampled_flags;
 	sample8[0] = sc.r; sample8[1] = sc.g; sample8[2] = sc.b; sample8[3] = wi.x; sample8[4] = wi.y; sample8[5] = wi.z; sample8[6] = s.pdf; sample8[7] = w;
 }
-void yor_material_specular(const yor_material_desc *md, const float in14[14], int32_t *flags, float out12[12], float *alpha)
+void yor_material_specular(const yor_material_desc *md, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha)
 {
 	mat_t m; mat_configure(&m, md);
 	sp_t sp; memset(&sp, 0, sizeof sp);
@@ -2556,13 +2703,13 @@ void yor_material_specular(const yor_material_desc *md, const float in14[14], in
 	bsdf_dat dat; unsigned bf;
 	mat_init_bsdf(&m, &dat, &bf);
 	int refl = 0, refr = 0; v3 d[2] = {V(0, 0, 0), V(0, 0, 0)}; rgb c[2] = {C(0, 0, 0), C(0, 0, 0)};
-	mat_get_specular(&m, &dat, &sp, wo, &refl, &refr, d, c);
+	mat_get_specular(&m, &dat, &sp, wo, raylevel, &refl, &refr, d, c);
 	*flags = (refl ? 1 : 0) | (refr ? 2 : 0);
 	if(!refl) { d[0] = V(0, 0, 0); c[0] = C(0, 0, 0); }
 	if(!refr) { d[1] = V(0, 0, 0); c[1] = C(0, 0, 0); }
 	out12[0] = d[0].x; out12[1] = d[0].y; out12[2] = d[0].z; out12[3] = c[0].r; out12[4] = c[0].g; out12[5] = c[0].b;
 	out12[6] = d[1].x; out12[7] = d[1].y; out12[8] = d[1].z; out12[9] = c[1].r; out12[10] = c[1].g; out12[11] = c[1].b;
-	*alpha = (m.type == YOR_MAT_SHINYDIFFUSE) ? sd_alpha(&m, &dat, &sp, wo) : 1.f;
+	*alpha = mat_alpha(&m, &dat, &sp, wo);
 }
 void yor_lightmat_emit(const yor_material_desc *md, const float n[3], const float wo[3], int include_lights, float out3[3])
 {

@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-enum { YOR_MAT_SHINYDIFFUSE = 0, YOR_MAT_GLOSSY = 1, YOR_MAT_LIGHT = 2 };
+enum { YOR_MAT_SHINYDIFFUSE = 0, YOR_MAT_GLOSSY = 1, YOR_MAT_LIGHT = 2,
+       YOR_MAT_GLASS = 3,   /* color = filter_color, mirror_color, ior = IOR, sigma = transmit_filter (double), fresnel_effect = fake_shadows */
+       YOR_MAT_MIRROR = 4   /* color, specular_reflect = reflect */ };
 enum { YOR_LIGHT_AREA = 0, YOR_LIGHT_POINT = 1 };
 enum { YOR_INTEGRATOR_PATH = 0, YOR_INTEGRATOR_DIRECT = 1 };
 enum { YOR_FILTER_BOX = 0, YOR_FILTER_MITCHELL = 1, YOR_FILTER_GAUSS = 2, YOR_FILTER_LANCZOS = 3 };
@@ -199,7 +201,7 @@ int yor_arealight_intersect(const yor_light_desc *l, const float from[3], const 
 int yor_pointlight_illuminate(const yor_light_desc *l, const float p[3], float out7[7]);
 /* in14 = n, ng, wo, wl, s1, s2 ; outputs as in the harness */
 /* Material::getSpecular + getAlpha: flags bit0 reflect, bit1 refract; out12 = dir0, col0, dir1, col1 */
-void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t *flags, float out12[12], float *alpha);
+void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha);
 void yor_material_probe(const yor_material_desc *m, const float in14[14], int32_t sample_flags,
                         int32_t *bsdf_flags, float eval3[3], float *pdf, int32_t *sampled_flags, float sample8[8]);
 void yor_lightmat_emit(const yor_material_desc *m, const float n[3], const float wo[3], int include_lights, float out3[3]);

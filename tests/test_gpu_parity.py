@@ -478,3 +478,25 @@ def test_recursive_raytrace_mirror_and_transparency(raydepth, integrator, pipeli
     compare_films(film, ofilm, f"recursive raytrace depth {raydepth} {integrator}")
     flat, _ = po.OracleScene(sc).render(dict(rd, raydepth=0))
     assert not np.allclose(po.film_to_rgb(flat), po.film_to_rgb(ofilm), rtol=1e-3), "the recursion changes the image"
+
+
+@pytest.mark.parametrize("raydepth", [2, 6])
+def test_glass_and_mirror_materials(raydepth, pipeline):
+    """GlassMaterial (refraction, Fresnel reflection, total inner reflection, the level-3 cut of reflections inside the
+    glass, with and without fake shadows) and MirrorMaterial through recursiveRaytrace and as path bounces."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(300, seed=29, res=(52, 44), sigma=0.06)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.7, 0.95, 0.8), "transmit_filter": 0.9, "mirror_color": (1.0, 0.95, 0.9)})
+    sc["materials"].append({"type": "mirror", "color": (0.9, 0.85, 0.7), "reflect": 0.9})
+    sc["materials"].append({"type": "glass", "IOR": 1.9, "filter_color": (1.0, 0.6, 0.6), "transmit_filter": 0.5, "fake_shadows": True})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    free = np.arange(10, len(tm))                     # the soup triangles (the first ten are the walls)
+    tm[free[0::3]] = nm - 3; tm[free[1::5]] = nm - 2; tm[free[2::7]] = nm - 1
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(52, 44, 4, bounces=3, raydepth=raydepth, background=(0.3, 0.3, 0.5), bg_transp=True, bg_transp_refract=True)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"glass + mirror, raydepth {raydepth}")

@@ -218,6 +218,9 @@ def test_lights(gold):
     check(variant, got, g["pl_out7"], "PointLight::illuminate")
 
 
+# RenderState::raylevel_ when the golden getSpecular calls were made (GlassMaterial::getSpecular depends on it)
+SPEC_RAYLEVEL = {"gg0d": 4, "gg1": 2}
+
 MATERIALS = {
     "sd0": {"type": "shinydiffusemat", "color": (0.7, 0.6, 0.5), "diffuse_reflect": 0.9},
     "sd1": {"type": "shinydiffusemat", "color": (0.8, 0.3, 0.2), "mirror_color": (0.9, 0.95, 1.0), "diffuse_reflect": 0.8,
@@ -227,6 +230,10 @@ MATERIALS = {
     "sd3": {"type": "shinydiffusemat", "color": (0.6, 0.6, 0.7), "mirror_color": (0.9, 0.8, 0.7), "diffuse_reflect": 0.7, "specular_reflect": 0.45},
     "sd4": {"type": "shinydiffusemat", "color": (0.5, 0.8, 0.6), "mirror_color": (1.0, 1.0, 1.0), "diffuse_reflect": 0.6,
             "specular_reflect": 0.5, "transparency": 0.6, "fresnel_effect": True, "IOR": 1.33, "transmit_filter": 0.4},
+    "gg0": {"type": "glass", "IOR": 1.52, "filter_color": (0.6, 0.9, 0.7), "transmit_filter": 0.8, "mirror_color": (0.95, 0.9, 1.0)},
+    "gg0d": {"type": "glass", "IOR": 1.52, "filter_color": (0.6, 0.9, 0.7), "transmit_filter": 0.8, "mirror_color": (0.95, 0.9, 1.0)},
+    "gg1": {"type": "glass", "IOR": 2.1, "filter_color": (1.0, 0.5, 0.5), "transmit_filter": 0.3, "fake_shadows": True},
+    "mi0": {"type": "mirror", "color": (0.9, 0.8, 0.6), "reflect": 0.85},
     "gl0": {"type": "glossy", "color": (0.9, 0.85, 0.8), "diffuse_color": (0.4, 0.5, 0.6), "diffuse_reflect": 0.4,
             "glossy_reflect": 0.6, "exponent": 50.0, "as_diffuse": True},
     "gl1": {"type": "glossy", "color": (1, 1, 1), "glossy_reflect": 0.8, "exponent": 500.0, "as_diffuse": True},
@@ -263,7 +270,7 @@ def test_materials(gold, name):
     o12 = np.zeros(12, np.float32)
     for i in range(inp.shape[0]):
         f = C.c_int32(); a = C.c_float()
-        L.yor_material_specular(C.byref(md), po.fptr(inp[i]), C.byref(f), po.fptr(o12), C.byref(a))
+        L.yor_material_specular(C.byref(md), po.fptr(inp[i]), SPEC_RAYLEVEL.get(name, 1), C.byref(f), po.fptr(o12), C.byref(a))
         sf.append(f.value); sp12.extend(o12.tolist()); al.append(a.value)
     assert sf == [int(v) for v in g[f"{name}_specflags"]]
     check(variant, sp12, g[f"{name}_spec12"], f"{name} getSpecular")

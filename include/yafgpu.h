@@ -126,6 +126,9 @@ typedef struct yafgpu_render_params
 	uint32_t pass_offset;          /* samples per pixel taken by the earlier passes (renderPass's `offset`) */
 	int32_t accumulate;            /* add to the planes instead of starting from zero */
 	float aa_clamp_samples;        /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975); 0 = off */
+	int32_t transp_shad;           /* tr_shad_: shadow rays are filtered by transparent materials instead of blocked
+	                                  (TriKdTree::intersectTs, kdtree_triangle.cc:983-1162) */
+	int32_t shadow_depth;          /* s_depth_: more distinct transparent surfaces than this along a shadow ray block it; at most 8 */
 	int32_t raydepth;              /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791): levels of perfect specular
 	                                  reflection / filtered transmission followed from a camera hit; at most 7 */
 	const uint8_t *resample_mask;  /* HOST pointer, width*height bytes, row-major in window coordinates: the pixels that

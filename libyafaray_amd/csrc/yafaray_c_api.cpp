@@ -56,6 +56,7 @@ struct IntegratorCfg
 	std::string type;
 	int path_samples = 32, bounces = 3, rr_min_bounces = 0, raydepth = 5;
 	bool no_recursive = false, bg_transp = false, bg_transp_refract = false, transp_shad = false;
+	int shadow_depth = 5;            // integrator_path_tracer.cc:352, integrator_direct_light.cc:201
 };
 
 struct CameraCfg { yafgpu_camera cam; };
@@ -656,7 +657,7 @@ yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const ch
 	{
 		bool transp_shad = false, do_ao = false, caustics = false;
 		std::string c_method;
-		p.get("raydepth", c.raydepth); p.get("transpShad", transp_shad); p.get("do_AO", do_ao);
+		p.get("raydepth", c.raydepth); p.get("shadowDepth", c.shadow_depth); p.get("transpShad", transp_shad); p.get("do_AO", do_ao);
 		p.get("bg_transp", c.bg_transp); p.get("bg_transp_refract", c.bg_transp_refract);
 		c.transp_shad = transp_shad;     // checked against the materials at render time (TriKdTree::intersectTs, row K3)
 		if(do_ao) { fail(yi, "createIntegrator: ambient occlusion is not supported by the GPU path"); return nullptr; }
@@ -753,13 +754,6 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(premult) return fail(yi, "render: premultiplied alpha is not supported by the GPU path");
 	(void)clamp_indirect;   // only clamps caustic-photon estimates (integrator_path_tracer.cc:160-165), which this path does not have
 	const IntegratorCfg &ic = inte->second->c;
-	if(ic.transp_shad)
-	{	// TriKdTree::intersectTs (kdtree_triangle.cc:983-1162) filters the light through materials that say isTransparent();
-		// with none in the scene it is the any-hit query, which is what runs
-		for(auto *m : yi->material_order)
-			if((m->m.type == YAFGPU_MAT_SHINYDIFFUSE && m->m.is_transparent) || (m->m.type == YAFGPU_MAT_GLASS && m->m.fake_shadow))   // Material::isTransparent
-				return fail(yi, "render: transparent shadows (transpShad) through a transparent material are not supported by the GPU path");
-	}
 	yafgpu_render_params &rp = yi->rp;
 	std::memset(&rp, 0, sizeof rp);
 	rp.integrator = ic.type == "pathtracing" ? YAFGPU_INTEGRATOR_PATH : YAFGPU_INTEGRATOR_DIRECT;
@@ -772,6 +766,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.aa_light_sample_multiplier = 1.f;
 	rp.aa_clamp_samples = clamp_samples;
 	rp.raydepth = ic.raydepth;
+	rp.transp_shad = ic.transp_shad ? 1 : 0; rp.shadow_depth = ic.shadow_depth;
 	if(bg) { rp.has_background = 1; for(int k = 0; k < 3; ++k) rp.background[k] = bg->color[k]; }
 	rp.shard_index = yi->shard_index; rp.shard_count = yi->shard_count;
 

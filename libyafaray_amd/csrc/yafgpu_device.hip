@@ -305,6 +305,75 @@ YG_DEV void get_surface(const DevScene &sc, int ti, V3 hitp, float bu, float bv,
 	create_cs(sp.n, sp.nu, sp.nv);
 }
 
+// Transparent shadows: TriKdTree::intersectTs, kdtree_triangle.cc:983-1162.  Every triangle with ray_tmin <= t < dist
+// whose material casts shadows either blocks the ray (opaque), or — once per triangle, the reference's std::set
+// `filtered` — multiplies its transparency into filt; more than max_depth transparent triangles block it too.  The
+// product is taken in visiting order, as there (so its last bits depend on tree topology, there as here).
+constexpr int kTsMaxDepth = 8;
+YG_DEV bool kd_trace_ts(const DevScene &sc, LaneStack &stk, uint32_t *seen /* [kTsMaxDepth + 1] */, V3 from, V3 dir, float ray_tmin, float dist,
+                        int max_depth, Col &filt)
+{
+	filt = mkc(1.f, 1.f, 1.f);
+	float a, b;
+	if(sc.n_nodes == 0u) return false;
+	const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+	if(!bound_cross(sc, from, dir, inv_dir, dist, a, b)) return false;
+	const float t_exit = b;
+	float tmin = smax(a, 0.f), tmax = t_exit;
+	uint32_t node = 0u;
+	int depth = 0, n_seen = 0;
+	stk.reset();
+	for(;;)
+	{
+		if(dist < tmin) break;
+		uint2 nd = sc.nodes[node];
+		while((nd.y & 3u) != 3u)
+		{
+			const int axis = (int)(nd.y & 3u);
+			const float split = __uint_as_float(nd.x);
+			const float o = comp(from, axis), d = comp(dir, axis);
+			const float tplane = (split - o) * comp(inv_dir, axis);
+			const bool below = (o < split) || (o == split && d <= 0.f);
+			const uint32_t left = node + 1u, right = nd.y >> 2;
+			const uint32_t near_c = below ? left : right, far_c = below ? right : left;
+			if(!(tplane <= tmax) || tplane <= 0.f) node = near_c;
+			else if(tplane < tmin) node = far_c;
+			else { stk.push(far_c, tmax); node = near_c; tmax = tplane; }
+			nd = sc.nodes[node];
+		}
+		const uint32_t np = nd.y >> 2, first = nd.x;
+		for(uint32_t i = 0; i < np; ++i)
+		{
+			const uint32_t ti = sc.refs[first + i];
+			const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
+			float t, u, v;
+			if(!tri_test(r0, r1, r2, from, dir, t, u, v)) continue;
+			const uint32_t vis = __float_as_uint(r1.w) >> 30;
+			if(!(t < dist && t >= ray_tmin && (vis == 0u || vis == 2u))) continue;
+			const yafgpu_material &m = sc.mats[__float_as_uint(r1.w) & 0x3FFFFFFFu];
+			if(!mat_is_transparent(m)) return true;
+			bool known = false;
+			for(int k = 0; k < n_seen; ++k) known = known || (seen[k * kWave] == ti);
+			if(known) continue;
+			if(depth >= max_depth) return true;
+			if(n_seen <= kTsMaxDepth) seen[(n_seen++) * kWave] = ti;
+			SurfPt sp;
+			get_surface(sc, (int)ti, from + dir * t, u, v, sp);
+			filt = filt * mat_transparency(m, sp, dir);
+			++depth;
+		}
+		if(stk.empty())
+		{
+			if(!stk.lost() || tmax >= t_exit) break;
+			tmin = tmax; tmax = t_exit; node = 0u; stk.reset();
+			continue;
+		}
+		tmin = tmax;
+		stk.pop(node, tmax);
+	}
+	return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // direct lighting: MonteCarloIntegrator::doLightEstimation, integrator_montecarlo.cc:78-345,
 // over lights [l_begin, l_end).  One any-hit trace site serves the Dirac branch (:94-148), the
@@ -918,6 +987,8 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			o[1] = d0.x; o[2] = d0.y; o[3] = d0.z; o[4] = c0.r; o[5] = c0.g; o[6] = c0.b;
 			o[7] = d1.x; o[8] = d1.y; o[9] = d1.z; o[10] = c1.r; o[11] = c1.g; o[12] = c1.b;
 			o[13] = mat_alpha(m, d, sp, wo);
+			const Col tr = mat_transparency(m, sp, wo);
+			o[14] = tr.r; o[15] = tr.g; o[16] = tr.b;
 			break;
 		}
 		default: break;
@@ -952,7 +1023,7 @@ struct yafgpu_scene
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
-	bool has_specular = false; int wf_frames = 0;      // recursiveRaytrace frames allocated behind the working records
+	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
@@ -1028,6 +1099,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	}
 	auto *s = new yafgpu_scene();
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
+	for(int i = 0; i < d->n_materials; ++i) if((d->materials[i].type == YAFGPU_MAT_SHINYDIFFUSE && d->materials[i].is_transparent) || (d->materials[i].type == YAFGPU_MAT_GLASS && d->materials[i].fake_shadow)) s->has_transparent = true;
 	const auto t0 = std::chrono::steady_clock::now();
 	build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
 	s->info.build_seconds = s->tree.build_seconds;
@@ -1155,6 +1227,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_counts) (void)hipFree(s->wf_counts);
 	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 	if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
+	if(s->wf_filt) (void)hipFree(s->wf_filt);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	delete s;
 }
@@ -1314,6 +1387,16 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
 	}
+	// transparent shadows only cost anything when a material can be transparent to a shadow ray
+	const bool transp = rp.transp_shad != 0 && s->has_transparent;
+	if(transp && rp.shadow_depth > kTsMaxDepth) return fail(-18, "shadowDepth > 8 with transparent shadows: the device path remembers at most 9 filtered triangles per shadow ray");
+	if(transp && s->wf_cap > s->wf_filt_cap)
+	{
+		if(s->wf_filt) (void)hipFree(s->wf_filt);
+		s->wf_filt = nullptr; s->wf_filt_cap = 0;
+		HIP_OK(hipMalloc((void **)&s->wf_filt, (size_t)2 * s->wf_cap * sizeof(float4)));
+		s->wf_filt_cap = s->wf_cap;
+	}
 	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 64 * sizeof(uint32_t)));
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev));
@@ -1360,7 +1443,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
 		uint32_t *cnt[2] = {s->wf_counts, s->wf_counts + 32};
-		a.verdict = s->wf_verdict;
+		a.verdict = s->wf_verdict; a.shadow_filt = transp ? s->wf_filt : nullptr;
 		a.cnt_in = cnt[0]; a.cnt_out = cnt[1];
 		a.q_closest_in = nullptr; a.q_shadow_in = qset[0][1]; a.q_resume_in = qset[0][2];
 		a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
@@ -1387,7 +1470,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
 				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
 			if(it > 0 && (rc = timed(1, [&] {
-				if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, stream, a);
+				if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, stream, a);
+				else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, stream, a);
 				else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, stream, a); }))) return rc;
 			if((rc = timed(2, [&] { hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
 			// swap queues: what shade produced is the next iteration's input
@@ -1487,6 +1571,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(!mega) return render_wavefront(s, ra, stream, stats);
 		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
 		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
+		if(rp->transp_shad && s->has_transparent) return fail(-15, "the one-kernel pipeline has no transparent shadows; use the wavefront pipeline");
 		if(s->has_specular && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent materials");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)
 			return fail(-15, "the one-kernel pipeline renders single-pass films only; use the wavefront pipeline");

@@ -281,6 +281,36 @@ YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
 	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
 	return mk(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
 }
+// Material::isTransparent / getTransparency: ShinyDiffuse (material_shiny_diffuse.h:53, .cc:530-566), Glass with fake
+// shadows (material_glass.cc:217-228); Material's default: opaque
+YG_DEV bool mat_is_transparent(const yafgpu_material &m)
+{
+	return (m.type == YAFGPU_MAT_SHINYDIFFUSE && m.is_transparent) || (m.type == YAFGPU_MAT_GLASS && m.fake_shadow);
+}
+YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
+{
+	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	{
+		if(!m.is_transparent) return mkc(0.f, 0.f, 0.f);
+		float accum = 1.f;
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		const float kr = sd_fresnel(m, wo, n);
+		if(m.is_mirror) accum = 1.f - kr * m.mirror_strength;
+		accum *= m.transparency_strength * accum;                     // sic, :557
+		const float f = m.transmit_filter;
+		const Col tcol = col3(m.diffuse_color) * f + mkc(1.f - f, 1.f - f, 1.f - f);
+		return tcol * accum;
+	}
+	if(m.type == YAFGPU_MAT_GLASS)
+	{
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		float kr, kt;
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		return col3(m.filter_color) * kt;
+	}
+	return mkc(0.f, 0.f, 0.f);
+}
+
 // Material::getAlpha: ShinyDiffuse (:568-597), Glass (material_glass.cc:217-240), everything else 1
 YG_DEV float mat_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo)
 {

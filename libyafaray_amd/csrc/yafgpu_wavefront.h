@@ -38,6 +38,7 @@ struct WfArgs
 	const uint32_t *q_closest_in, *q_shadow_in, *q_resume_in;   // nullptr closest queue = identity (first iteration)
 	uint32_t *q_closest_out, *q_shadow_out, *q_resume_out;
 	uint32_t *verdict;                // [2*slot + which] any-hit answers
+	float4 *shadow_filt;              // [2*slot + which] product of the transparencies a shadow ray passed (transparent shadows), or nullptr
 	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
@@ -319,12 +320,22 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict
 	const uint32_t w = ubits(r14.w);
 	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0xfu), is = (int)(w >> 20);
 	const bool dirac = sc.lights[li].type == YAFGPU_LIGHT_POINT;
+	// transparent shadows (integrator_montecarlo.cc:114,182,309): what an unblocked ray picked up on its way scales the
+	// light.  (The reference scales the light colour before forming the contribution, here the parked contribution is
+	// scaled: same product, other rounding order.)
+	Col fa = mkc(1.f, 1.f, 1.f), fb = fa;
+	if(a.shadow_filt != nullptr) { fa = c3(a.shadow_filt[2u * slot]); fb = c3(a.shadow_filt[2u * slot + 1u]); }
 	if((mask & 1) && verdict.x == 0u)
 	{
-		if(dirac) HSET(17, f4(c3(HGET(17)) + c3(r14), 0.f));
-		else HSET(15, f4(c3(HGET(15)) + c3(r14), 0.f));
+		const Col add = (a.shadow_filt != nullptr) ? c3(r14) * fa : c3(r14);
+		if(dirac) HSET(17, f4(c3(HGET(17)) + add, 0.f));
+		else HSET(15, f4(c3(HGET(15)) + add, 0.f));
 	}
-	if((mask & 2) && verdict.y == 0u) HSET(16, f4(c3(HGET(16)) + c3(REC(21)), 0.f));
+	if((mask & 2) && verdict.y == 0u)
+	{
+		const Col add = (a.shadow_filt != nullptr) ? c3(REC(21)) * fb : c3(REC(21));
+		HSET(16, f4(c3(HGET(16)) + add, 0.f));
+	}
 	r14.w = fbits(pack_dlc(li, l_end, 0, is + 1));
 	HSET(14, r14);
 	return W_DL_NEXT;
@@ -984,6 +995,47 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				atomicAdd((unsigned long long *)&a.ra.counters->wave_rounds, (unsigned long long)rounds_node | ((unsigned long long)rounds_tri << 32));
 			}
 		}
+	}
+}
+
+// Scene::isShadowed with transparent shadows (scene.cc:996-1035) over the shadow queue: one lane per ray, no refill —
+// the feature path for scenes with transparent materials and transpShad, not the benchmark path.
+__global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
+{
+	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
+	__shared__ uint32_t s_seen[kWavesPerBlock][kTsMaxDepth + 1][kWave];
+	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
+	const DevScene &sc = a.ra.sc;
+	LaneStack stk;
+	stk.col = &s_stack[wave][0][lane];
+	uint32_t *seen = &s_seen[wave][0][lane];
+	const uint32_t n = a.cnt_in[1];
+	const size_t c = a.cap;
+	uint32_t count = 0u;
+	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t slot = a.q_shadow_in[i];
+		const uint32_t which = slot >> 31; slot &= 0x7fffffffu;
+		float4 r0 = a.state[slot], r1 = a.state[c + slot];
+		if(which)
+		{
+			const float4 r20 = a.state[20 * c + slot];
+			r1 = make_float4(r20.x, r20.y, r20.z, a.state[21 * c + slot].w);
+			r0.w = r20.w;
+		}
+		const V3 dir = v3(r1);
+		const V3 from = v3(r0) + dir * r0.w;
+		const float dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
+		Col filt;
+		const bool sh = kd_trace_ts(sc, stk, seen, from, dir, r0.w, dist, a.ra.rp.shadow_depth, filt);     // sray keeps ray.tmin_ (:998-999)
+		a.verdict[2u * slot + which] = sh ? 1u : 0u;
+		a.shadow_filt[2u * slot + which] = f4(filt, 0.f);
+		++count;
+	}
+	if(a.ra.counters != nullptr)
+	{
+		const uint32_t v = wave_sum(count);
+		if(lane == 0 && v) atomicAdd((unsigned long long *)&a.ra.counters->rays_shadow, (unsigned long long)v);
 	}
 }
 

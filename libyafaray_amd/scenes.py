@@ -110,7 +110,7 @@ def load_scene(yi, scene, render):
     yi.paramsClearAll()
     integ = {"type": render.get("integrator", "pathtracing")}
     integ["raydepth"] = 5      # MonteCarloIntegrator's default r_depth_, spelled out so that oracle and device agree
-    for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth"):
+    for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth", "transpShad", "shadowDepth"):
         if k in render:
             integ[k] = render[k]
     integ["caustic_type"] = "none"

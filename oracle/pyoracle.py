@@ -67,7 +67,7 @@ class RenderDesc(C.Structure):
         ("aa_indirect_sample_multiplier_factor", C.c_float), ("aa_detect_color_noise", C.c_int32),
         ("aa_dark_detection_type", C.c_int32), ("aa_dark_threshold_factor", C.c_float),
         ("aa_variance_edge_size", C.c_int32), ("aa_variance_pixels", C.c_int32), ("aa_clamp_samples", C.c_float),
-        ("raydepth", C.c_int32),
+        ("transp_shad", C.c_int32), ("shadow_depth", C.c_int32), ("raydepth", C.c_int32),
     ]
 
 
@@ -138,6 +138,7 @@ def lib():
     L.yor_arealight_intersect.argtypes = [C.POINTER(LightDesc), fp, fp, fp]
     L.yor_pointlight_illuminate.restype = C.c_int
     L.yor_pointlight_illuminate.argtypes = [C.POINTER(LightDesc), fp, fp]
+    L.yor_material_transparency.argtypes = [C.POINTER(MaterialDesc), fp, fp]
     L.yor_material_specular.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, C.POINTER(C.c_float)]
     L.yor_material_probe.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, fp,
                                      C.POINTER(C.c_int32), fp]
@@ -295,6 +296,8 @@ def render_desc(r):
     d.aa_variance_edge_size = r.get("AA_variance_edge_size", 10)
     d.aa_variance_pixels = r.get("AA_variance_pixels", 0)
     d.aa_clamp_samples = r.get("AA_clamp_samples", 0.0)
+    d.transp_shad = int(r.get("transpShad", False))
+    d.shadow_depth = r.get("shadowDepth", 5)  # integrator_path_tracer.cc:352
     d.raydepth = r.get("raydepth", 5)       # MonteCarloIntegrator default r_depth_
     return d
 

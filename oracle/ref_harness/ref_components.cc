@@ -393,7 +393,7 @@ static void run_material(Json &j, const char *prefix, Material *mat, int n_cases
 	state.userdata_ = (void *)userdata;
 	state.include_lights_ = true;
 	state.raylevel_ = raylevel;      // recursiveRaytrace increments it before it asks for the specular directions
-	std::vector<uint32_t> in, ev, sm, pd, spec, alph;
+	std::vector<uint32_t> in, ev, sm, pd, spec, alph, transp;
 	std::vector<int> flags_out, sflags_in, sflags_out, spec_flags;
 	for(int i = 0; i < n_cases; ++i)
 	{
@@ -438,6 +438,7 @@ static void run_material(Json &j, const char *prefix, Material *mat, int n_cases
 		if(!refr) { sdir[1] = Vec3(0.f); scol[1] = Rgb(0.f); }
 		pushv(spec, sdir[0]); pushc(spec, scol[0]); pushv(spec, sdir[1]); pushc(spec, scol[1]);
 		alph.push_back(f2u(mat->getAlpha(state, sp, wo)));
+		pushc(transp, mat->getTransparency(state, sp, wo));      // what a transparent-shadow ray along wo picks up (intersectTs)
 	}
 	std::string p(prefix);
 	j.arr_u32((p + "_in14").c_str(), in); j.arr_i32((p + "_flags").c_str(), flags_out);
@@ -445,6 +446,7 @@ static void run_material(Json &j, const char *prefix, Material *mat, int n_cases
 	j.arr_i32((p + "_sflags_in").c_str(), sflags_in); j.arr_i32((p + "_sflags_out").c_str(), sflags_out);
 	j.arr_u32((p + "_sample8").c_str(), sm);
 	j.arr_i32((p + "_specflags").c_str(), spec_flags); j.arr_u32((p + "_spec12").c_str(), spec); j.arr_u32((p + "_alpha").c_str(), alph);
+	j.arr_u32((p + "_transp3").c_str(), transp);
 }
 
 static void sec_materials(Json &j)

@@ -749,7 +749,16 @@ static int kd_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float d
 }
 
 /* TriKdTree::intersectS, kdtree_triangle.cc:840-977 */
-static int kd_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist, counters_t *cn)
+/* forward declarations for TriKdTree::intersectTs, which asks materials about their transparency */
+struct mat_s; struct sp_s;
+static int mat_is_transparent_idx(const yor_scene *s, int mat);
+static rgb mat_transparency_at(const yor_scene *s, int ti, v3 hit, float bu, float bv, v3 dir);
+
+/* ts == NULL: TriKdTree::intersectS (:840-977).  ts != NULL: TriKdTree::intersectTs (:983-1162): transparent
+ * triangles (each once: the std::set `filtered`) multiply their transparency into ts->filt instead of blocking the
+ * ray; more than ts->max_depth of them block it. */
+typedef struct { float ray_tmin; int max_depth; rgb filt; int depth; int n_seen; int seen[64]; } ts_state;
+static int kd_intersect_s_impl(const yor_scene *s, v3 from, v3 dir, float dist, counters_t *cn, ts_state *ts)
 {
 	float a, b, t, t_hit;
 	if(s->n_nodes == 0) return 0;
@@ -815,9 +824,22 @@ static int kd_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist, count
 				if(cn) cn->tests++;
 				if(tri_intersect(mp, from, dir, &t_hit, &uu, &vv))
 				{
-					if(t_hit < dist && t_hit >= 0.f)
+					if(t_hit < dist && t_hit >= (ts ? ts->ray_tmin : 0.f))
 					{
-						if(mat_visible_shadow(&s->mats[mp->mat])) return 1;
+						if(mat_visible_shadow(&s->mats[mp->mat]))
+						{
+							if(!ts || !mat_is_transparent_idx(s, mp->mat)) return 1;
+							int ti = (int)s->leaf_refs[first + i], known = 0;
+							for(int k = 0; k < ts->n_seen; ++k) if(ts->seen[k] == ti) { known = 1; break; }
+							if(!known)
+							{
+								if(ts->n_seen < 64) ts->seen[ts->n_seen++] = ti;
+								if(ts->depth >= ts->max_depth) return 1;
+								v3 h = vadd(from, vmul(dir, t_hit));
+								ts->filt = cmul(ts->filt, mat_transparency_at(s, ti, h, uu, vv, dir));
+								++ts->depth;
+							}
+						}
 					}
 				}
 			}
@@ -828,6 +850,7 @@ static int kd_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist, count
 	}
 	return 0;
 }
+static int kd_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist, counters_t *cn) { return kd_intersect_s_impl(s, from, dir, dist, cn, NULL); }
 
 /* brute-force versions: the traversal-independent definition of the same queries */
 static int brute_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float dist, int *tri_out, float *z_out, float *bu, float *bv)
@@ -899,6 +922,21 @@ static int scene_is_shadowed(const yor_scene *s, v3 from, v3 dir, float tmin, fl
 	else dis = tmax - 2 * tmin;
 	if(cn) cn->rays_shadow++;
 	return kd_intersect_s(s, sfrom, dir, dis, cn);
+}
+
+/* Scene::isShadowed with transparent shadows, scene.cc:996-1035: filt = product of the transparencies passed */
+static int scene_is_shadowed_ts(const yor_scene *s, v3 from, v3 dir, float tmin, float tmax, int max_depth, rgb *filt, counters_t *cn)
+{
+	v3 sfrom = vadd(from, vmul(dir, tmin));
+	float dis;
+	if(tmax < 0) dis = INFINITY;
+	else dis = tmax - 2 * tmin;
+	if(cn) cn->rays_shadow++;
+	ts_state ts; memset(&ts, 0, sizeof ts);
+	ts.ray_tmin = tmin; ts.max_depth = max_depth; ts.filt = C(1.f, 1.f, 1.f);      /* sray keeps ray.tmin_ (:998-999) */
+	int r = kd_intersect_s_impl(s, sfrom, dir, dis, cn, &ts);
+	*filt = ts.filt;
+	return r;
 }
 
 /* ------------------------------------------------------------------ materials */
@@ -1280,6 +1318,44 @@ static float sd_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 
 /* ShinyDiffuseMaterial::getSpecular, material_shiny_diffuse.cc:474-528 (no shader nodes, no wireframe);
  * every other material of this path keeps Material::getSpecular's default: neither */
+/* Material::getTransparency: ShinyDiffuse (material_shiny_diffuse.cc:530-566), Glass (material_glass.cc:217-228);
+ * Material's default is black */
+static rgb mat_transparency(const mat_t *m, const sp_t *sp, v3 wo)
+{
+	if(m->type == YOR_MAT_SHINYDIFFUSE)
+	{
+		if(!m->is_transparent) return C(0, 0, 0);
+		float accum = 1.f;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr = sd_fresnel(m, wo, n);
+		if(m->is_mirror) accum = 1.f - kr * m->mirror_strength;
+		accum *= m->transparency_strength * accum;       /* sic, :557 */
+		float f = m->transmit_filter;
+		rgb tcol = cadd(cscale(m->diffuse_color, f), C(1.f - f, 1.f - f, 1.f - f));
+		return cscale(tcol, accum);
+	}
+	if(m->type == YOR_MAT_GLASS)
+	{
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr, kt;
+		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		return cscale(m->filter_color, kt);
+	}
+	return C(0, 0, 0);
+}
+/* Material::isTransparent: ShinyDiffuse m_is_transparent_ (material_shiny_diffuse.h:53), Glass fake_shadow_ (material_glass.h) */
+static int mat_is_transparent(const mat_t *m)
+{
+	return (m->type == YOR_MAT_SHINYDIFFUSE && m->is_transparent) || (m->type == YOR_MAT_GLASS && m->fake_shadow);
+}
+static int mat_is_transparent_idx(const yor_scene *s, int mat) { return mat_is_transparent(&s->mats[mat]); }
+static rgb mat_transparency_at(const yor_scene *s, int ti, v3 hit, float bu, float bv, v3 dir)
+{
+	sp_t sp;
+	get_surface(s, ti, hit, bu, bv, &sp);
+	return mat_transparency(&s->mats[sp.mat], &sp, dir);
+}
+
 /* GlassMaterial::getTransparency / getAlpha, material_glass.cc:217-240 */
 static float glass_alpha(const mat_t *m, const sp_t *sp, v3 wo)
 {
@@ -1896,11 +1972,15 @@ static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *s
 		{
 			if(st->rd->shadow_bias_auto) lr_tmin = st->shadow_bias * fmaxf_(1.f, vlength(sp->p));
 			else lr_tmin = st->shadow_bias;
-			if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
+			rgb scol = C(1.f, 1.f, 1.f);
+			const int tr_shad = st->rd->transp_shad;
+			if(cast_shadows) shadowed = tr_shad ? scene_is_shadowed_ts(s, sp->p, lr_dir, lr_tmin, lr_tmax, st->rd->shadow_depth, &scol, &st->cn)
+			                                     : scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
 			else shadowed = 0;
 			float angle_light_normal = (material->flat ? 1.f : fabsf(vdot(sp->n, lr_dir)));
 			if(!shadowed)
 			{
+				if(tr_shad && cast_shadows) lcol = cmul(lcol, scol);                 /* :114 */
 				rgb surf_col = mat_eval(material, dat, sp, wo, lr_dir, BSDF_ALL);
 				col = cadd(col, cscale(cmul(surf_col, lcol), angle_light_normal));
 			}
@@ -1925,10 +2005,14 @@ static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *s
 			{
 				if(st->rd->shadow_bias_auto) lr_tmin = st->shadow_bias * fmaxf_(1.f, vlength(sp->p));
 				else lr_tmin = st->shadow_bias;
-				if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
+				rgb scol = C(1.f, 1.f, 1.f);
+				const int tr_shad = st->rd->transp_shad;
+				if(cast_shadows) shadowed = tr_shad ? scene_is_shadowed_ts(s, sp->p, lr_dir, lr_tmin, lr_tmax, st->rd->shadow_depth, &scol, &st->cn)
+				                                     : scene_is_shadowed(s, sp->p, lr_dir, lr_tmin, lr_tmax, &st->cn);
 				else shadowed = 0;
 				if(!shadowed && ls_pdf > 1e-6f)
 				{
+					if(tr_shad && cast_shadows) ls_col = cmul(ls_col, scol);          /* :182 */
 					rgb surf_col = mat_eval(material, dat, sp, wo, lr_dir, BSDF_ALL);
 					float angle_light_normal = (material->flat ? 1.f : fabsf(vdot(sp->n, lr_dir)));
 					/* canIntersect() is true for area lights (light_area.h) */
@@ -1966,10 +2050,14 @@ static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *s
 				float light_pdf;
 				if(sm.pdf > 1e-6f && arealight_intersect(light, sp->p, b_dir, &b_tmax, &lcol, &light_pdf))
 				{
-					if(cast_shadows) shadowed = scene_is_shadowed(s, sp->p, b_dir, b_tmin, b_tmax, &st->cn);
+					rgb scol = C(1.f, 1.f, 1.f);
+					const int tr_shad = st->rd->transp_shad;
+					if(cast_shadows) shadowed = tr_shad ? scene_is_shadowed_ts(s, sp->p, b_dir, b_tmin, b_tmax, st->rd->shadow_depth, &scol, &st->cn)
+					                                     : scene_is_shadowed(s, sp->p, b_dir, b_tmin, b_tmax, &st->cn);
 					else shadowed = 0;
 					if(!shadowed && light_pdf > 1e-6f)
 					{
+						if(tr_shad && cast_shadows) lcol = cmul(lcol, scol);          /* :309 */
 						float l_pdf = 1.f / light_pdf;
 						float l_2 = l_pdf * l_pdf;
 						float m_2 = sm.pdf * sm.pdf;
@@ -2692,6 +2780,14 @@ void yor_material_probe(const yor_material_desc *md, const float in14[14], int32
 	rgb sc = mat_sample(&m, &dat, &sp, wo, &wi, &s, &w);
 	*sampled_flags = (int32_t)s.sampled_flags;
 	sample8[0] = sc.r; sample8[1] = sc.g; sample8[2] = sc.b; sample8[3] = wi.x; sample8[4] = wi.y; sample8[5] = wi.z; sample8[6] = s.pdf; sample8[7] = w;
+}
+void yor_material_transparency(const yor_material_desc *md, const float in14[14], float out3[3])
+{
+	mat_t m; mat_configure(&m, md);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.n = V(in14[0], in14[1], in14[2]); sp.ng = V(in14[3], in14[4], in14[5]);
+	rgb t = mat_transparency(&m, &sp, V(in14[6], in14[7], in14[8]));
+	out3[0] = t.r; out3[1] = t.g; out3[2] = t.b;
 }
 void yor_material_specular(const yor_material_desc *md, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha)
 {

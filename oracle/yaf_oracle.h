@@ -134,6 +134,8 @@ typedef struct yor_render_desc
 	float aa_dark_threshold_factor;
 	int32_t aa_variance_edge_size, aa_variance_pixels;
 	float aa_clamp_samples;            /* ImageFilm::addSample clampProportionalRgb (imagefilm.cc:975) */
+	int32_t transp_shad;               /* tr_shad_: shadow rays are filtered by transparent materials (TriKdTree::intersectTs) */
+	int32_t shadow_depth;              /* s_depth_: more distinct transparent surfaces than this along a shadow ray = shadowed */
 	int32_t raydepth;                  /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791); 0 behaves like "no recursion" */
 } yor_render_desc;
 
@@ -200,6 +202,8 @@ int yor_arealight_illum_sample(const yor_light_desc *l, const float p[3], float 
 int yor_arealight_intersect(const yor_light_desc *l, const float from[3], const float dir[3], float out5[5]);
 int yor_pointlight_illuminate(const yor_light_desc *l, const float p[3], float out7[7]);
 /* in14 = n, ng, wo, wl, s1, s2 ; outputs as in the harness */
+/* Material::getTransparency(sp, wo) */
+void yor_material_transparency(const yor_material_desc *m, const float in14[14], float out3[3]);
 /* Material::getSpecular + getAlpha: flags bit0 reflect, bit1 refract; out12 = dir0, col0, dir1, col1 */
 void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha);
 void yor_material_probe(const yor_material_desc *m, const float in14[14], int32_t sample_flags,

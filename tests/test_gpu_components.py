@@ -153,7 +153,8 @@ def test_materials(gold, probe_scene, name):
     # Material::getSpecular (recursiveRaytrace's perfect reflection / filtered transmission) and getAlpha
     from tests.test_oracle_golden import SPEC_RAYLEVEL
     xs = np.concatenate([x[:, :10], np.full((n, 1), float(SPEC_RAYLEVEL.get(name, 1)), np.float32)], axis=1)
-    s = yi.probe(12, xs, 14)
+    s = yi.probe(12, xs, 17)
     assert np.array_equal(s[:, 0].view(np.uint32), g[f"{name}_specflags"].astype(np.uint32)), "getSpecular flags"
     exact(s[:, 1:13], g[f"{name}_spec12"], f"{name} getSpecular")
     exact(s[:, 13], g[f"{name}_alpha"], f"{name} getAlpha")
+    exact(s[:, 14:17], g[f"{name}_transp3"], f"{name} getTransparency")

@@ -275,6 +275,12 @@ def test_materials(gold, name):
     assert sf == [int(v) for v in g[f"{name}_specflags"]]
     check(variant, sp12, g[f"{name}_spec12"], f"{name} getSpecular")
     check(variant, al, g[f"{name}_alpha"], f"{name} getAlpha")
+    tr = []
+    t3 = np.zeros(3, np.float32)
+    for i in range(inp.shape[0]):
+        L.yor_material_transparency(C.byref(md), po.fptr(inp[i]), po.fptr(t3))
+        tr.extend(t3.tolist())
+    check(variant, tr, g[f"{name}_transp3"], f"{name} getTransparency")
 
 
 def test_light_material(gold):

@@ -28,7 +28,8 @@ extern "C" {
 #define YAFGPU_FILM_CHANNELS 5   /* r,g,b,a,weight : Pixel, include/utility/util_image_buffers.h:36-48 */
 #define YAFGPU_FILM_PLANES   4   /* own, right, down, diagonal splat planes */
 
-enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2, YAFGPU_MAT_GLASS = 3, YAFGPU_MAT_MIRROR = 4 };
+enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2, YAFGPU_MAT_GLASS = 3, YAFGPU_MAT_MIRROR = 4,
+       YAFGPU_MAT_COATED_GLOSSY = 5 /* glossy's fields + mirror_color, mirror_strength, glass_ior = IOR, c_flags[0..2], n_bsdf */ };
 enum { YAFGPU_LIGHT_AREA = 0, YAFGPU_LIGHT_POINT = 1 };
 enum { YAFGPU_INTEGRATOR_PATH = 0, YAFGPU_INTEGRATOR_DIRECT = 1 };
 enum { YAFGPU_FILTER_BOX = 0, YAFGPU_FILTER_MITCHELL = 1, YAFGPU_FILTER_GAUSS = 2, YAFGPU_FILTER_LANCZOS = 3 };

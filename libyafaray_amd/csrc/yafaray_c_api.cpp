@@ -230,6 +230,40 @@ bool make_lightmat(const ParamMap &p, yafgpu_material &m)
 	return true;
 }
 
+// CoatedGlossyMaterial::factory + ctor, material_coated_glossy.cc:464-560, :41-66 (Blinn lobe, as_diffuse only)
+bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+{
+	float col[3] = {1, 1, 1}, dcol[3] = {1, 1, 1}, mcol[3] = {1, 1, 1};
+	float refl = 1.f, diff = 0.f, exponent = 50.f, mirror = 1.f, wire = 0.f; double ior = 1.4, sigma = 0.1;
+	bool as_diff = true, aniso = false, recv = true; std::string vis = "normal", brdf; int add_depth = 0;
+	p.getColor("color", col); p.getColor("diffuse_color", dcol); p.get("diffuse_reflect", diff); p.get("glossy_reflect", refl);
+	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso); p.get("IOR", ior);
+	p.getColor("mirror_color", mcol); p.get("specular_reflect", mirror);
+	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire);
+	if(aniso) return fail(yi, "coated_glossy: the anisotropic (Ashikhmin-Shirley) lobe is not supported by the GPU path");
+	if(!as_diff) return fail(yi, "coated_glossy: as_diffuse = false needs recursiveRaytrace's glossy branch, which the GPU path does not implement");
+	if(wire != 0.f) return fail(yi, "coated_glossy: wireframe shading is not supported by the GPU path");
+	if(add_depth != 0) return fail(yi, "coated_glossy: additionaldepth is not supported by the GPU path");
+	if(!yi->eparams.empty()) return fail(yi, "coated_glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
+	if(ior == 1.0) ior = 1.0000001f;                                // :512
+	std::memset(&m, 0, sizeof m);
+	m.type = YAFGPU_MAT_COATED_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
+	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; m.mirror_color[k] = mcol[k]; }
+	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = 1;
+	m.c_flags[0] = 0x1u | 0x10u;                                    // Specular | Reflect
+	m.c_flags[1] = 0x4u | 0x10u;                                    // as_diffuse: Diffuse | Reflect
+	if(diff > 0.f) { m.c_flags[2] = 0x4u | 0x10u; m.with_diffuse = 1; m.n_bsdf = 3; }
+	else { m.c_flags[2] = 0u; m.n_bsdf = 2; }
+	m.bsdf_flags = m.c_flags[0] | m.c_flags[1] | m.c_flags[2];
+	if(p.get("diffuse_brdf", brdf) && brdf == "Oren-Nayar")
+	{	// initOrenNayar :81-87
+		p.get("sigma", sigma);
+		const double s2 = sigma * sigma;
+		m.oren_a = (float)(1.0 - 0.5 * (s2 / (s2 + 0.33))); m.oren_b = (float)(0.45 * s2 / (s2 + 0.09)); m.use_oren = 1;
+	}
+	return true;
+}
+
 // GlassMaterial::factory + ctor, material_glass.cc:340-443, :32-49 (no dispersion, absorption or shader nodes)
 bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 {
@@ -587,8 +621,9 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
 	else if(type == "glass") ok = make_glass(yi, yi->params, m->m);
+	else if(type == "coated_glossy") ok = make_coated_glossy(yi, yi->params, m->m);
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
-	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, light_mat, glass, mirror)"); return nullptr; }
+	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }
 	if(!ok) return nullptr;
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();

@@ -93,7 +93,7 @@ YG_DEV uint32_t mat_init_bsdf(const yafgpu_material &m, BsdfDat &d)
 		if(m.is_translucent) d.c2 = m.translucency_strength;
 		if(m.is_diffuse) d.c3 = m.diffuse_strength;
 	}
-	else if(m.type == YAFGPU_MAT_GLOSSY)
+	else if(m.type == YAFGPU_MAT_GLOSSY || m.type == YAFGPU_MAT_COATED_GLOSSY)
 	{
 		d.m_diffuse = m.diffuse;
 		d.m_glossy = m.reflectivity;
@@ -132,6 +132,47 @@ YG_DEV V3 blinn_sample(float s_1, float s_2, float e) // :99-106
 	return mk(sin_theta * f_cos(phi), sin_theta * f_sin(phi), cos_theta);
 }
 
+// refract__, vector.cc:86-108
+YG_DEV bool refract_dir(V3 n, V3 wi, V3 &wo, float ior)
+{
+	V3 N = n;
+	float eta = ior;
+	const V3 i = -wi;
+	float cos_v_n = dot(wi, n);
+	if(cos_v_n < 0.f) { N = -n; cos_v_n = -cos_v_n; }
+	else eta = (float)(1.0 / (double)ior);
+	const float k = 1.f - eta * eta * (1.f - cos_v_n * cos_v_n);
+	if(k <= 0.f) return false;
+	wo = normalize(i * eta + N * (eta * cos_v_n - f_sqrt(k)));
+	return true;
+}
+// fresnel__, vector.cc:110-142 (kr is formed in double)
+YG_DEV void fresnel_dielectric(V3 i, V3 n, float ior, float &kr, float &kt)
+{
+	const float eta = ior;
+	const V3 N = (dot(i, n) < 0.f) ? -n : n;
+	const float c = dot(i, N);
+	float g = eta * eta + c * c - 1.f;
+	g = (g <= 0.f) ? 0.f : f_sqrt(g);
+	const float aux = c * (g + c);
+	kr = (float)(((0.5 * (double)(g - c) * (double)(g - c)) / (double)((g + c) * (g + c))) *
+	             (double)(1.f + ((aux - 1.f) * (aux - 1.f)) / ((aux + 1.f) * (aux + 1.f))));
+	kt = (kr < 1.0f) ? 1.f - kr : 0.f;
+}
+// the shading normal the glass uses, material_glass.cc:77-80, 263-271
+YG_DEV V3 glass_normal(const SurfPt &sp, V3 wo)
+{
+	const bool outside = dot(sp.ng, wo) > 0.f;
+	const float cos_wo_n = dot(sp.n, wo);
+	if(outside ? (cos_wo_n >= 0.f) : (cos_wo_n <= 0.f)) return sp.n;
+	const float f = (float)(1.00001 * (double)cos_wo_n);
+	return normalize(sp.n - wo * f);
+}
+YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
+{
+	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
+	return mk(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
+}
 // Material::eval — material_shiny_diffuse.cc:244-293, material_glossy.cc:113-173
 YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
 {
@@ -167,6 +208,30 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		if(m.with_diffuse)
 		{
 			Col add = col3(m.diff_color) * (d.m_diffuse * (1.f - d.m_glossy));
+			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wl, wo, n);
+			col = col + add;
+		}
+		return col;
+	}
+	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	{	// material_coated_glossy.cc:130-186
+		Col col = mkc(0.f, 0.f, 0.f);
+		const bool diffuse_flag = (bsdfs & kDiffuse) != 0u;
+		if(!diffuse_flag || (dot(sp.ng, wl) * dot(sp.ng, wo)) < 0.f) return col;
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		float kr, kt;
+		const float wi_n = fabsf(dot(wl, n)), wo_n = fabsf(dot(wo, n));
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		if((m.as_diffuse && diffuse_flag) || (!m.as_diffuse && (bsdfs & kGlossy)))
+		{
+			const V3 h = normalize(wo + wl);
+			const float cos_wi_h = dot(wl, h);
+			const float glossy = (float)((double)(kt * blinn_d(dot(h, n), m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			col = col3(m.gloss_color) * glossy;
+		}
+		if(m.with_diffuse && diffuse_flag)
+		{
+			Col add = (col3(m.diff_color) * (d.m_diffuse * (1.f - d.m_glossy))) * kt;
 			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wl, wo, n);
 			col = col + add;
 		}
@@ -228,6 +293,33 @@ YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &s
 		}
 		return pdf;
 	}
+	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	{	// material_coated_glossy.cc:376-424
+		if((dot(sp.ng, wo) * dot(sp.ng, wi)) < 0.f) return 0.f;
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		float pdf = 0.f, kr, kt;
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		const float acc[3] = {kr, kt * (1.f - d.p_diffuse), kt * d.p_diffuse};
+		float sum = 0.f;
+		int n_match = 0;
+		for(int i = 0; i < m.n_bsdf; ++i)
+		{
+			if((bsdfs & m.c_flags[i]) == m.c_flags[i])
+			{
+				const float width = acc[i];
+				sum += width;
+				if(i == 1)
+				{
+					const V3 h = normalize(wi + wo);
+					pdf += blinn_pdf(dot(n, h), dot(wo, h), m.exponent) * width;
+				}
+				else if(i == 2) pdf += fabsf(dot(wi, n)) * width;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) return 0.f;
+		return pdf / sum;
+	}
 	return 0.f;
 }
 
@@ -240,47 +332,6 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 	return 1.f - (1.f - d.c0 * kr) * d.c1;
 }
 
-// refract__, vector.cc:86-108
-YG_DEV bool refract_dir(V3 n, V3 wi, V3 &wo, float ior)
-{
-	V3 N = n;
-	float eta = ior;
-	const V3 i = -wi;
-	float cos_v_n = dot(wi, n);
-	if(cos_v_n < 0.f) { N = -n; cos_v_n = -cos_v_n; }
-	else eta = (float)(1.0 / (double)ior);
-	const float k = 1.f - eta * eta * (1.f - cos_v_n * cos_v_n);
-	if(k <= 0.f) return false;
-	wo = normalize(i * eta + N * (eta * cos_v_n - f_sqrt(k)));
-	return true;
-}
-// fresnel__, vector.cc:110-142 (kr is formed in double)
-YG_DEV void fresnel_dielectric(V3 i, V3 n, float ior, float &kr, float &kt)
-{
-	const float eta = ior;
-	const V3 N = (dot(i, n) < 0.f) ? -n : n;
-	const float c = dot(i, N);
-	float g = eta * eta + c * c - 1.f;
-	g = (g <= 0.f) ? 0.f : f_sqrt(g);
-	const float aux = c * (g + c);
-	kr = (float)(((0.5 * (double)(g - c) * (double)(g - c)) / (double)((g + c) * (g + c))) *
-	             (double)(1.f + ((aux - 1.f) * (aux - 1.f)) / ((aux + 1.f) * (aux + 1.f))));
-	kt = (kr < 1.0f) ? 1.f - kr : 0.f;
-}
-// the shading normal the glass uses, material_glass.cc:77-80, 263-271
-YG_DEV V3 glass_normal(const SurfPt &sp, V3 wo)
-{
-	const bool outside = dot(sp.ng, wo) > 0.f;
-	const float cos_wo_n = dot(sp.n, wo);
-	if(outside ? (cos_wo_n >= 0.f) : (cos_wo_n <= 0.f)) return sp.n;
-	const float f = (float)(1.00001 * (double)cos_wo_n);
-	return normalize(sp.n - wo * f);
-}
-YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
-{
-	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
-	return mk(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
-}
 // Material::isTransparent / getTransparency: ShinyDiffuse (material_shiny_diffuse.h:53, .cc:530-566), Glass with fake
 // shadows (material_glass.cc:217-228); Material's default: opaque
 YG_DEV bool mat_is_transparent(const yafgpu_material &m)
@@ -353,6 +404,24 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 		else { col_reflect = col3(m.mirror_color); dir_reflect = vec_reflect(wo, n); do_reflect = true; }      // total inner reflection
 		return;
 	}
+	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	{	// CoatedGlossyMaterial::getSpecular, material_coated_glossy.cc:426-462
+		const bool outside = dot(sp.ng, wo) >= 0.f;
+		const float cos_wo_n = dot(sp.n, wo);
+		const V3 ng = outside ? sp.ng : -sp.ng;
+		V3 n = sp.n;
+		if(!(outside ? (cos_wo_n >= 0.f) : (cos_wo_n <= 0.f))) n = normalize(sp.n - wo * (float)(1.00001 * (double)cos_wo_n));
+		float kr, kt;
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		if(raylevel > 5) return;
+		V3 r = vec_reflect(wo, n);
+		col_reflect = (col3(m.mirror_color) * kr) * m.mirror_strength;
+		const float cos_wi_ng = dot(r, ng);
+		if((double)cos_wi_ng < 0.01) r = normalize(r + ng * (float)(0.01 - (double)cos_wi_ng));
+		dir_reflect = r;
+		do_reflect = true;
+		return;
+	}
 	if(m.type == YAFGPU_MAT_MIRROR)
 	{
 		col_reflect = col3(m.mirror_color);
@@ -423,6 +492,107 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		}
 		s.pdf = 0.f;
 		return mkc(0.f, 0.f, 0.f);
+	}
+	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	{	// material_coated_glossy.cc:188-374, Blinn lobe
+		const float cos_ng_wo = dot(sp.ng, wo);
+		const V3 n = face_forward(sp.ng, sp.n, wo);
+		V3 hs = mk(0.f, 0.f, 0.f);
+		s.pdf = 0.f;
+		float kr, kt;
+		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		const float acc[3] = {kr, kt * (1.f - d.p_diffuse), kt * d.p_diffuse};
+		bool use1 = false, use2 = false;
+		float sum = 0.f, val[3], width[3];
+		int c_index[3] = {0, 0, 0}, rc1 = 0, rc2 = 0;
+		int n_match = 0, pick = -1;
+		for(int i = 0; i < m.n_bsdf; ++i)
+		{
+			if((s.flags & m.c_flags[i]) == m.c_flags[i])
+			{
+				if(i == 1) { use1 = true; rc1 = n_match; }
+				if(i == 2) { use2 = true; rc2 = n_match; }
+				width[n_match] = acc[i];
+				c_index[n_match] = i;
+				sum += width[n_match];
+				val[n_match] = sum;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) { wi = reflect_dir(n, wo); return mkc(0.f, 0.f, 0.f); }
+		else if(n_match == 1) { pick = 0; width[0] = 1.f; }
+		else
+		{
+			const float inv_sum = 1.f / sum;
+			for(int i = 0; i < n_match; ++i)
+			{
+				val[i] *= inv_sum;
+				width[i] *= inv_sum;
+				if((s.s_1 <= val[i]) && (pick < 0)) pick = i;
+			}
+		}
+		if(pick < 0) pick = n_match - 1;
+		float w_pick = width[0], v_prev = 0.f; int ci = c_index[0];
+		if(pick == 1) { w_pick = width[1]; v_prev = val[0]; ci = c_index[1]; }
+		if(pick == 2) { w_pick = width[2]; v_prev = val[1]; ci = c_index[2]; }
+		const float s_1 = (pick > 0) ? (s.s_1 - v_prev) / w_pick : s.s_1 / w_pick;
+		const float w_glossy = (rc1 == 0) ? width[0] : (rc1 == 1 ? width[1] : width[2]);
+		const float w_diffuse = (rc2 == 0) ? width[0] : (rc2 == 1 ? width[1] : width[2]);
+		Col scolor = mkc(0.f, 0.f, 0.f);
+		float cos_ng_wi;
+		if(ci == 0)
+		{
+			wi = reflect_dir(n, wo);
+			scolor = (col3(m.mirror_color) * kr) * m.mirror_strength;
+			s.pdf = w_pick;
+		}
+		else if(ci == 1) hs = blinn_sample(s_1, s.s_2, m.exponent);
+		else
+		{
+			wi = sample_cos_hemisphere(n, sp.nu, sp.nv, s_1, s.s_2);
+			cos_ng_wi = dot(sp.ng, wi);
+			if(cos_ng_wo * cos_ng_wi < 0.f) return mkc(0.f, 0.f, 0.f);
+		}
+		float wi_n = fabsf(dot(wi, n));
+		const float wo_n = fabsf(dot(wo, n));
+		if(ci != 0)
+		{
+			if(use1)
+			{
+				float cos_wo_h;
+				V3 h;
+				if(ci != 1)
+				{
+					h = normalize(wi + wo);
+					cos_wo_h = dot(wo, h);
+				}
+				else
+				{
+					h = sp.nu * hs.x + sp.nv * hs.y + n * hs.z;
+					cos_wo_h = dot(wo, h);
+					if(cos_wo_h < 0.f) { h = vec_reflect(h, n); cos_wo_h = dot(wo, h); }
+					wi = reflect_dir(h, wo);
+					cos_ng_wi = dot(sp.ng, wi);
+					if(cos_ng_wo * cos_ng_wi < 0.f) return mkc(0.f, 0.f, 0.f);
+				}
+				wi_n = fabsf(dot(wi, n));
+				const float cos_hn = dot(h, n);
+				s.pdf += blinn_pdf(cos_hn, cos_wo_h, m.exponent) * w_glossy;
+				const float glossy = (float)((double)(blinn_d(cos_hn, m.exponent) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+				scolor = col3(m.gloss_color) * (glossy * kt);
+			}
+			if(use2)
+			{
+				Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color)) * kt;
+				if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+				scolor = scolor + add;
+				s.pdf += wi_n * w_diffuse;
+			}
+			w = wi_n / (s.pdf * 0.99f + 0.01f);
+		}
+		else w = 1.f;
+		s.sampled = m.c_flags[ci];
+		return scolor;
 	}
 	if(m.type == YAFGPU_MAT_MIRROR)
 	{	// MirrorMaterial::sample, material_glass.cc:467-473: flags ignored, pdf left at Sample's initial 0

@@ -186,6 +186,20 @@ def material_desc(m):
         d.as_diffuse = int(m.get("as_diffuse", True))
         d.oren_nayar = int(m.get("diffuse_brdf", "") == "Oren-Nayar")
         d.sigma = m.get("sigma", 0.1)
+    elif t == "coated_glossy":
+        d.type = 5
+        d.glossy_color = f3(*m.get("color", (1, 1, 1))[:3])
+        d.diffuse_color = f3(*m.get("diffuse_color", (1, 1, 1))[:3])
+        d.mirror_color = f3(*m.get("mirror_color", (1, 1, 1))[:3])
+        d.glossy_diffuse_reflect = m.get("diffuse_reflect", 0.0)
+        d.glossy_reflect = m.get("glossy_reflect", 1.0)
+        d.exponent = m.get("exponent", 50.0)
+        d.as_diffuse = int(m.get("as_diffuse", True))
+        d.specular_reflect = m.get("specular_reflect", 1.0)
+        ior = m.get("IOR", 1.4)
+        d.ior = 1.0000001 if ior == 1.0 else ior
+        d.oren_nayar = int(m.get("diffuse_brdf", "") == "Oren-Nayar")
+        d.sigma = m.get("sigma", 0.1)
     elif t == "glass":
         d.type = 3
         d.color = f3(*m.get("filter_color", (1, 1, 1))[:3])

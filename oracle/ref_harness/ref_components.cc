@@ -34,6 +34,7 @@
 #include "common/scene.h"
 #include "camera/camera_perspective.h"
 #include "material/material_glass.h"
+#include "material/material_coated_glossy.h"
 #include "light/light_area.h"
 #include "light/light_point.h"
 #include "material/material_shiny_diffuse.h"
@@ -498,6 +499,31 @@ static void sec_materials(Json &j)
 		pm["fake_shadows"] = Parameter(true);
 		Material *m = GlassMaterial::factory(pm, no_nodes, fake_env());
 		run_material(j, "gg1", m, 160, true, 2);
+	}
+	{	// cg0: coated glossy with a diffuse substrate
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.9f, 0.8f, 0.7f, 1.f)); pm["diffuse_color"] = Parameter(Rgba(0.3f, 0.5f, 0.7f, 1.f));
+		pm["mirror_color"] = Parameter(Rgba(1.f, 0.95f, 0.9f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.5f); pm["glossy_reflect"] = Parameter(0.6f); pm["exponent"] = Parameter(80.f);
+		pm["specular_reflect"] = Parameter(0.8f); pm["IOR"] = Parameter(1.6); pm["as_diffuse"] = Parameter(true);
+		Material *m = CoatedGlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "cg0", m, 240, true, 1);
+	}
+	{	// cg1: coated glossy without substrate, Oren-Nayar irrelevant, deep recursion level (getSpecular stops above 5)
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(1.f, 1.f, 1.f, 1.f)); pm["glossy_reflect"] = Parameter(0.9f); pm["exponent"] = Parameter(300.f);
+		pm["specular_reflect"] = Parameter(1.f); pm["IOR"] = Parameter(1.0);
+		Material *m = CoatedGlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "cg1", m, 120, true, 6);
+	}
+	{	// cg2: diffuse substrate with Oren-Nayar
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.8f, 0.8f, 0.8f, 1.f)); pm["diffuse_color"] = Parameter(Rgba(0.7f, 0.3f, 0.2f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.8f); pm["glossy_reflect"] = Parameter(0.3f); pm["exponent"] = Parameter(25.f);
+		pm["specular_reflect"] = Parameter(0.5f); pm["IOR"] = Parameter(1.8);
+		pm["diffuse_brdf"] = Parameter(std::string("Oren-Nayar")); pm["sigma"] = Parameter(0.3);
+		Material *m = CoatedGlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "cg2", m, 160, true, 2);
 	}
 	{	// mi0: mirror
 		ParamMap pm;

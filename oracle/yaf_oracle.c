@@ -1016,6 +1016,28 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 			m->use_oren = 1;
 		}
 	}
+	else if(d->type == YOR_MAT_COATED_GLOSSY)
+	{	/* CoatedGlossyMaterial::factory + ctor, material_coated_glossy.cc:41-66, 464-560 (Blinn lobe, no nodes) */
+		m->gloss_color = C(d->glossy_color[0], d->glossy_color[1], d->glossy_color[2]);
+		m->diff_color = C(d->diffuse_color[0], d->diffuse_color[1], d->diffuse_color[2]);
+		m->mirror_color = C(d->mirror_color[0], d->mirror_color[1], d->mirror_color[2]);
+		m->mirror_strength = d->specular_reflect;
+		m->ior = d->ior;
+		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
+		m->as_diffuse = d->as_diffuse;
+		m->c_flags[0] = BSDF_SPECULAR | BSDF_REFLECT;
+		m->c_flags[1] = m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
+		if(m->diffuse > 0) { m->c_flags[2] = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; m->n_bsdf = 3; }
+		else { m->c_flags[2] = BSDF_NONE; m->n_bsdf = 2; }
+		m->flags = m->c_flags[0] | m->c_flags[1] | m->c_flags[2];
+		if(d->oren_nayar)
+		{	/* initOrenNayar :81-87 */
+			double sigma_2 = d->sigma * d->sigma;
+			m->oren_a = (float)(1.0 - 0.5 * (sigma_2 / (sigma_2 + 0.33)));
+			m->oren_b = (float)(0.45 * sigma_2 / (sigma_2 + 0.09));
+			m->use_oren = 1;
+		}
+	}
 	else if(d->type == YOR_MAT_GLASS)
 	{	/* GlassMaterial::factory + ctor, material_glass.cc:32-49, 340-388 (no dispersion, no absorption, no nodes) */
 		m->ior = d->ior;
@@ -1152,8 +1174,8 @@ static void mat_init_bsdf(const mat_t *m, bsdf_dat *dat, unsigned *bsdf_types)
 		if(m->is_translucent) dat->component[2] = m->translucency_strength;
 		if(m->is_diffuse) dat->component[3] = m->diffuse_strength;
 	}
-	else if(m->type == YOR_MAT_GLOSSY)
-	{	/* material_glossy.cc:51-64 */
+	else if(m->type == YOR_MAT_GLOSSY || m->type == YOR_MAT_COATED_GLOSSY)
+	{	/* material_glossy.cc:51-64, material_coated_glossy.cc:68-81 */
 		dat->m_diffuse = m->diffuse;
 		dat->m_glossy = m->reflectivity;
 		dat->p_diffuse = fminf_(0.6f, 1.f - (dat->m_glossy / (dat->m_glossy + (1.f - dat->m_glossy) * dat->m_diffuse)));
@@ -1235,6 +1257,31 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		}
 		return col;
 	}
+	if(m->type == YOR_MAT_COATED_GLOSSY)
+	{	/* material_coated_glossy.cc:130-186 */
+		rgb col = C(0, 0, 0);
+		int diffuse_flag = (bsdfs & BSDF_DIFFUSE) != 0;
+		if(!diffuse_flag || (vdot(sp->ng, wl) * vdot(sp->ng, wo)) < 0.f) return col;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float kr, kt;
+		float wi_n = fabsf(vdot(wl, n));
+		float wo_n = fabsf(vdot(wo, n));
+		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		if((m->as_diffuse && diffuse_flag) || (!m->as_diffuse && (bsdfs & BSDF_GLOSSY)))
+		{
+			v3 h = vnormalize(vadd(wo, wl));
+			float cos_wi_h = vdot(wl, h);
+			float glossy = (float)((double)(kt * blinn_d(vdot(h, n), m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			col = cscale(m->gloss_color, glossy);
+		}
+		if(m->with_diffuse && diffuse_flag)
+		{
+			rgb add_col = cscale(cscale(m->diff_color, dat->m_diffuse * (1.f - dat->m_glossy)), kt);
+			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, wl, wo, n));
+			col = cadd(col, add_col);
+		}
+		return col;
+	}
 	return C(0, 0, 0); /* LightMaterial::eval, material_simple.h */
 }
 
@@ -1265,6 +1312,37 @@ static float mat_pdf(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo,
 				{
 					pdf += fabsf(vdot(wi, n)) * width;
 				}
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001) return 0.f;
+		return pdf / sum;
+	}
+	else if(m->type == YOR_MAT_COATED_GLOSSY)
+	{	/* material_coated_glossy.cc:376-424 */
+		if((vdot(sp->ng, wo) * vdot(sp->ng, wi)) < 0.f) return 0.f;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		float pdf = 0.f, kr, kt;
+		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		float accum_c[3], sum = 0.f, width;
+		accum_c[0] = kr;
+		accum_c[1] = kt * (1.f - dat->p_diffuse);
+		accum_c[2] = kt * (dat->p_diffuse);
+		int n_match = 0;
+		for(int i = 0; i < m->n_bsdf; ++i)
+		{
+			if((bsdfs & m->c_flags[i]) == m->c_flags[i])
+			{
+				width = accum_c[i];
+				sum += width;
+				if(i == 1)
+				{
+					v3 h = vnormalize(vadd(wi, wo));
+					float cos_wo_h = vdot(wo, h);
+					float cos_n_h = vdot(n, h);
+					pdf += blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * width;
+				}
+				else if(i == 2) pdf += fabsf(vdot(wi, n)) * width;
 				++n_match;
 			}
 		}
@@ -1392,6 +1470,29 @@ static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp
 			if(outside || raylevel < 3) { wi[0] = refl; col[0] = cscale(m->spec_refl_color, kr); *do_reflect = 1; }
 		}
 		else { col[0] = m->spec_refl_color; wi[0] = refl; *do_reflect = 1; }
+		return;
+	}
+	if(m->type == YOR_MAT_COATED_GLOSSY)
+	{	/* CoatedGlossyMaterial::getSpecular, material_coated_glossy.cc:426-462 */
+		int outside = vdot(sp->ng, wo) >= 0;
+		float cos_wo_n = vdot(sp->n, wo);
+		v3 n, ng = outside ? sp->ng : vneg(sp->ng);
+		if(outside ? (cos_wo_n >= 0) : (cos_wo_n <= 0)) n = sp->n;
+		else { float f = (float)(1.00001 * (double)cos_wo_n); n = vnormalize(vsub(sp->n, vmul(wo, f))); }
+		float kr, kt;
+		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		if(raylevel > 5) return;
+		const float vn = 2.0f * (wo.x * n.x + wo.y * n.y + wo.z * n.z);
+		v3 r = V(vn * n.x - wo.x, vn * n.y - wo.y, vn * n.z - wo.z);
+		col[0] = cscale(cscale(m->mirror_color, kr), m->mirror_strength);
+		float cos_wi_ng = vdot(r, ng);
+		if((double)cos_wi_ng < 0.01)
+		{
+			float k = (float)(0.01 - (double)cos_wi_ng);
+			r = vnormalize(vadd(r, vmul(ng, k)));
+		}
+		wi[0] = r;
+		*do_reflect = 1;
 		return;
 	}
 	if(m->type == YOR_MAT_MIRROR)
@@ -1624,6 +1725,119 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 			scolor = cadd(scolor, add_col);
 		}
 		*w = wi_n / (s->pdf * 0.99f + 0.01f);
+		return scolor;
+	}
+	if(m->type == YOR_MAT_COATED_GLOSSY)
+	{	/* material_coated_glossy.cc:188-374, Blinn lobe */
+		float cos_ng_wo = vdot(sp->ng, wo), cos_ng_wi;
+		v3 n = face_forward(sp->ng, sp->n, wo);
+		v3 hs = V(0, 0, 0);
+		s->pdf = 0.f;
+		float kr, kt, wi_n = 0.f, wo_n = 0.f;
+		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		int use[3] = {0, 0, 0};
+		float sum = 0.f, accum_c[3], val[3], width[3];
+		int c_index[3], rc_index[3] = {0, 0, 0};
+		accum_c[0] = kr;
+		accum_c[1] = kt * (1.f - dat->p_diffuse);
+		accum_c[2] = kt * (dat->p_diffuse);
+		int n_match = 0, pick = -1;
+		for(int i = 0; i < m->n_bsdf; ++i)
+		{
+			if((s->flags & m->c_flags[i]) == m->c_flags[i])
+			{
+				use[i] = 1;
+				width[n_match] = accum_c[i];
+				c_index[n_match] = i;
+				rc_index[i] = n_match;
+				sum += width[n_match];
+				val[n_match] = sum;
+				++n_match;
+			}
+		}
+		if(!n_match || (double)sum < 0.00001)
+		{
+			*wi = reflect_dir(n, wo);
+			return C(0, 0, 0);
+		}
+		else if(n_match == 1) { pick = 0; width[0] = 1.f; }
+		else
+		{
+			float inv_sum = 1.f / sum;
+			for(int i = 0; i < n_match; ++i)
+			{
+				val[i] *= inv_sum;
+				width[i] *= inv_sum;
+				if((s->s_1 <= val[i]) && (pick < 0)) pick = i;
+			}
+		}
+		if(pick < 0) pick = n_match - 1;
+		float s_1;
+		if(pick > 0) s_1 = (s->s_1 - val[pick - 1]) / width[pick];
+		else s_1 = s->s_1 / width[pick];
+		rgb scolor = C(0, 0, 0);
+		switch(c_index[pick])
+		{
+			case 0:
+				*wi = reflect_dir(n, wo);
+				scolor = cscale(cscale(m->mirror_color, kr), m->mirror_strength);
+				s->pdf = width[pick];
+				break;
+			case 1:
+				hs = blinn_sample(s_1, s->s_2, m->exponent);
+				break;
+			default:
+				*wi = sample_cos_hemisphere(n, sp->nu, sp->nv, s_1, s->s_2);
+				cos_ng_wi = vdot(sp->ng, *wi);
+				if(cos_ng_wo * cos_ng_wi < 0) return C(0, 0, 0);
+		}
+		wi_n = fabsf(vdot(*wi, n));
+		wo_n = fabsf(vdot(wo, n));
+		if(c_index[pick] != 0)
+		{
+			if(use[1])
+			{
+				float glossy, cos_wo_h;
+				v3 h;
+				if(c_index[pick] != 1)
+				{
+					h = vnormalize(vadd(*wi, wo));
+					hs = V(vdot(h, sp->nu), vdot(h, sp->nv), vdot(h, n));
+					cos_wo_h = vdot(wo, h);
+				}
+				else
+				{
+					h = vadd(vadd(vmul(sp->nu, hs.x), vmul(sp->nv, hs.y)), vmul(n, hs.z));
+					cos_wo_h = vdot(wo, h);
+					if(cos_wo_h < 0.f)
+					{
+						const float vn = 2.0f * (h.x * n.x + h.y * n.y + h.z * n.z);
+						h = V(vn * n.x - h.x, vn * n.y - h.y, vn * n.z - h.z);
+						cos_wo_h = vdot(wo, h);
+					}
+					*wi = reflect_dir(h, wo);
+					cos_ng_wi = vdot(sp->ng, *wi);
+					if(cos_ng_wo * cos_ng_wi < 0) return C(0, 0, 0);
+				}
+				wi_n = fabsf(vdot(*wi, n));
+				{
+					float cos_hn = vdot(h, n);
+					s->pdf += blinn_pdf(cos_hn, cos_wo_h, m->exponent) * width[rc_index[1]];
+					glossy = (float)((double)(blinn_d(cos_hn, m->exponent) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+				}
+				scolor = cscale(m->gloss_color, glossy * kt);
+			}
+			if(use[2])
+			{
+				rgb add_col = cscale(diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color), kt);
+				if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+				scolor = cadd(scolor, add_col);
+				s->pdf += wi_n * width[rc_index[2]];
+			}
+			*w = wi_n / (s->pdf * 0.99f + 0.01f);
+		}
+		else *w = 1.f;
+		s->sampled_flags = m->c_flags[c_index[pick]];
 		return scolor;
 	}
 	/* LightMaterial::sample, material_simple.cc:41-46 */

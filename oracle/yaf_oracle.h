@@ -25,7 +25,8 @@ extern "C" {
 
 enum { YOR_MAT_SHINYDIFFUSE = 0, YOR_MAT_GLOSSY = 1, YOR_MAT_LIGHT = 2,
        YOR_MAT_GLASS = 3,   /* color = filter_color, mirror_color, ior = IOR, sigma = transmit_filter (double), fresnel_effect = fake_shadows */
-       YOR_MAT_MIRROR = 4   /* color, specular_reflect = reflect */ };
+       YOR_MAT_MIRROR = 4,  /* color, specular_reflect = reflect */
+       YOR_MAT_COATED_GLOSSY = 5 /* glossy's fields + mirror_color, specular_reflect = mirror strength, ior = IOR */ };
 enum { YOR_LIGHT_AREA = 0, YOR_LIGHT_POINT = 1 };
 enum { YOR_INTEGRATOR_PATH = 0, YOR_INTEGRATOR_DIRECT = 1 };
 enum { YOR_FILTER_BOX = 0, YOR_FILTER_MITCHELL = 1, YOR_FILTER_GAUSS = 2, YOR_FILTER_LANCZOS = 3 };

@@ -470,3 +470,24 @@ def test_transparent_shadows(shadow_depth, pipeline):
     compare_films(film, ofilm, f"transparent shadows, depth {shadow_depth}", exact_weights=True)
     opaque, _ = po.OracleScene(sc).render(dict(rd, transpShad=False))
     assert po.film_to_rgb(ofilm)[..., :3].sum() > po.film_to_rgb(opaque)[..., :3].sum() * 1.02, "filtered shadows let light through"
+
+
+def test_coated_glossy_material(pipeline):
+    """CoatedGlossyMaterial (as_diffuse): Blinn lobe + diffuse substrate under a Fresnel-weighted specular coat that
+    recursiveRaytrace follows (material_coated_glossy.cc)."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(300, seed=37, res=(48, 40), sigma=0.07)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "coated_glossy", "color": (0.9, 0.8, 0.7), "diffuse_color": (0.3, 0.5, 0.7), "mirror_color": (1.0, 0.95, 0.9),
+                            "diffuse_reflect": 0.5, "glossy_reflect": 0.6, "exponent": 80.0, "specular_reflect": 0.8, "IOR": 1.6})
+    sc["materials"].append({"type": "coated_glossy", "color": (1.0, 1.0, 1.0), "glossy_reflect": 0.9, "exponent": 300.0, "IOR": 1.0})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[0:4] = nm - 2                                   # two walls
+    free = np.arange(10, len(tm)); tm[free[0::3]] = nm - 1
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(48, 40, 6, bounces=3, raydepth=3)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "coated glossy")

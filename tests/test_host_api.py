@@ -56,7 +56,7 @@ def test_factories_fail_loudly_outside_scope():
     yi = fresh()
     yi.startScene(0)
     for kind, params, needle in [
-        ("material", {"type": "coated_glossy"}, "scope"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
+        ("material", {"type": "rough_glass"}, "scope"), ("material", {"type": "coated_glossy", "as_diffuse": False}, "as_diffuse"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
         ("material", {"type": "glossy", "anisotropic": True}, "anisotropic"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
@@ -69,7 +69,7 @@ def test_factories_fail_loudly_outside_scope():
     assert not yi.createMaterial("untyped") and "type" in yi.getLastError()
     strict = fresh(strict=True)
     strict.startScene(0)
-    strict.paramsSet({"type": "coated_glossy"})
+    strict.paramsSet({"type": "blend_mat"})
     with pytest.raises(YafaRayError):
         strict.createMaterial("g")
 

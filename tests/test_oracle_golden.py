@@ -219,7 +219,7 @@ def test_lights(gold):
 
 
 # RenderState::raylevel_ when the golden getSpecular calls were made (GlassMaterial::getSpecular depends on it)
-SPEC_RAYLEVEL = {"gg0d": 4, "gg1": 2}
+SPEC_RAYLEVEL = {"gg0d": 4, "gg1": 2, "cg1": 6, "cg2": 2}
 
 MATERIALS = {
     "sd0": {"type": "shinydiffusemat", "color": (0.7, 0.6, 0.5), "diffuse_reflect": 0.9},
@@ -233,6 +233,11 @@ MATERIALS = {
     "gg0": {"type": "glass", "IOR": 1.52, "filter_color": (0.6, 0.9, 0.7), "transmit_filter": 0.8, "mirror_color": (0.95, 0.9, 1.0)},
     "gg0d": {"type": "glass", "IOR": 1.52, "filter_color": (0.6, 0.9, 0.7), "transmit_filter": 0.8, "mirror_color": (0.95, 0.9, 1.0)},
     "gg1": {"type": "glass", "IOR": 2.1, "filter_color": (1.0, 0.5, 0.5), "transmit_filter": 0.3, "fake_shadows": True},
+    "cg0": {"type": "coated_glossy", "color": (0.9, 0.8, 0.7), "diffuse_color": (0.3, 0.5, 0.7), "mirror_color": (1.0, 0.95, 0.9),
+            "diffuse_reflect": 0.5, "glossy_reflect": 0.6, "exponent": 80.0, "specular_reflect": 0.8, "IOR": 1.6, "as_diffuse": True},
+    "cg1": {"type": "coated_glossy", "color": (1, 1, 1), "glossy_reflect": 0.9, "exponent": 300.0, "specular_reflect": 1.0, "IOR": 1.0},
+    "cg2": {"type": "coated_glossy", "color": (0.8, 0.8, 0.8), "diffuse_color": (0.7, 0.3, 0.2), "diffuse_reflect": 0.8, "glossy_reflect": 0.3,
+            "exponent": 25.0, "specular_reflect": 0.5, "IOR": 1.8, "diffuse_brdf": "Oren-Nayar", "sigma": 0.3},
     "mi0": {"type": "mirror", "color": (0.9, 0.8, 0.6), "reflect": 0.85},
     "gl0": {"type": "glossy", "color": (0.9, 0.85, 0.8), "diffuse_color": (0.4, 0.5, 0.6), "diffuse_reflect": 0.4,
             "glossy_reflect": 0.6, "exponent": 50.0, "as_diffuse": True},

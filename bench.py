@@ -62,27 +62,25 @@ def cpu_baseline(name, budget_s=20.0):
     the same scene at reduced resolution / samples per pixel, sized from a pilot run to ~budget_s of CPU wall."""
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # sized iteratively: a small pilot, then runs at the workload's spp whose pixel count is scaled from the rate of
-    # the previous one until a run lasts at least half the budget (the first runs pay thread start-up and cold
-    # caches, so their rate underestimates).  The camera resolution is part of the scene, so each size is its own
-    # scene; sizes may exceed the workload's own resolution: same scene, more pixels.
-    spp = w_spp = WORKLOADS[name]["spp"]
-    sres, run_spp, build_s = 128, 8, 0.0
-    for attempt in range(4):
+    # sized by growth: runs at the workload's spp whose pixel count grows by at most 8x per step, from the rate of the
+    # step before, until one lasts at least a third of the budget — that one is reported.  (Short runs pay thread
+    # start-up and cold caches, so their rate underestimates; growing in bounded steps keeps both the overshoot and
+    # the total time bounded.)  The camera resolution is part of the scene, so each size is its own scene; sizes may
+    # exceed the workload's own resolution: same scene, more pixels.
+    spp = WORKLOADS[name]["spp"]
+    sres, build_s = 64, 0.0
+    for step in range(8):
         w, sc, rd = make_workload(name, res=sres)
         t0 = time.time()
         osc = po.OracleScene(sc)            # kd build is setup, not timed
         build_s = time.time() - t0
-        _, st = osc.render(dict(rd, AA_minsamples=run_spp, oracle_threads=cores, tile_size=8))
+        _, st = osc.render(dict(rd, AA_minsamples=spp, oracle_threads=cores, tile_size=8))
         osc.close()
         rays = st.rays_closest + st.rays_shadow
-        if run_spp == w_spp and (st.render_seconds >= 0.5 * budget_s or sres >= 2048):
+        if st.render_seconds >= budget_s / 3.0 or sres >= 2048:
             break
-        rate = rays / max(st.render_seconds, 1e-6)
-        rays_per_sample = rays / max(st.camera_samples, 1)
-        samples = budget_s * rate / rays_per_sample
-        sres = int(max(32, min(2048, (samples / spp) ** 0.5))) // 32 * 32
-        run_spp = w_spp
+        grow = min(8.0, max(1.5, 0.8 * budget_s / max(st.render_seconds, 1e-3)))
+        sres = int(min(2048, max(sres + 32, sres * grow ** 0.5))) // 32 * 32
     return {"value": round(rays / st.render_seconds / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"same scene ({w['n_tris']} tris), {sres}x{sres} px, {spp} spp, {rays} rays in {st.render_seconds:.2f} s "
                       f"(oracle kd build {build_s:.1f} s excluded)"}

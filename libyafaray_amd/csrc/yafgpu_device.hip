@@ -1023,6 +1023,7 @@ struct yafgpu_scene
 	// wavefront workspace (allocated on first use, sized for kWfMaxPaths paths or the whole frame)
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
+	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
 	bool profiling = false;
@@ -1228,6 +1229,9 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 	if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
 	if(s->wf_filt) (void)hipFree(s->wf_filt);
+	if(s->side_stream) (void)hipStreamDestroy(s->side_stream);
+	if(s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	delete s;
 }
@@ -1416,6 +1420,13 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	int iters = 1 + r_all;
 	if(rp.integrator == YAFGPU_INTEGRATOR_PATH)
 		iters += std::max(1, rp.path_samples) * ((1 + r_one) + std::max(0, rp.bounces - 1) * (1 + r_one));
+	const bool overlap = std::getenv("YAFGPU_NO_OVERLAP") == nullptr;
+	if(overlap && !s->side_stream)
+	{
+		HIP_OK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+		HIP_OK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+		HIP_OK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+	}
 	hipEvent_t ev[2] = {nullptr, nullptr};
 	if(s->profiling) { HIP_OK(hipEventCreate(&ev[0])); HIP_OK(hipEventCreate(&ev[1])); for(int k = 0; k < 4; ++k) { s->prof_ms[k] = 0; s->prof_launches[k] = 0; } }
 	auto timed = [&](int slot, auto &&launch) -> int {
@@ -1466,13 +1477,29 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			}
 			else if(frames == 0 && it >= iters) break;
 			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 8 * sizeof(uint32_t), stream));
+			const bool overlap_now = overlap && it > 0 && !s->profiling;
+			if(overlap_now)
+			{	// fork point: everything enqueued so far (the previous shade, the counter reset) precedes both launches
+				HIP_OK(hipEventRecord(s->ev_fork, stream));
+				HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
+			}
 			if((rc = timed(0, [&] {
 				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
 				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
+			// The two traversal launches of an iteration are independent (each drains its own queue, writes its own
+			// answers), and a persistent kernel's tail leaves CUs idle: outside profiling the any-hit launch goes to a
+			// side stream so that its waves fill the closest-hit launch's tail (and vice versa).
+			const bool fork = overlap_now;
+			hipStream_t any_stream = fork ? s->side_stream : stream;
 			if(it > 0 && (rc = timed(1, [&] {
-				if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, stream, a);
-				else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, stream, a);
-				else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, stream, a); }))) return rc;
+				if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
+				else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);
+				else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a); }))) return rc;
+			if(fork)
+			{
+				HIP_OK(hipEventRecord(s->ev_join, s->side_stream));
+				HIP_OK(hipStreamWaitEvent(stream, s->ev_join, 0));
+			}
 			if((rc = timed(2, [&] { hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
 			// swap queues: what shade produced is the next iteration's input
 			cur ^= 1;

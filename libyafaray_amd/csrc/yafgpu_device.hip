@@ -1420,7 +1420,9 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	int iters = 1 + r_all;
 	if(rp.integrator == YAFGPU_INTEGRATOR_PATH)
 		iters += std::max(1, rp.path_samples) * ((1 + r_one) + std::max(0, rp.bounces - 1) * (1 + r_one));
-	const bool overlap = std::getenv("YAFGPU_NO_OVERLAP") == nullptr;
+	// opt-in (YAFGPU_OVERLAP=1): +2-4 % on the bench scenes, but per-kernel durations then overlap in a profiler trace, so
+	// the default keeps one kernel on the GPU at a time and the roofline numbers comparable with rocprofv3's
+	const bool overlap = std::getenv("YAFGPU_OVERLAP") != nullptr;
 	if(overlap && !s->side_stream)
 	{
 		HIP_OK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));

@@ -491,3 +491,44 @@ def test_coated_glossy_material(pipeline):
     film, st, ofilm, ost = render_both(sc, rd)
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, "coated glossy")
+
+
+def test_xml_scene_with_every_feature(pipeline, tmp_path):
+    """The C++ XML loader driven with everything the device path does — glass, mirror, coated glossy, mirror /
+    transparent shinydiffuse, depth of field, recursion depth, transparent shadows, adaptive multi-pass AA with a
+    gauss filter and a sample clamp — against the oracle fed by an independent Python parse of the same file."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline renders the single-pass pinhole diffuse subset only")
+    from tests import xml_scene, xml_writer
+    sc = scenes.cornell_soup(240, seed=43, res=(44, 36), sigma=0.08)
+    sc["materials"] = [dict(m, type=m.get("type", "shinydiffusemat")) for m in sc["materials"]]
+    sc["materials"][0].update({"specular_reflect": 0.3, "mirror_color": (0.9, 0.9, 1.0)})
+    sc["materials"] += [
+        {"type": "glass", "IOR": 1.5, "filter_color": (0.8, 0.95, 0.85), "transmit_filter": 0.9, "fake_shadows": True},
+        {"type": "mirror", "color": (0.9, 0.85, 0.7), "reflect": 0.9},
+        {"type": "coated_glossy", "color": (0.9, 0.8, 0.7), "diffuse_color": (0.3, 0.5, 0.7), "diffuse_reflect": 0.5, "glossy_reflect": 0.6,
+         "exponent": 80.0, "specular_reflect": 0.8, "IOR": 1.6},
+        {"type": "shinydiffusemat", "color": (0.4, 0.8, 0.5), "diffuse_reflect": 0.6, "transparency": 0.6, "transmit_filter": 0.7},
+    ]
+    tm = np.array(sc["tri_mat"], np.int32)
+    free = np.arange(10, len(tm)); nm = len(sc["materials"])
+    for k in range(4):
+        tm[free[k::6]] = nm - 4 + k
+    sc["tri_mat"] = tm
+    sc["camera"] = dict(sc["camera"], aperture=0.03, dof_distance=3.8, bokeh_type="hexagon", bokeh_rotation=15.0)
+    rd = scenes.render_settings(44, 36, 3, bounces=2, raydepth=3, transpShad=True, shadowDepth=3, background=(0.2, 0.25, 0.4),
+                                AA_passes=3, AA_inc_samples=2, AA_threshold=0.02, AA_clamp_samples=2.0, filter_type="gauss", AA_pixelwidth=1.5)
+    path = str(tmp_path / "everything.xml")
+    xml_writer.write(path, sc, rd)
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film, st = yi.getFilm(44, 36), yi.getRenderStats()
+    osc_scene, ord_ = xml_scene.load(path)
+    from libyafaray_amd import interface
+    osc = po.OracleScene(osc_scene)
+    osc.set_tree(*interface.build_kdtree(osc_scene["verts"], threads=4)[:3])      # riVdC(1) == riS(1): see test_multi_pass_anti_aliasing
+    ofilm, ost = osc.render(ord_)
+    assert st.camera_samples == ost.camera_samples
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "xml scene with every feature", exact_weights=False)

@@ -69,7 +69,8 @@ def load(path):
     integ = integrators[render["integrator_name"]]
     rd = dict(render)
     rd["integrator"] = integ["type"]
-    for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract"):
+    for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth",
+              "transpShad", "shadowDepth"):
         if k in integ:
             rd[k] = integ[k]
     if background is not None and "background_name" in render:

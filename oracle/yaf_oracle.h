@@ -5,12 +5,14 @@
  * cpu_baseline leg may load it.  The product (libyafaray_amd) never links or calls it.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - fast-math, QMC, createCs/sampleCosHemisphere, Bound::cross, perspective camera,
- *     area/point lights, shinydiffuse/glossy/light materials are pinned bit-for-bit against
+ *   - fast-math, QMC, createCs/sampleCosHemisphere, Bound::cross, perspective camera (pinhole and
+ *     depth of field), area/point lights, shinydiffuse/glossy/coated-glossy/glass/mirror/light
+ *     materials (eval, pdf, sample, getSpecular, getAlpha, getTransparency) are pinned bit-for-bit against
  *     the reference's own sources compiled here (oracle/_ref, IEEE build) and to ~1e-4
  *     against the reference's -ffast-math release flags (tests/golden/ref_components_*.json).
- *   - kd traversal, Triangle::intersect/getSurface, PathIntegrator::integrate,
- *     doLightEstimation, renderTile and ImageFilm::addSample are restated from the source
+ *   - kd traversal (intersect / intersectS / intersectTs), Triangle::intersect/getSurface,
+ *     PathIntegrator::integrate, recursiveRaytrace, doLightEstimation, TiledIntegrator::render /
+ *     renderTile, ImageFilm::addSample / nextPass are restated from the source
  *     but the reference's implementation of them is NOT buildable under this project's
  *     rules (cmake-generated header): for those rows parity is UNPINNED.
  */

@@ -103,6 +103,8 @@ typedef struct yafgpu_scene_desc
 	const yafgpu_light *lights;
 	yafgpu_camera camera;
 	int32_t build_threads;       /* host threads for the kd build; <=0: hardware concurrency */
+	int32_t build_on_device;     /* 1: build the kd-tree on the GPU (kdtree_build_device.hip); 0: host builder.
+	                                The environment variable YAFGPU_BUILD=device|host overrides it. */
 } yafgpu_scene_desc;
 
 typedef struct yafgpu_render_params
@@ -214,6 +216,8 @@ int yafgpu_probe(yafgpu_scene_t *scene, int32_t op, int32_t n, const float *in, 
  * TriKdTree ctor, kdtree_triangle.cc:76-157), exposed so that host tests can check the tree the
  * kernels will walk.  nodes = n_nodes*2 uint32 (kdtree_build.h layout), refs = n_leaf_refs uint32. */
 typedef struct yafgpu_kdtree yafgpu_kdtree_t;
+/* the same on the GPU (needs a device); NULL on failure, yafgpu_last_error() says why */
+yafgpu_kdtree_t *yafgpu_kdtree_build_device(const float *verts, int32_t n_tris);
 yafgpu_kdtree_t *yafgpu_kdtree_build(const float *verts, int32_t n_tris, int32_t threads);
 void yafgpu_kdtree_info(const yafgpu_kdtree_t *tree, yafgpu_tree_info *info);
 void yafgpu_kdtree_get(const yafgpu_kdtree_t *tree, uint32_t *nodes, uint32_t *refs, float bound6[6]);

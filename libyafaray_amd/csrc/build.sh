@@ -10,9 +10,10 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 mkdir -p "$HERE/obj"
 "$HIPCC" $FLAGS -c "$HERE/yafgpu_device.hip" -o "$HERE/obj/yafgpu_device.o" ${YAFGPU_EXTRA_FLAGS:-}
 "$HIPCC" $FLAGS -c "$HERE/kdtree_build.cpp" -o "$HERE/obj/kdtree_build.o"
+"$HIPCC" $FLAGS -c "$HERE/kdtree_build_device.hip" -o "$HERE/obj/kdtree_build_device.o"
 SRCS_CPP=""
 for f in yafaray_c_api yafaray_xml; do
   if [ -f "$HERE/$f.cpp" ]; then "$HIPCC" $FLAGS -c "$HERE/$f.cpp" -o "$HERE/obj/$f.o"; SRCS_CPP="$SRCS_CPP $HERE/obj/$f.o"; fi
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/yafgpu_device.o" "$HERE/obj/kdtree_build.o" $SRCS_CPP -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/yafgpu_device.o" "$HERE/obj/kdtree_build.o" "$HERE/obj/kdtree_build_device.o" $SRCS_CPP -lpthread
 echo "built $OUT"

@@ -363,6 +363,15 @@ yafgpu_kdtree_t *yafgpu_kdtree_build(const float *verts, int32_t n_tris, int32_t
 	yafgpu::build_kdtree(verts, n_tris, 48, threads, k->t);
 	return k;
 }
+void yafgpu_internal_set_error(const char *msg);    // yafgpu_device.hip: the library's last-error string
+yafgpu_kdtree_t *yafgpu_kdtree_build_device(const float *verts, int32_t n_tris)
+{
+	auto *k = new yafgpu_kdtree();
+	k->n_tris = n_tris;
+	std::string err;
+	if(yafgpu::build_kdtree_device(verts, n_tris, 48, k->t, &err)) { yafgpu_internal_set_error(err.c_str()); delete k; return nullptr; }
+	return k;
+}
 void yafgpu_kdtree_info(const yafgpu_kdtree_t *k, yafgpu_tree_info *info)
 {
 	info->n_nodes = (uint32_t)k->t.nodes.size(); info->n_leaf_refs = (uint32_t)k->t.refs.size();

@@ -5,6 +5,7 @@
 // the reference's build *parameters* (scene.cc:818, kdtree_triangle.cc:89-100).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace yafgpu {
@@ -27,5 +28,9 @@ struct KdTree
 // verts: n_tris*9 floats (a,b,c).  depth_cap bounds the tree depth (the traversal stack never
 // needs more entries than the depth).  threads<=0: hardware concurrency.
 void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, KdTree &out);
+
+// The same tree built on the GPU (kdtree_build_device.hip): breadth-first binned / exact-candidate SAH with the same
+// parameters and cost model.  Returns 0, or a negative code with *err set (never falls back to the host builder).
+int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err);
 
 } // namespace yafgpu

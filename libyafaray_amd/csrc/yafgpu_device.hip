@@ -1071,6 +1071,7 @@ static const int kPrimsHost[50] = {1, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37
 extern "C" {
 
 const char *yafgpu_last_error(void) { return g_err.c_str(); }
+extern "C" void yafgpu_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 
 int yafgpu_device_count(void)
 {
@@ -1102,7 +1103,16 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
 	for(int i = 0; i < d->n_materials; ++i) if((d->materials[i].type == YAFGPU_MAT_SHINYDIFFUSE && d->materials[i].is_transparent) || (d->materials[i].type == YAFGPU_MAT_GLASS && d->materials[i].fake_shadow)) s->has_transparent = true;
 	const auto t0 = std::chrono::steady_clock::now();
-	build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
+	{
+		bool on_device = d->build_on_device != 0;
+		if(const char *e = std::getenv("YAFGPU_BUILD")) on_device = std::strcmp(e, "device") == 0;
+		if(on_device)
+		{
+			std::string err;
+			if(build_kdtree_device(d->verts, d->n_tris, kDepthCap, s->tree, &err)) { delete s; return fail(-20, err); }
+		}
+		else build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
+	}
 	s->info.build_seconds = s->tree.build_seconds;
 	s->info.n_nodes = (uint32_t)s->tree.nodes.size();
 	s->info.n_leaf_refs = (uint32_t)s->tree.refs.size();

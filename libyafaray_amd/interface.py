@@ -60,7 +60,7 @@ GPU_ABI_SYMBOLS = [
     "yafgpu_last_error", "yafgpu_device_count", "yafgpu_set_device", "yafgpu_scene_create", "yafgpu_scene_destroy",
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host", "yafgpu_render_passes_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
-    "yafgpu_kdtree_build", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
+    "yafgpu_kdtree_build", "yafgpu_kdtree_build_device", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
     "yafgpu_set_profiling", "yafgpu_get_profile",
 ]
 
@@ -356,16 +356,24 @@ class TreeInfo(C.Structure):
                 ("build_seconds", C.c_double), ("upload_seconds", C.c_double), ("device_bytes", C.c_uint64)]
 
 
-def build_kdtree(verts, threads=0):
-    """Host-only build of the flattened kd-tree the kernels walk -> (nodes (n,2) u32, refs (m,) u32, bound (6,) f32, info)."""
+def build_kdtree(verts, threads=0, device=False):
+    """Build of the flattened kd-tree the kernels walk, on the host (no GPU needed) or on the device
+    -> (nodes (n,2) u32, refs (m,) u32, bound (6,) f32, info)."""
     L = load()
     v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
     L.yafgpu_kdtree_build.restype = C.c_void_p
     L.yafgpu_kdtree_build.argtypes = [C.POINTER(C.c_float), C.c_int32, C.c_int32]
+    L.yafgpu_kdtree_build_device.restype = C.c_void_p
+    L.yafgpu_kdtree_build_device.argtypes = [C.POINTER(C.c_float), C.c_int32]
     L.yafgpu_kdtree_info.argtypes = [C.c_void_p, C.POINTER(TreeInfo)]
     L.yafgpu_kdtree_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     L.yafgpu_kdtree_destroy.argtypes = [C.c_void_p]
-    h = L.yafgpu_kdtree_build(v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0], threads)
+    if device:
+        h = L.yafgpu_kdtree_build_device(v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0])
+        if not h:
+            raise YafaRayError("device kd build: " + L.yafgpu_last_error().decode())
+    else:
+        h = L.yafgpu_kdtree_build(v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0], threads)
     info = TreeInfo()
     L.yafgpu_kdtree_info(h, C.byref(info))
     nodes = np.zeros((max(info.n_nodes, 1), 2), np.uint32)

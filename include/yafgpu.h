@@ -103,7 +103,8 @@ typedef struct yafgpu_scene_desc
 	const yafgpu_light *lights;
 	yafgpu_camera camera;
 	int32_t build_threads;       /* host threads for the kd build; <=0: hardware concurrency */
-	int32_t build_on_device;     /* 1: build the kd-tree on the GPU (kdtree_build_device.hip); 0: host builder.
+	int32_t build_on_device;     /* kd-tree builder: 1 = on the GPU (kdtree_build_device.hip), -1 = host builder,
+	                                0 = by size (GPU from 65 536 triangles on).  Both give the same query results.
 	                                The environment variable YAFGPU_BUILD=device|host overrides it. */
 } yafgpu_scene_desc;
 

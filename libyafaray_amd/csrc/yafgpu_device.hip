@@ -1104,7 +1104,8 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	for(int i = 0; i < d->n_materials; ++i) if((d->materials[i].type == YAFGPU_MAT_SHINYDIFFUSE && d->materials[i].is_transparent) || (d->materials[i].type == YAFGPU_MAT_GLASS && d->materials[i].fake_shadow)) s->has_transparent = true;
 	const auto t0 = std::chrono::steady_clock::now();
 	{
-		bool on_device = d->build_on_device != 0;
+		// 0: by size -- the device builder wins from a few ten thousand triangles on (1 M: 0.07 s against 0.33 s)
+		bool on_device = d->build_on_device > 0 || (d->build_on_device == 0 && d->n_tris >= 65536);
 		if(const char *e = std::getenv("YAFGPU_BUILD")) on_device = std::strcmp(e, "device") == 0;
 		if(on_device)
 		{

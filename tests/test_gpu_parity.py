@@ -7,6 +7,7 @@ from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 
+DEVICE_TREE = __import__("os").environ.get("YAFGPU_BUILD") == "device"     # the suite also runs with the GPU-built tree
 RTOL = 1e-4     # BASELINE.json north_star: per-pixel RGB within 1e-4 relative
 ABS_FLOOR = 1e-3
 
@@ -316,7 +317,7 @@ def test_multi_pass_anti_aliasing(aa, pipeline):
     # materials, which TriKdTree::intersect resolves by visiting order (kdtree_triangle.cc:782), i.e. by tree
     # topology.  The oracle therefore walks the same tree as the device here; everywhere else it builds its own.
     osc = po.OracleScene(sc)
-    osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4)[:3])
+    osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4, device=DEVICE_TREE)[:3])
     ofilm, ost = osc.render(rd)
     assert st.camera_samples == ost.camera_samples
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
@@ -527,7 +528,7 @@ def test_xml_scene_with_every_feature(pipeline, tmp_path):
     osc_scene, ord_ = xml_scene.load(path)
     from libyafaray_amd import interface
     osc = po.OracleScene(osc_scene)
-    osc.set_tree(*interface.build_kdtree(osc_scene["verts"], threads=4)[:3])      # riVdC(1) == riS(1): see test_multi_pass_anti_aliasing
+    osc.set_tree(*interface.build_kdtree(osc_scene["verts"], threads=4, device=DEVICE_TREE)[:3])      # riVdC(1) == riS(1): see test_multi_pass_anti_aliasing
     ofilm, ost = osc.render(ord_)
     assert st.camera_samples == ost.camera_samples
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow

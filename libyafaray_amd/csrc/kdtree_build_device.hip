@@ -184,16 +184,24 @@ __global__ __launch_bounds__(kBuildBlock) void build_level(const BuildArgs a)
 			{
 				for(int i = tid; i < 3 * (kBins + 1); i += kBuildBlock) { (&s_starts[0][0])[i] = 0u; (&s_ends[0][0])[i] = 0u; }
 				__syncthreads();
-				for(uint32_t i = (uint32_t)tid; i < np; i += kBuildBlock)
+				// four references in flight per thread: a lone workgroup streaming a huge node is bound by load latency
+				for(uint32_t i0 = (uint32_t)tid; i0 < np; i0 += 4u * kBuildBlock)
 				{
-					const Ref r = a.refs_in[w.begin + i];
-					for(int axis = 0; axis < 3; ++axis)
+					Ref r[4];
+#pragma unroll
+					for(int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * kBuildBlock; if(i < np) r[u] = a.refs_in[w.begin + i]; }
+#pragma unroll
+					for(int u = 0; u < 4; ++u)
 					{
-						if(!(d[axis] > 0.f)) continue;
-						const float scale = (float)kBins / d[axis];
-						int s = (int)floorf((r.lo[axis] - w.lo[axis]) * scale), e = (int)ceilf((r.hi[axis] - w.lo[axis]) * scale);
-						s = min(max(s, 0), kBins); e = min(max(e, 0), kBins);
-						atomicAdd(&s_starts[axis][s], 1u); atomicAdd(&s_ends[axis][e], 1u);
+						if(i0 + (uint32_t)u * kBuildBlock >= np) continue;
+						for(int axis = 0; axis < 3; ++axis)
+						{
+							if(!(d[axis] > 0.f)) continue;
+							const float scale = (float)kBins / d[axis];
+							int s = (int)floorf((r[u].lo[axis] - w.lo[axis]) * scale), e = (int)ceilf((r[u].hi[axis] - w.lo[axis]) * scale);
+							s = min(max(s, 0), kBins); e = min(max(e, 0), kBins);
+							atomicAdd(&s_starts[axis][s], 1u); atomicAdd(&s_ends[axis][e], 1u);
+						}
 					}
 				}
 				__syncthreads();
@@ -260,13 +268,34 @@ __global__ __launch_bounds__(kBuildBlock) void build_level(const BuildArgs a)
 			if(tid < 2) s_count[tid] = 0u;
 			__syncthreads();
 			uint32_t nl = 0u, nr = 0u;
-			for(uint32_t i = (uint32_t)tid; i < np; i += kBuildBlock)
+			if(small)
 			{
-				float lo, hi;
-				if(small) { lo = s_box[i][best_axis]; hi = s_box[i][best_axis + 3]; }
-				else { const Ref &r = a.refs_in[w.begin + i]; lo = r.lo[best_axis]; hi = r.hi[best_axis]; }
-				nl += (lo < best_pos || (lo == best_pos && hi == best_pos)) ? 1u : 0u;
-				nr += (hi > best_pos) ? 1u : 0u;
+				for(uint32_t i = (uint32_t)tid; i < np; i += kBuildBlock)
+				{
+					const float lo = s_box[i][best_axis], hi = s_box[i][best_axis + 3];
+					nl += (lo < best_pos || (lo == best_pos && hi == best_pos)) ? 1u : 0u;
+					nr += (hi > best_pos) ? 1u : 0u;
+				}
+			}
+			else
+			{
+				for(uint32_t i0 = (uint32_t)tid; i0 < np; i0 += 4u * kBuildBlock)
+				{
+					float lo[4], hi[4];
+#pragma unroll
+					for(int u = 0; u < 4; ++u)
+					{
+						const uint32_t i = i0 + (uint32_t)u * kBuildBlock;
+						lo[u] = INFINITY; hi[u] = -INFINITY;       // counts on neither side
+						if(i < np) { const Ref &r = a.refs_in[w.begin + i]; lo[u] = r.lo[best_axis]; hi[u] = r.hi[best_axis]; }
+					}
+#pragma unroll
+					for(int u = 0; u < 4; ++u)
+					{
+						nl += (lo[u] < best_pos || (lo[u] == best_pos && hi[u] == best_pos)) ? 1u : 0u;
+						nr += (hi[u] > best_pos) ? 1u : 0u;
+					}
+				}
 			}
 			if(nl) atomicAdd(&s_count[0], nl);
 			if(nr) atomicAdd(&s_count[1], nr);
@@ -327,16 +356,20 @@ __global__ __launch_bounds__(kBuildBlock) void build_level(const BuildArgs a)
 			const int axis = s_axis; const float pos = s_split;
 			// a wave reserves its slots with one LDS atomic per side
 			const int lane = tid & 63;
+			auto fetch = [&](uint32_t i, Ref &r) -> bool
+			{
+				if(i >= np) return false;
+				if(small) { for(int k = 0; k < 3; ++k) { r.lo[k] = s_box[i][k]; r.hi[k] = s_box[i][3 + k]; } r.tri = s_tri[i]; }
+				else r = a.refs_in[w.begin + i];
+				return true;
+			};
+			Ref ahead{};
+			bool ahead_valid = fetch((uint32_t)tid, ahead);
 			for(uint32_t base = 0u; base < np; base += kBuildBlock)
 			{
-				const uint32_t i = base + (uint32_t)tid;
-				const bool valid = i < np;
-				Ref r{};
-				if(valid)
-				{
-					if(small) { for(int k = 0; k < 3; ++k) { r.lo[k] = s_box[i][k]; r.hi[k] = s_box[i][3 + k]; } r.tri = s_tri[i]; }
-					else r = a.refs_in[w.begin + i];
-				}
+				const Ref r = ahead;
+				const bool valid = ahead_valid;
+				ahead_valid = fetch(base + kBuildBlock + (uint32_t)tid, ahead);      // the next round's load overlaps this round's stores
 				const float lo = r.lo[axis], hi = r.hi[axis];
 				const bool go_l = valid && (lo < pos || (lo == pos && hi == pos)), go_r = valid && hi > pos;
 				const unsigned long long ml = __ballot(go_l), mr = __ballot(go_r);

@@ -62,7 +62,8 @@ typedef struct yafgpu_material
 	float filter_color[3];         /* transmit_filter * filter_color + (1 - transmit_filter) */
 	int32_t fake_shadow;
 	uint32_t tm_flags;             /* the transmission lobe: Filter|Transmit with fake shadows, else Specular|Transmit */
-	int32_t pad[1];
+	int32_t has_vol_i;             /* glass "absorption": vol_i_ = BeerVolumeHandler (material_glass.cc:371-398), bsdf_flags has Volumetric */
+	float beer_sigma[3];           /* its sigma_a_ = -log(absorption) / absorption_dist (volumehandler_beer.cc:28-35) */
 } yafgpu_material;
 
 /* A light after its constructor ran on the host (light_area.cc:34-52, light_point.cc:28-36) */

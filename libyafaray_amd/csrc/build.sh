@@ -8,12 +8,21 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # expressions (discrete hit / lobe / shadow decisions decide image parity)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 mkdir -p "$HERE/obj"
-"$HIPCC" $FLAGS -c "$HERE/yafgpu_device.hip" -o "$HERE/obj/yafgpu_device.o" ${YAFGPU_EXTRA_FLAGS:-}
+# the device unit and the scene-specialised shading kernels (yafgpu_shade_variant.hip) compile side by side
+"$HIPCC" $FLAGS -c "$HERE/yafgpu_device.hip" -o "$HERE/obj/yafgpu_device.o" ${YAFGPU_EXTRA_FLAGS:-} &
+PID_DEV=$!
+#   diffuse: shinydiffusemat + light_mat, no recursiveRaytrace (BASELINE configs C2, C3)
+"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=diffuse -DYAFGPU_MAT_MASK=0x5u -DYAFGPU_FEAT_RECURSE=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_diffuse.o" ${YAFGPU_EXTRA_FLAGS:-} &
+PID_V1=$!
+#   glossy: + glossy (as_diffuse), no recursiveRaytrace (C4)
+"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=glossy -DYAFGPU_MAT_MASK=0x7u -DYAFGPU_FEAT_RECURSE=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_glossy.o" ${YAFGPU_EXTRA_FLAGS:-} &
+PID_V2=$!
+wait $PID_DEV; wait $PID_V1; wait $PID_V2
 "$HIPCC" $FLAGS -c "$HERE/kdtree_build.cpp" -o "$HERE/obj/kdtree_build.o"
 "$HIPCC" $FLAGS -c "$HERE/kdtree_build_device.hip" -o "$HERE/obj/kdtree_build_device.o"
 SRCS_CPP=""
 for f in yafaray_c_api yafaray_xml; do
   if [ -f "$HERE/$f.cpp" ]; then "$HIPCC" $FLAGS -c "$HERE/$f.cpp" -o "$HERE/obj/$f.o"; SRCS_CPP="$SRCS_CPP $HERE/obj/$f.o"; fi
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/yafgpu_device.o" "$HERE/obj/kdtree_build.o" "$HERE/obj/kdtree_build_device.o" $SRCS_CPP -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/yafgpu_device.o" "$HERE/obj/shade_diffuse.o" "$HERE/obj/shade_glossy.o" "$HERE/obj/kdtree_build.o" "$HERE/obj/kdtree_build_device.o" $SRCS_CPP -lpthread
 echo "built $OUT"

@@ -264,7 +264,7 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	return true;
 }
 
-// GlassMaterial::factory + ctor, material_glass.cc:340-443, :32-49 (no dispersion, absorption or shader nodes)
+// GlassMaterial::factory + ctor, material_glass.cc:340-443, :32-49 (no dispersion or shader nodes)
 bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 {
 	double ior = 1.4, filt = 0.0, disp = 0.0; float fcol[3] = {1, 1, 1}, scol[3] = {1, 1, 1}, absorp[3] = {1, 1, 1}, wire = 0.f;
@@ -273,7 +273,6 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	p.get("dispersion_power", disp); p.get("fake_shadows", fake); p.get("receive_shadows", recv); p.get("visibility", vis);
 	p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire); p.getColor("absorption", absorp);
 	if(disp > 0.0) return fail(yi, "glass: dispersion is not supported by the GPU path (recursiveRaytrace's dispersive branch)");
-	if(absorp[0] < 1.f || absorp[1] < 1.f || absorp[2] < 1.f) return fail(yi, "glass: absorption (a volume handler) is not supported by the GPU path");
 	if(add_depth != 0) return fail(yi, "glass: additionaldepth is not supported by the GPU path");
 	if(wire != 0.f) return fail(yi, "glass: wireframe shading is not supported by the GPU path");
 	if(!yi->eparams.empty()) return fail(yi, "glass: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
@@ -286,6 +285,19 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	m.bsdf_flags = 0x1u | 0x10u | 0x20u;                         // BsdfAllSpecular
 	if(fake) m.bsdf_flags |= 0x40u;
 	m.tm_flags = fake ? (0x40u | 0x20u) : (0x1u | 0x20u);
+	if(absorp[0] < 1.f || absorp[1] < 1.f || absorp[2] < 1.f)
+	{	// material_glass.cc:371-398: vol_i_ = BeerVolumeHandler(absorption, absorption_dist); volumehandler_beer.cc:28-35
+		double dist = 1.0;
+		p.get("absorption_dist", dist);
+		const float maxlog = (float)std::log(1e38);
+		for(int k = 0; k < 3; ++k)
+		{
+			m.beer_sigma[k] = (absorp[k] > 1e-38) ? (float)-std::log((double)absorp[k]) : maxlog;
+			if(dist != 0.f) m.beer_sigma[k] = m.beer_sigma[k] * (float)(1.f / dist);
+		}
+		m.has_vol_i = 1;
+		m.bsdf_flags |= 0x100u;                                   // BsdfVolumetric
+	}
 	return true;
 }
 // MirrorMaterial::factory + ctor, material_glass.cc:486-493, material_glass.h:74-79

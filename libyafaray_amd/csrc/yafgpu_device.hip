@@ -693,6 +693,7 @@ YG_DEV uint32_t wave_sum(uint32_t v)
 	return v;
 }
 
+#ifndef YAFGPU_VARIANT_TU      // the one-kernel pipeline belongs to the main unit
 // ------------------------------------------------------------------------------------------------
 // The render pass: TiledIntegrator::renderTile (integrator_tiled.cc:309-521) for every tile of the
 // shard + ImageFilm::addSample (imagefilm.cc:925-1015) for the box filter of width <= 1.002 px
@@ -818,8 +819,11 @@ __global__ __launch_bounds__(kBlock, YAFGPU_WAVES) void render_kernel(const Rend
 	}
 }
 
+#endif // YAFGPU_VARIANT_TU
+
 } // namespace yafgpu
 #include "yafgpu_wavefront.h"
+#ifndef YAFGPU_VARIANT_TU      // everything below: kernels and host code of the main unit
 namespace yafgpu {
 
 // film[y][x] = own + right(x-1,y) + down(x,y-1) + diag(x-1,y-1): the neighbours' splats onto this pixel
@@ -1024,6 +1028,8 @@ struct yafgpu_scene
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
+	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
+	bool has_volumetric = false;
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
 	bool profiling = false;
@@ -1101,6 +1107,16 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	}
 	auto *s = new yafgpu_scene();
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
+	{	// material types some triangle actually uses (a definition nothing refers to does not cost a kernel variant)
+		std::vector<char> used((size_t)d->n_materials, 0);
+		for(int i = 0; i < d->n_tris; ++i) used[(size_t)d->tri_mat[i]] = 1;
+		for(int i = 0; i < d->n_materials; ++i)
+		{
+			if(!used[(size_t)i]) continue;
+			s->mat_mask |= 1u << (uint32_t)d->materials[i].type;
+			if(d->materials[i].bsdf_flags & kVolumetric) s->has_volumetric = true;
+		}
+	}
 	for(int i = 0; i < d->n_materials; ++i) if((d->materials[i].type == YAFGPU_MAT_SHINYDIFFUSE && d->materials[i].is_transparent) || (d->materials[i].type == YAFGPU_MAT_GLASS && d->materials[i].fake_shadow)) s->has_transparent = true;
 	const auto t0 = std::chrono::steady_clock::now();
 	{
@@ -1351,6 +1367,41 @@ static int wf_grid(const void *kernel, int cus)
 	return cus * std::min(per_cu, cap);
 }
 
+// Scene-specialised builds of wf_shade (yafgpu_shade_variant.hip), most specialised first.  A variant serves a scene
+// whose material types are a subset of its mask and which needs recursiveRaytrace only if the variant has it; every
+// other scene takes the general kernel of this unit.  YAFGPU_SHADE_VARIANT=general forces the general kernel.
+extern "C" {
+#define YG_DECLARE_SHADE_VARIANT(name) \
+	void yafgpu_shade_##name##_describe(uint32_t *, int *); const void *yafgpu_shade_##name##_kernel(); \
+	int yafgpu_shade_##name##_launch(const void *, size_t, int, hipStream_t);
+YG_DECLARE_SHADE_VARIANT(diffuse)
+YG_DECLARE_SHADE_VARIANT(glossy)
+#undef YG_DECLARE_SHADE_VARIANT
+}
+struct ShadeVariant
+{
+	const char *name;
+	void (*describe)(uint32_t *, int *);
+	const void *(*kernel)();
+	int (*launch)(const void *, size_t, int, hipStream_t);
+};
+static const ShadeVariant kShadeVariants[] = {
+	{"diffuse", yafgpu_shade_diffuse_describe, yafgpu_shade_diffuse_kernel, yafgpu_shade_diffuse_launch},
+	{"glossy", yafgpu_shade_glossy_describe, yafgpu_shade_glossy_kernel, yafgpu_shade_glossy_launch},
+};
+static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
+{
+	if(const char *e = std::getenv("YAFGPU_SHADE_VARIANT")) if(std::strcmp(e, "general") == 0) return nullptr;
+	const bool needs_recurse = frames > 0 || s->has_volumetric;
+	for(const ShadeVariant &v : kShadeVariants)
+	{
+		uint32_t mask = 0u; int recurse = 0;
+		v.describe(&mask, &recurse);
+		if((s->mat_mask & ~mask) == 0u && (recurse || !needs_recurse)) return &v;
+	}
+	return nullptr;
+}
+
 static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream, bool stats)
 {
 	const yafgpu_render_params &rp = ra.rp;
@@ -1419,7 +1470,9 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	const int cus = prop.multiProcessorCount;
 	const int g_trace_c = stats ? wf_grid((const void *)wf_trace<false, true>, cus) : wf_grid((const void *)wf_trace<false, false>, cus);
 	const int g_trace_s = stats ? wf_grid((const void *)wf_trace<true, true>, cus) : wf_grid((const void *)wf_trace<true, false>, cus);
-	const int g_shade = wf_grid((const void *)wf_shade, cus);
+	const ShadeVariant *shade_variant = pick_shade_variant(s, frames);
+	if(std::getenv("YAFGPU_VERBOSE")) std::fprintf(stderr, "[yafgpu] shading kernel: %s (materials 0x%x, frames %d)\n", shade_variant ? shade_variant->name : "general", s->mat_mask, frames);
+	const int g_shade = wf_grid(shade_variant ? shade_variant->kernel() : (const void *)wf_shade, cus);
 	// upper bound of kd-tree queries per path = iterations needed (every path advances one query per iteration)
 	int r_all = 0, r_one = 0;
 	for(int i = 0; i < s->n_lights; ++i)
@@ -1513,7 +1566,11 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				HIP_OK(hipEventRecord(s->ev_join, s->side_stream));
 				HIP_OK(hipStreamWaitEvent(stream, s->ev_join, 0));
 			}
-			if((rc = timed(2, [&] { hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
+			int variant_rc = 0;
+			if((rc = timed(2, [&] {
+				if(shade_variant) variant_rc = shade_variant->launch(&a, sizeof a, g_shade, stream);
+				else hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
+			if(variant_rc) return fail(-21, "shading kernel variant and main unit disagree on the argument layout");
 			// swap queues: what shade produced is the next iteration's input
 			cur ^= 1;
 			a.cnt_in = cnt[cur]; a.cnt_out = cnt[cur ^ 1];
@@ -1893,3 +1950,4 @@ int yafgpu_probe(yafgpu_scene_t *s, int32_t op, int32_t n, const float *in, int3
 }
 
 } // extern "C"
+#endif // YAFGPU_VARIANT_TU

@@ -19,6 +19,13 @@
 namespace yafgpu {
 
 // BsdfFlags, include/material/material.h:49-64
+// Material types this compilation of the shading code handles: a kernel built for scenes without some material types
+// (YAFGPU_MAT_MASK, one bit per YAFGPU_MAT_*) drops their code and the registers it would pin.
+#ifndef YAFGPU_MAT_MASK
+#define YAFGPU_MAT_MASK 0x3fu
+#endif
+#define YG_IS(m, T) ((((YAFGPU_MAT_MASK) >> (T)) & 1u) != 0u && (m).type == (T))
+
 enum : uint32_t {
 	kNone = 0, kSpecular = 1, kGlossy = 2, kDiffuse = 4, kDispersive = 8, kReflect = 0x10, kTransmit = 0x20,
 	kFilter = 0x40, kEmit = 0x80, kVolumetric = 0x100,
@@ -86,14 +93,14 @@ YG_DEV float oren_nayar(float oa, float ob, V3 wi, V3 wo, V3 n)
 YG_DEV uint32_t mat_init_bsdf(const yafgpu_material &m, BsdfDat &d)
 {
 	d.c0 = d.c1 = d.c2 = d.c3 = 0.f; d.m_diffuse = d.m_glossy = d.p_diffuse = 0.f;
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE))
 	{
 		if(m.is_mirror) d.c0 = m.mirror_strength;
 		if(m.is_transparent) d.c1 = m.transparency_strength;
 		if(m.is_translucent) d.c2 = m.translucency_strength;
 		if(m.is_diffuse) d.c3 = m.diffuse_strength;
 	}
-	else if(m.type == YAFGPU_MAT_GLOSSY || m.type == YAFGPU_MAT_COATED_GLOSSY)
+	else if(YG_IS(m, YAFGPU_MAT_GLOSSY) || YG_IS(m, YAFGPU_MAT_COATED_GLOSSY))
 	{
 		d.m_diffuse = m.diffuse;
 		d.m_glossy = m.reflectivity;
@@ -130,6 +137,14 @@ YG_DEV V3 blinn_sample(float s_1, float s_2, float e) // :99-106
 	const float sin_theta = f_sqrt(1.f - cos_theta * cos_theta);
 	const float phi = (float)((double)s_1 * k2Pi);
 	return mk(sin_theta * f_cos(phi), sin_theta * f_sin(phi), cos_theta);
+}
+
+// BeerVolumeHandler::transmittance over a ray that ended at tmax (volumehandler_beer.cc:37-48); fExp__(x) = fExp2__(M_LOG2E * x)
+YG_DEV Col beer_transmittance(const float sigma[3], float tmax)
+{
+	if(tmax < 0.f || tmax > 1e30f) return mkc(0.f, 0.f, 0.f);
+	const float l2e = (float)1.4426950408889634074;
+	return mkc(f_exp2(l2e * (-tmax * sigma[0])), f_exp2(l2e * (-tmax * sigma[1])), f_exp2(l2e * (-tmax * sigma[2])));
 }
 
 // refract__, vector.cc:86-108
@@ -176,7 +191,7 @@ YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
 // Material::eval — material_shiny_diffuse.cc:244-293, material_glossy.cc:113-173
 YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
 {
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE))
 	{
 		const float cos_ng_wo = dot(sp.ng, wo), cos_ng_wl = dot(sp.ng, wl);
 		const V3 n = face_forward(sp.ng, sp.n, wo);
@@ -192,7 +207,7 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		if(m.use_oren) m_d *= oren_nayar(m.oren_a, m.oren_b, wo, wl, n);
 		return col3(m.diffuse_color) * m_d;
 	}
-	if(m.type == YAFGPU_MAT_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_GLOSSY))
 	{
 		if(!(bsdfs & kDiffuse) || (dot(sp.ng, wl) * dot(sp.ng, wo)) < 0.f) return mkc(0.f, 0.f, 0.f);
 		Col col = mkc(0.f, 0.f, 0.f);
@@ -213,7 +228,7 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		}
 		return col;
 	}
-	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_COATED_GLOSSY))
 	{	// material_coated_glossy.cc:130-186
 		Col col = mkc(0.f, 0.f, 0.f);
 		const bool diffuse_flag = (bsdfs & kDiffuse) != 0u;
@@ -243,7 +258,7 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 // Material::pdf — material_shiny_diffuse.cc:410-460, material_glossy.cc:359-405
 YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wi, uint32_t bsdfs)
 {
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE))
 	{
 		if(!(bsdfs & kDiffuse)) return 0.f;
 		float pdf = 0.f, acc[4];
@@ -269,7 +284,7 @@ YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &s
 		if(!n_match || (double)sum < 0.00001) return 0.f;
 		return pdf / sum;
 	}
-	if(m.type == YAFGPU_MAT_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_GLOSSY))
 	{
 		if(dot(sp.ng, wo) * dot(sp.ng, wi) < 0.f) return 0.f;
 		const V3 n = face_forward(sp.ng, sp.n, wo);
@@ -293,7 +308,7 @@ YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &s
 		}
 		return pdf;
 	}
-	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_COATED_GLOSSY))
 	{	// material_coated_glossy.cc:376-424
 		if((dot(sp.ng, wo) * dot(sp.ng, wi)) < 0.f) return 0.f;
 		const V3 n = face_forward(sp.ng, sp.n, wo);
@@ -336,11 +351,11 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 // shadows (material_glass.cc:217-228); Material's default: opaque
 YG_DEV bool mat_is_transparent(const yafgpu_material &m)
 {
-	return (m.type == YAFGPU_MAT_SHINYDIFFUSE && m.is_transparent) || (m.type == YAFGPU_MAT_GLASS && m.fake_shadow);
+	return (YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE) && m.is_transparent) || (YG_IS(m, YAFGPU_MAT_GLASS) && m.fake_shadow);
 }
 YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 {
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE))
 	{
 		if(!m.is_transparent) return mkc(0.f, 0.f, 0.f);
 		float accum = 1.f;
@@ -352,7 +367,7 @@ YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 		const Col tcol = col3(m.diffuse_color) * f + mkc(1.f - f, 1.f - f, 1.f - f);
 		return tcol * accum;
 	}
-	if(m.type == YAFGPU_MAT_GLASS)
+	if(YG_IS(m, YAFGPU_MAT_GLASS))
 	{
 		const V3 n = face_forward(sp.ng, sp.n, wo);
 		float kr, kt;
@@ -365,8 +380,8 @@ YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 // Material::getAlpha: ShinyDiffuse (:568-597), Glass (material_glass.cc:217-240), everything else 1
 YG_DEV float mat_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo)
 {
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE) return sd_alpha(m, d, sp, wo);
-	if(m.type == YAFGPU_MAT_GLASS)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE)) return sd_alpha(m, d, sp, wo);
+	if(YG_IS(m, YAFGPU_MAT_GLASS))
 	{
 		const V3 n = face_forward(sp.ng, sp.n, wo);
 		float kr, kt;
@@ -388,7 +403,7 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 {
 	do_reflect = false; do_refract = false;
 	dir_reflect = mk(0.f, 0.f, 0.f); dir_refract = dir_reflect; col_reflect = mkc(0.f, 0.f, 0.f); col_refract = col_reflect;
-	if(m.type == YAFGPU_MAT_GLASS)
+	if(YG_IS(m, YAFGPU_MAT_GLASS))
 	{
 		const bool outside = dot(sp.ng, wo) > 0.f;
 		const V3 n = glass_normal(sp, wo);
@@ -404,7 +419,7 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 		else { col_reflect = col3(m.mirror_color); dir_reflect = vec_reflect(wo, n); do_reflect = true; }      // total inner reflection
 		return;
 	}
-	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_COATED_GLOSSY))
 	{	// CoatedGlossyMaterial::getSpecular, material_coated_glossy.cc:426-462
 		const bool outside = dot(sp.ng, wo) >= 0.f;
 		const float cos_wo_n = dot(sp.n, wo);
@@ -422,7 +437,7 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 		do_reflect = true;
 		return;
 	}
-	if(m.type == YAFGPU_MAT_MIRROR)
+	if(YG_IS(m, YAFGPU_MAT_MIRROR))
 	{
 		col_reflect = col3(m.mirror_color);
 		dir_reflect = reflect_dir(face_forward(sp.ng, sp.n, wo), wo);
@@ -462,7 +477,7 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 // material_simple.cc:41-46
 YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
 {
-	if(m.type == YAFGPU_MAT_GLASS)
+	if(YG_IS(m, YAFGPU_MAT_GLASS))
 	{	// GlassMaterial::sample, material_glass.cc:65-215, the branch without dispersion (:143-213)
 		if(!(s.flags & kSpecular)) { s.pdf = 0.f; return mkc(0.f, 0.f, 0.f); }
 		const V3 n = glass_normal(sp, wo);
@@ -493,7 +508,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		s.pdf = 0.f;
 		return mkc(0.f, 0.f, 0.f);
 	}
-	if(m.type == YAFGPU_MAT_COATED_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_COATED_GLOSSY))
 	{	// material_coated_glossy.cc:188-374, Blinn lobe
 		const float cos_ng_wo = dot(sp.ng, wo);
 		const V3 n = face_forward(sp.ng, sp.n, wo);
@@ -594,14 +609,14 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		s.sampled = m.c_flags[ci];
 		return scolor;
 	}
-	if(m.type == YAFGPU_MAT_MIRROR)
+	if(YG_IS(m, YAFGPU_MAT_MIRROR))
 	{	// MirrorMaterial::sample, material_glass.cc:467-473: flags ignored, pdf left at Sample's initial 0
 		wi = reflect_dir(sp.n, wo);
 		s.sampled = kSpecular | kReflect;
 		w = 1.f;
 		return col3(m.mirror_color) * (1.f / fabsf(dot(sp.n, wi)));
 	}
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE))
 	{
 		float acc[4];
 		const float cos_ng_wo = dot(sp.ng, wo);
@@ -669,7 +684,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		w = w * (alpha) + 1.f * (1.f - alpha);
 		return scolor;
 	}
-	if(m.type == YAFGPU_MAT_GLOSSY)
+	if(YG_IS(m, YAFGPU_MAT_GLOSSY))
 	{
 		const float cos_ng_wo = dot(sp.ng, wo);
 		const V3 n = face_forward(sp.ng, sp.n, wo);
@@ -750,8 +765,8 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 // Material::emit — material_shiny_diffuse.cc:295-306, material_simple.cc:50-57
 YG_DEV Col mat_emit(const yafgpu_material &m, const SurfPt &sp, V3 wo, bool include_lights)
 {
-	if(m.type == YAFGPU_MAT_SHINYDIFFUSE) return col3(m.emit_color);
-	if(m.type == YAFGPU_MAT_LIGHT)
+	if(YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE)) return col3(m.emit_color);
+	if(YG_IS(m, YAFGPU_MAT_LIGHT))
 	{
 		if(!include_lights) return mkc(0.f, 0.f, 0.f);
 		if(m.double_sided) return col3(m.light_col);

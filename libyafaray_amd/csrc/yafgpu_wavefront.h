@@ -226,6 +226,11 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 #define HGET(k) hot_get<k>(a, slot, h)
 #define HSET(k, v) hot_set<k>(a, slot, h, (v))
 
+#define FREC(L, j) wf_rec(a, kWfRecs + 5 * (L) + (j), slot)      // recursion frames, see st_recurse
+// recursiveRaytrace (frames, absorption): a kernel built with 0 serves scenes without specular / filter materials
+#ifndef YAFGPU_FEAT_RECURSE
+#define YAFGPU_FEAT_RECURSE 1
+#endif
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
 YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal)
 {
@@ -238,6 +243,8 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	{
 		c.col = mkc(0.f, 0.f, 0.f);
 		float alpha = rp.bg_transp ? 0.f : 1.f;
+		// a recursion level's own ray: the level above wants its tmax_ (the hit distance; -1 on a miss) for absorption
+		if(YAFGPU_FEAT_RECURSE && c.level > 0) FREC(c.level - 1, 3).w = got ? ans.y : -1.f;
 		if(!got)
 		{
 			if(rp.has_background && !rp.bg_transp_refract) c.col = c.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
@@ -290,6 +297,11 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
 	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, 0.f); REC(9) = f4(hit.ng, 0.f); REC(10) = f4(pwo, 0.f);
 	HSET(18, z4);
+	if(YAFGPU_FEAT_RECURSE && (mb & kVolumetric) && c.stage == kStDepth && pm.has_vol_i && dot(hit.n, pwo) < 0.f)
+	{	// integrator_path_tracer.cc:276-279: the segment ran inside an absorbing material (lcol does not depend on it)
+		const float4 r11 = HGET(11);
+		HSET(11, f4(c3(r11) * beer_transmittance(pm.beer_sigma, ans.y), r11.w));
+	}
 	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
 	if(want_dl)
 	{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
@@ -536,7 +548,6 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 //   F0 colour so far | alpha without a transmitted ray     F1 transmission weight | material alpha
 //   F2 hit point | flags (1: transmitted ray still to go, 2: it is the one out now)
 //   F3 transmitted direction                                 F4 reflection weight
-#define FREC(L, j) wf_rec(a, kWfRecs + 5 * (L) + (j), slot)
 YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
 {
 	REC(0) = f4(p, a.ra.ray_min_dist); REC(1) = f4(dir, -1.f);      // DiffRay(sp.p_, dir, scene_->ray_min_dist_)
@@ -545,7 +556,7 @@ YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
 YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	if(c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
+	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
 	const float4 r5 = REC(5);
 	if(!(ubits(r5.w) & (kSpecular | kFilter))) return W_RETURN;
 	const float4 p = REC(3);
@@ -561,9 +572,14 @@ YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 	const int L = c.level;
 	FREC(L, 0) = f4(c.col, REC(19).w);
 	FREC(L, 1) = f4(c_refr, m_alpha);
-	FREC(L, 2) = f4(sp0.p, fbits(refl ? (refr ? 1u : 0u) : 2u));
-	FREC(L, 3) = f4(d_refr, 0.f);
-	FREC(L, 4) = f4(c_refl, 0.f);
+	// :991, :1016 vol = material->getVolumeHandler(sp.ng_ * ref_ray.dir_ < 0): flags 4 / 8 = the reflected / transmitted ray
+	// runs inside the absorbing material
+	uint32_t vol = 0u;
+	if((ubits(r5.w) & kVolumetric) && m.has_vol_i)
+		vol = (refl && dot(sp0.ng, d_refl) < 0.f ? 4u : 0u) | (refr && dot(sp0.ng, d_refr) < 0.f ? 8u : 0u);
+	FREC(L, 2) = f4(sp0.p, fbits((refl ? (refr ? 1u : 0u) : 2u) | vol));
+	FREC(L, 3) = f4(d_refr, 0.f);                              // .w: the tmax_ of the ray that is out (st_after_closest)
+	FREC(L, 4) = f4(c_refl, fbits((uint32_t)sp0.mat));
 	wf_start_level(a, slot, c, sp0.p, refl ? d_refl : d_refr);
 	c.level = L + 1;
 	return W_PARK_CLOSEST;
@@ -576,18 +592,23 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 	for(;;)
 	{
 		if(rp.bg_transp) alpha = smax(alpha, 0.f);      // EmptyVolumeIntegrator: transmittance 1 (integrator_path_tracer.cc:336-344)
-		if(c.level == 0) { REC(19) = make_float4(0.f, 0.f, 0.f, alpha); return W_FINISH; }
+		if(!YAFGPU_FEAT_RECURSE || c.level == 0) { REC(19) = make_float4(0.f, 0.f, 0.f, alpha); return W_FINISH; }
 		const int P = c.level - 1;
 		const float4 f0 = FREC(P, 0), f2 = FREC(P, 2);
 		const uint32_t flags = ubits(f2.w);
-		const Col integ = c.col;
+		Col integ = c.col;
+		if(flags & ((flags & 2u) ? 8u : 4u))
+		{	// the ray ran inside absorbing glass: integ *= vcol (:991-994, :1016-1019)
+			const yafgpu_material &pm = a.ra.sc.mats[ubits(FREC(P, 4).w)];
+			integ = integ * beer_transmittance(pm.beer_sigma, FREC(P, 3).w);
+		}
 		if(!(flags & 2u))
 		{	// :980-990 the reflected ray is back
 			const Col col_p = c3(f0) + integ * c3(FREC(P, 4));
 			if(flags & 1u)
 			{	// :991-1023 now the transmitted one, at the same level
 				FREC(P, 0) = f4(col_p, f0.w);
-				FREC(P, 2) = f4(v3(f2), fbits(2u));
+				FREC(P, 2) = f4(v3(f2), fbits(2u | (flags & 8u)));
 				wf_start_level(a, slot, c, v3(f2), v3(FREC(P, 3)));
 				return W_PARK_CLOSEST;
 			}
@@ -715,6 +736,7 @@ YG_DEV void wf_push(uint32_t *queue, uint32_t *count, bool pred, uint32_t slot)
 	if(pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 
+#ifndef YAFGPU_VARIANT_TU      // a shade-kernel variant unit compiles wf_shade only
 // camera rays: TiledIntegrator::renderTile :378-410
 __global__ __launch_bounds__(kBlock) void wf_generate(const WfArgs a)
 {
@@ -1039,6 +1061,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 	}
 }
 
+#endif // YAFGPU_VARIANT_TU
 // resume every answered path: entries [0, n_closest) come from the closest queue, the rest from the resume queue
 #ifndef YAFGPU_SHADE_WAVES
 #define YAFGPU_SHADE_WAVES 3     // 168 VGPRs, 44 B of scratch; C2: 3 -> 7.25, 4 -> 8.5 ms per pass (4: 224 B of scratch)
@@ -1139,6 +1162,7 @@ YG_DEV float4 wf_clamped(float4 c, float max_value)
 	return c;
 }
 
+#ifndef YAFGPU_VARIANT_TU      // 
 // ImageFilm::addSample (imagefilm.cc:925-1015), box filter half-width 0.501: one thread per pixel of the
 // chunk adds its samples in index order into the own / right / down / diagonal planes
 __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
@@ -1224,4 +1248,5 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 		atomicAdd((unsigned long long *)&a.ra.counters->camera_samples, (unsigned long long)a.n_paths);
 }
 
+#endif // YAFGPU_VARIANT_TU
 } // namespace yafgpu

@@ -81,7 +81,7 @@ def _color(v):
     return ("color", float(v[0]), float(v[1]), float(v[2]), 1.0)
 
 
-_COLOR_KEYS = {"color", "mirror_color", "diffuse_color", "filter_color"}
+_COLOR_KEYS = {"color", "mirror_color", "diffuse_color", "filter_color", "absorption"}
 
 
 def load_scene(yi, scene, render):

@@ -32,6 +32,7 @@ class MaterialDesc(C.Structure):
         ("glossy_reflect", C.c_float), ("glossy_diffuse_reflect", C.c_float), ("exponent", C.c_float),
         ("as_diffuse", C.c_int32),
         ("light_color", f3), ("light_power", C.c_float), ("double_sided", C.c_int32), ("pad1", C.c_int32),
+        ("absorption", f3), ("has_absorption", C.c_int32), ("absorption_dist", C.c_double),
     ]
 
 
@@ -143,6 +144,7 @@ def lib():
     L.yor_material_probe.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, fp,
                                      C.POINTER(C.c_int32), fp]
     L.yor_lightmat_emit.argtypes = [C.POINTER(MaterialDesc), fp, fp, C.c_int, fp]
+    L.yor_beer_transmittance.argtypes = [fp, C.c_double, C.c_float, C.POINTER(C.c_int32), fp]
     _lib = L
     return L
 
@@ -207,9 +209,12 @@ def material_desc(m):
         d.ior = m.get("IOR", 1.4)
         d.sigma = m.get("transmit_filter", 0.0)          # a double parameter: filt * filt_col + (1 - filt)
         d.fresnel_effect = int(m.get("fake_shadows", False))
-        for k in ("dispersion_power", "absorption"):
-            if k in m and m[k] not in (0, 0.0, (1, 1, 1), (1.0, 1.0, 1.0)):
-                raise ValueError("glass: dispersion / absorption are outside the restated path")
+        if m.get("dispersion_power", 0.0) not in (0, 0.0):
+            raise ValueError("glass: dispersion is outside the restated path")
+        if "absorption" in m:
+            d.absorption = f3(*m["absorption"][:3])
+            d.has_absorption = 1
+            d.absorption_dist = m.get("absorption_dist", 1.0)
     elif t == "mirror":
         d.type = 4
         d.color = f3(*m.get("color", (1, 1, 1))[:3])

@@ -40,6 +40,7 @@
 #include "material/material_shiny_diffuse.h"
 #include "material/material_glossy.h"
 #include "material/material_simple.h"
+#include "volume/volumehandler_beer.h"
 
 using namespace yafaray4;
 
@@ -580,6 +581,34 @@ static void sec_materials(Json &j)
 	}
 }
 
+// BeerVolumeHandler(absorption colour, distance) + transmittance(ray.tmax_): what a glass material with "absorption"
+// multiplies onto the light that travelled through it (volumehandler_beer.cc:28-48, material_glass.cc:371-398)
+static void sec_beer(Json &j)
+{
+	std::vector<uint32_t> in, out;
+	RenderState state(nullptr);
+	const float cols[6][3] = {{0.5f, 0.7f, 0.9f}, {0.95f, 0.2f, 0.01f}, {1.f, 1.f, 0.3f}, {0.f, 0.5f, 1e-39f}, {0.33f, 0.66f, 0.99f}, {0.8f, 0.8f, 0.8f}};
+	const double dists[6] = {1.0, 0.35, 3.0, 1.0, 0.0, 12.5};
+	for(int c = 0; c < 6; ++c)
+	{
+		BeerVolumeHandler beer(Rgb(cols[c][0], cols[c][1], cols[c][2]), dists[c]);
+		const VolumeHandler *vol = &beer;
+		for(int i = 0; i < 24; ++i)
+		{
+			Ray ray(Point3(0.f, 0.f, 0.f), Vec3(0.f, 0.f, 1.f), 0.f, -1.f);
+			if(i == 0) ray.tmax_ = -1.f;
+			else if(i == 1) ray.tmax_ = 2e30f;
+			else if(i == 2) ray.tmax_ = 0.f;
+			else ray.tmax_ = urand() * (i % 3 == 0 ? 40.f : 2.f);
+			Rgb col(1.f);
+			const bool ok = vol->transmittance(state, ray, col);
+			in.push_back(f2u(cols[c][0])); in.push_back(f2u(cols[c][1])); in.push_back(f2u(cols[c][2])); in.push_back(f2u((float)dists[c])); in.push_back(f2u(ray.tmax_));
+			out.push_back(ok ? 1u : 0u); pushc(out, col);
+		}
+	}
+	j.arr_u32("beer_in5", in); j.arr_u32("beer_out4", out);
+}
+
 int main()
 {
 	Json j;
@@ -591,6 +620,7 @@ int main()
 	sec_camera_dof(j);
 	sec_lights(j);
 	sec_materials(j);
+	sec_beer(j);
 	j.s += "\n}\n";
 	fputs(j.s.c_str(), stdout);
 	return 0;

@@ -410,6 +410,7 @@ typedef struct
 	/* shinydiffuse state after config(), material_shiny_diffuse.cc:46-92 */
 	rgb diffuse_color, mirror_color, emit_color;
 	float mirror_strength, transparency_strength, translucency_strength, diffuse_strength, emit_strength, transmit_filter;
+	int has_vol_i; rgb beer_sigma;   /* vol_i_: BeerVolumeHandler of an absorbing glass */
 	int is_mirror, is_transparent, is_translucent, is_diffuse, has_fresnel;
 	float ior_squared;
 	int use_oren; float oren_a, oren_b;
@@ -943,6 +944,27 @@ static int scene_is_shadowed_ts(const yor_scene *s, v3 from, v3 dir, float tmin,
 typedef struct { float component[4]; float m_diffuse, m_glossy, p_diffuse; } bsdf_dat; /* SdDat / MDatT */
 typedef struct { float s_1, s_2, pdf; unsigned flags, sampled_flags; } sample_t;         /* material.h:68-78 */
 
+
+/* BeerVolumeHandler::BeerVolumeHandler(acol, dist), volumehandler_beer.cc:28-35 */
+static rgb beer_sigma(const float acol[3], double dist)
+{
+	const float maxlog = (float)log(1e38);
+	rgb s;
+	s.r = (acol[0] > 1e-38) ? (float)-log(acol[0]) : maxlog;
+	s.g = (acol[1] > 1e-38) ? (float)-log(acol[1]) : maxlog;
+	s.b = (acol[2] > 1e-38) ? (float)-log(acol[2]) : maxlog;
+	if(dist != 0.f) s = cscale(s, (float)(1.f / dist));
+	return s;
+}
+/* BeerVolumeHandler::transmittance, volumehandler_beer.cc:37-48; fExp__(x) = fExp2__(M_LOG2E * x) (util_math_optimizations.h) */
+static rgb beer_transmittance(rgb sigma, float tmax)
+{
+	if(tmax < 0.f || tmax > 1e30f) return C(0.f, 0.f, 0.f);
+	const float dist = tmax;
+	const float l2e = (float)1.4426950408889634074;
+	return C(yor_fexp2(l2e * (-dist * sigma.r)), yor_fexp2(l2e * (-dist * sigma.g)), yor_fexp2(l2e * (-dist * sigma.b)));
+}
+
 static void mat_configure(mat_t *m, const yor_material_desc *d)
 {
 	memset(m, 0, sizeof *m);
@@ -1049,6 +1071,14 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 		m->flags = BSDF_SPECULAR | BSDF_REFLECT | BSDF_TRANSMIT;          /* BsdfAllSpecular */
 		if(m->fake_shadow) m->flags |= BSDF_FILTER;
 		m->tm_flags = m->fake_shadow ? (BSDF_FILTER | BSDF_TRANSMIT) : (BSDF_SPECULAR | BSDF_TRANSMIT);
+		/* material_glass.cc:371-398: any channel of "absorption" below 1 -> bsdf_flags_ |= BsdfVolumetric and
+		 * vol_i_ = BeerVolumeHandler(absorption, absorption_dist (default 1)) */
+		if(d->has_absorption && (d->absorption[0] < 1.f || d->absorption[1] < 1.f || d->absorption[2] < 1.f))
+		{
+			m->flags |= BSDF_VOLUMETRIC;
+			m->has_vol_i = 1;
+			m->beer_sigma = beer_sigma(d->absorption, d->absorption_dist);
+		}
 	}
 	else if(d->type == YOR_MAT_MIRROR)
 	{	/* MirrorMaterial, material_glass.h:74-79, material_glass.cc:486-493 */
@@ -2309,7 +2339,8 @@ static rgb estimate_one_direct_light(rstate_t *st, const sp_t *sp, const mat_t *
 
 /* PathIntegrator::integrate, integrator_path_tracer.cc:112-347 (raylevel 0, no caustics, no
  * recursive raytrace: materials with specular/glossy/filter lobes are rejected by yor_render) */
-static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, float out_rgba[4])
+/* ray_tmax_out (may be NULL): the ray's tmax_ after the call, i.e. the distance to the first hit or the caller's tmax on a miss */
+static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, float out_rgba[4], float *ray_tmax_out)
 {
 	const yor_scene *s = st->s;
 	const yor_render_desc *rd = st->rd;
@@ -2381,6 +2412,9 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 					pwo = vneg(p_dir);
 					if(mat_bsdfs & BSDF_DIFFUSE) lcol = estimate_one_direct_light(st, hit, p_mat, &dat_n, pwo);
 					else lcol = C(0, 0, 0);
+					/* :276-279 the segment just travelled, if it ran inside an absorbing material (getVolumeHandler(inside)) */
+					if((mat_bsdfs & BSDF_VOLUMETRIC) && vdot(hit->n, pwo) < 0 && p_mat->has_vol_i)
+						throughput = cmul(throughput, beer_transmittance(p_mat->beer_sigma, p_tmax));
 					if(depth > rd->rr_min_bounces)
 					{	/* Russian roulette :282-288 */
 						float random_value = (float)mwc_next(st->prng);
@@ -2403,15 +2437,20 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 			mat_get_specular(material, &dat0, &sp, wo, raylevel + 1, &reflect, &refract, sdir, rcol);
 			if(reflect)
 			{
-				float integ[4];
-				integrate(st, sp.p, sdir[0], st->ray_min_dist, -1.0f, raylevel + 1, integ);
-				col = cadd(col, cmul(C(integ[0], integ[1], integ[2]), rcol[0]));
+				float integ[4], ref_tmax;
+				integrate(st, sp.p, sdir[0], st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+				rgb ic = C(integ[0], integ[1], integ[2]);
+				/* :991-994 vol = material->getVolumeHandler(sp.ng_ * ref_ray.dir_ < 0); integ *= vcol */
+				if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, sdir[0]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
+				col = cadd(col, cmul(ic, rcol[0]));
 			}
 			if(refract)
 			{
-				float integ[4];
-				integrate(st, sp.p, sdir[1], st->ray_min_dist, -1.0f, raylevel + 1, integ);
-				col = cadd(col, cmul(C(integ[0], integ[1], integ[2]), rcol[1]));
+				float integ[4], ref_tmax;
+				integrate(st, sp.p, sdir[1], st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+				rgb ic = C(integ[0], integ[1], integ[2]);
+				if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, sdir[1]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax)); /* :1016-1019 */
+				col = cadd(col, cmul(ic, rcol[1]));
 				alpha = integ[3];
 			}
 		}
@@ -2429,6 +2468,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 	/* EmptyVolumeIntegrator: transmittance 1, integration 0 (integrator_empty_volume.cc:32-38) */
 	if(rd->bg_transp) alpha = fmaxf_(alpha, 1.f - 1.f);
 	out_rgba[0] = col.r; out_rgba[1] = col.g; out_rgba[2] = col.b; out_rgba[3] = alpha;
+	if(ray_tmax_out) *ray_tmax_out = tmax;
 }
 
 /* ------------------------------------------------------------------ film
@@ -2627,7 +2667,7 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 				camera_shoot_lens(cam, j + dx, i + dy, lens_u, lens_v, &from, &dir, &tmin, &tmax, &wt);
 				wk->camera_samples++;
 				float c[4];
-				integrate(st, from, dir, tmin, tmax, 0, c);
+				integrate(st, from, dir, tmin, tmax, 0, c, NULL);
 				if(c[3] > 1.f) c[3] = 1.f;                 /* :459 */
 				c[0] *= wt; c[1] *= wt; c[2] *= wt; c[3] *= wt; /* :512 */
 				film_add_sample(wk->film, c, j, i, dx, dy, wk->n_threads > 1 ? &wk->deferred : NULL);
@@ -3021,6 +3061,13 @@ void yor_material_specular(const yor_material_desc *md, const float in14[14], in
 	out12[6] = d[1].x; out12[7] = d[1].y; out12[8] = d[1].z; out12[9] = c[1].r; out12[10] = c[1].g; out12[11] = c[1].b;
 	*alpha = mat_alpha(&m, &dat, &sp, wo);
 }
+void yor_beer_transmittance(const float acol[3], double dist, float tmax, int32_t *ok, float out3[3])
+{
+	const rgb t = beer_transmittance(beer_sigma(acol, dist), tmax);
+	*ok = 1;
+	out3[0] = t.r; out3[1] = t.g; out3[2] = t.b;
+}
+
 void yor_lightmat_emit(const yor_material_desc *md, const float n[3], const float wo[3], int include_lights, float out3[3])
 {
 	mat_t m; mat_configure(&m, md);

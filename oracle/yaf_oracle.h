@@ -7,7 +7,8 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   - fast-math, QMC, createCs/sampleCosHemisphere, Bound::cross, perspective camera (pinhole and
  *     depth of field), area/point lights, shinydiffuse/glossy/coated-glossy/glass/mirror/light
- *     materials (eval, pdf, sample, getSpecular, getAlpha, getTransparency) are pinned bit-for-bit against
+ *     materials (eval, pdf, sample, getSpecular, getAlpha, getTransparency), BeerVolumeHandler (glass absorption)
+ *     are pinned bit-for-bit against
  *     the reference's own sources compiled here (oracle/_ref, IEEE build) and to ~1e-4
  *     against the reference's -ffast-math release flags (tests/golden/ref_components_*.json).
  *   - kd traversal (intersect / intersectS / intersectTs), Triangle::intersect/getSurface,
@@ -68,6 +69,10 @@ typedef struct yor_material_desc
 	float light_power;
 	int32_t double_sided;
 	int32_t pad1;
+	/* glass "absorption" / "absorption_dist": a BeerVolumeHandler inside the material (material_glass.cc:371-398) */
+	float absorption[3];
+	int32_t has_absorption;
+	double absorption_dist;
 } yor_material_desc;
 
 typedef struct yor_light_desc
@@ -211,6 +216,8 @@ void yor_material_transparency(const yor_material_desc *m, const float in14[14],
 void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha);
 void yor_material_probe(const yor_material_desc *m, const float in14[14], int32_t sample_flags,
                         int32_t *bsdf_flags, float eval3[3], float *pdf, int32_t *sampled_flags, float sample8[8]);
+/* BeerVolumeHandler(acol, dist)::transmittance over a ray of length tmax (volumehandler_beer.cc:28-48) */
+void yor_beer_transmittance(const float acol[3], double dist, float tmax, int32_t *ok, float out3[3]);
 void yor_lightmat_emit(const yor_material_desc *m, const float n[3], const float wo[3], int include_lights, float out3[3]);
 
 #ifdef __cplusplus

@@ -448,6 +448,77 @@ def test_transparent_shadows_flag_with_opaque_materials(pipeline):
     assert np.array_equal(films[0], films[1])
 
 
+@pytest.mark.parametrize("raydepth,integrator", [(1, "pathtracing"), (3, "pathtracing"), (5, "pathtracing"), (4, "directlighting")])
+def test_recursive_raytrace_mirror_and_transparency(raydepth, integrator, pipeline):
+    """recursiveRaytrace's perfect specular branch (integrator_montecarlo.cc:971-1025) for shinydiffusemat's mirror
+    (with and without Fresnel) and transparency (filtered, straight through): a full integrate() per followed ray, one
+    level deeper, alpha from the transmitted ray.  Frames per level behind the parked records; the iteration loop
+    runs until the queues are empty."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(260, seed=13, res=(48, 40))
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"][0].update({"specular_reflect": 0.5, "mirror_color": (0.9, 0.9, 1.0)})
+    sc["materials"][1].update({"transparency": 0.5, "transmit_filter": 0.6, "specular_reflect": 0.3, "fresnel_effect": True, "IOR": 1.4})
+    sc["materials"][2].update({"transparency": 0.7, "transmit_filter": 0.2})
+    rd = scenes.render_settings(48, 40, 4, bounces=2, integrator=integrator, raydepth=raydepth, background=(0.2, 0.3, 0.4),
+                                bg_transp=True, bg_transp_refract=True)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"recursive raytrace depth {raydepth} {integrator}")
+    flat, _ = po.OracleScene(sc).render(dict(rd, raydepth=0))
+    assert not np.allclose(po.film_to_rgb(flat), po.film_to_rgb(ofilm), rtol=1e-3), "the recursion changes the image"
+
+
+@pytest.mark.parametrize("raydepth", [2, 6])
+def test_glass_and_mirror_materials(raydepth, pipeline):
+    """GlassMaterial (refraction, Fresnel reflection, total inner reflection, the level-3 cut of reflections inside the
+    glass, with and without fake shadows) and MirrorMaterial through recursiveRaytrace and as path bounces."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(300, seed=29, res=(52, 44), sigma=0.06)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.7, 0.95, 0.8), "transmit_filter": 0.9, "mirror_color": (1.0, 0.95, 0.9)})
+    sc["materials"].append({"type": "mirror", "color": (0.9, 0.85, 0.7), "reflect": 0.9})
+    sc["materials"].append({"type": "glass", "IOR": 1.9, "filter_color": (1.0, 0.6, 0.6), "transmit_filter": 0.5, "fake_shadows": True})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    free = np.arange(10, len(tm))                     # the soup triangles (the first ten are the walls)
+    tm[free[0::3]] = nm - 3; tm[free[1::5]] = nm - 2; tm[free[2::7]] = nm - 1
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(52, 44, 4, bounces=3, raydepth=raydepth, background=(0.3, 0.3, 0.5), bg_transp=True, bg_transp_refract=True)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"glass + mirror, raydepth {raydepth}")
+
+
+@pytest.mark.parametrize("raydepth,bounces", [(4, 3), (7, 4)])
+def test_glass_absorption(raydepth, bounces, pipeline):
+    """Glass with "absorption": the material owns a BeerVolumeHandler (material_glass.cc:371-398); light that travelled
+    inside it is attenuated by exp(-sigma * distance) — for followed specular rays in recursiveRaytrace
+    (integrator_montecarlo.cc:991-994, 1016-1019; a ray that leaves the scene from inside comes back black) and for
+    path segments that end on the inner side of the surface (integrator_path_tracer.cc:276-279)."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(240, seed=37, res=(52, 44), sigma=0.12)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "glass", "IOR": 1.45, "filter_color": (0.95, 0.95, 1.0), "transmit_filter": 0.6,
+                            "absorption": (0.3, 0.8, 0.95), "absorption_dist": 0.35})
+    sc["materials"].append({"type": "glass", "IOR": 1.7, "absorption": (0.9, 0.2, 0.0)})          # default distance 1; a zero channel
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    free = np.arange(10, len(tm))
+    tm[free[0::2]] = nm - 2; tm[free[1::4]] = nm - 1
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(52, 44, 4, bounces=bounces, raydepth=raydepth, background=(0.3, 0.3, 0.5))
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"glass absorption, raydepth {raydepth}")
+    clear = dict(sc); clear["materials"] = [{k: v for k, v in m.items() if not k.startswith("absorption")} for m in sc["materials"]]
+    cfilm, _ = po.OracleScene(clear).render(rd)
+    assert po.film_to_rgb(cfilm)[..., :3].sum() > po.film_to_rgb(ofilm)[..., :3].sum() * 1.02, "absorption darkens the image"
+
+
 @pytest.mark.parametrize("shadow_depth", [1, 5])
 def test_transparent_shadows(shadow_depth, pipeline):
     """Shadow rays through transparent shinydiffuse and fake-shadow glass are filtered, not blocked

@@ -179,6 +179,23 @@ def test_camera(gold):
     check(variant, got, g["cam_ray9"], "PerspectiveCamera::shootRay")
 
 
+def test_beer_volume_handler(gold):
+    """BeerVolumeHandler(absorption colour, distance)::transmittance — the absorption of a glass material."""
+    variant, g = gold
+    L = po.lib()
+    inp = f32(g["beer_in5"]).reshape(-1, 5).copy()
+    ref = g["beer_out4"].reshape(-1, 4)
+    got = []
+    out = np.zeros(3, np.float32)
+    ok = C.c_int32(0)
+    for row in inp:
+        L.yor_beer_transmittance(po.fptr(row[0:3].copy()), float(row[3]), float(row[4]), C.byref(ok), po.fptr(out))
+        assert ok.value == 1
+        got.extend(out.tolist())
+    assert np.all(ref[:, 0] == 1)
+    check(variant, got, np.ascontiguousarray(ref[:, 1:4]).reshape(-1), "BeerVolumeHandler::transmittance")
+
+
 def test_lights(gold):
     variant, g = gold
     L = po.lib()

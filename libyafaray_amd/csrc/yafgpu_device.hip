@@ -1668,7 +1668,8 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(!mega) return render_wavefront(s, ra, stream, stats);
 		if(ra.wide_filter) return fail(-15, "the one-kernel pipeline implements the box filter of width <= 1.002 only; use the wavefront pipeline");
 		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
-		if(rp->transp_shad && s->has_transparent) return fail(-15, "the one-kernel pipeline has no transparent shadows; use the wavefront pipeline");
+		// transpShad changes which hits occlude even without a transparent material (intersectTs skips hits before tmin_)
+		if(rp->transp_shad) return fail(-15, "the one-kernel pipeline has no transparent shadows (transpShad); use the wavefront pipeline");
 		if(s->has_specular && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent materials");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)
 			return fail(-15, "the one-kernel pipeline renders single-pass films only; use the wavefront pipeline");

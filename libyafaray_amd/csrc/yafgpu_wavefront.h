@@ -868,7 +868,9 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					{
 						from = from + dir * r0.w;
 						dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
-						ray_tmin = 0.f;
+						// intersectS accepts hits from 0 on, intersectTs (transpShad) from the ray's tmin_ on — measured from
+						// the origin already moved by tmin_ (kdtree_triangle.cc:936 / :1099, scene.cc isShadowed)
+						ray_tmin = a.ra.rp.transp_shad ? r0.w : 0.f;
 						++cn.shadow;
 					}
 					else
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				const bool ok = tri_test_flat(r0, r1, r2, from, dir, t, u, v);
 				const uint32_t vis = __float_as_uint(r1.w) >> 30;
 				bool found = false;
-				if(kAny) found = ok && t < dist && t >= 0.f && (vis == 0u || vis == 2u);
+				if(kAny) found = ok && t < dist && t >= ray_tmin && (vis == 0u || vis == 2u);
 				else
 				{
 					const bool better = ok && t < z && t >= ray_tmin && (vis == 0u || vis == 1u);

@@ -901,13 +901,21 @@ static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, 
 }
 
 /* Scene::intersect, scene.cc:896-927 */
+static FILE *g_ray_log = NULL;
 static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float *tmax, sp_t *sp, counters_t *cn)
 {
 	float dis, z, bu = 0, bv = 0; int ti = -1;
 	if(*tmax < 0) dis = INFINITY;
 	else dis = *tmax;
 	if(cn) cn->rays_closest++;
-	if(!kd_intersect(s, from, dir, tmin, dis, &ti, &z, &bu, &bv, cn)) return 0;
+	const int got = kd_intersect(s, from, dir, tmin, dis, &ti, &z, &bu, &bv, cn);
+	if(g_ray_log)      /* debugging aid (YOR_LOG_RAYS=<file>, single-threaded renders): every closest-hit query and its answer */
+	{
+		float rec[10] = {from.x, from.y, from.z, dir.x, dir.y, dir.z, tmin, *tmax, got ? z : -1.f, 0.f};
+		int32_t tri = got ? ti : -1; memcpy(&rec[9], &tri, 4);
+		fwrite(rec, sizeof rec, 1, g_ray_log);
+	}
+	if(!got) return 0;
 	v3 h = vadd(from, vmul(dir, z)); /* ray.from_ + z * ray.dir_ */
 	get_surface(s, ti, h, bu, bv, sp);
 	*tmax = z;
@@ -2863,6 +2871,7 @@ static void run_pass(yor_scene *s, const yor_render_desc *rd, film_t *film, work
 
 int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_stats *stats)
 {
+	{ const char *lp = getenv("YOR_LOG_RAYS"); if(g_ray_log) { fclose(g_ray_log); g_ray_log = NULL; } if(lp && *lp) g_ray_log = fopen(lp, "wb"); }
 	if(rd->aa_passes < 1) return -1;
 	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
 	for(int i = 0; i < s->n_mats; ++i)

@@ -160,10 +160,15 @@ def material_desc(m):
     material_glossy.cc:427-439, material_simple.cc:69-71) plus 'type'."""
     d = MaterialDesc()
     t = m["type"]
+    # "visibility" / "receive_shadows" are read by the shinydiffuse, glossy, coated_glossy and glass factories only
+    # (material_shiny_diffuse.cc:627-646, material_glossy.cc:427-439, material_coated_glossy.cc, material_glass.cc:340-360);
+    # MirrorMaterial::factory and LightMaterial::factory (material_glass.cc:486-493, material_simple.cc:63-73) leave the
+    # Material defaults (normal, receiving); "flat_material" belongs to shinydiffuse alone
+    reads_flags = t in ("shinydiffusemat", "glossy", "coated_glossy", "glass")
     vis = {"normal": 0, "no_shadows": 1, "shadow_only": 2, "invisible": 3}[m.get("visibility", "normal")]
-    d.visibility = vis
-    d.receive_shadows = int(m.get("receive_shadows", True))
-    d.flat_material = int(m.get("flat_material", False))
+    d.visibility = vis if reads_flags else 0
+    d.receive_shadows = int(m.get("receive_shadows", True)) if reads_flags else 1
+    d.flat_material = int(m.get("flat_material", False)) if t == "shinydiffusemat" else 0
     if t == "shinydiffusemat":
         d.type = MAT_SHINYDIFFUSE
         d.color = f3(*m.get("color", (1, 1, 1))[:3])

@@ -1430,7 +1430,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	}
 	HIP_OK(hipMemcpy(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	uint32_t max_paths = kWfMaxPaths;
-	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(65536u, (uint32_t)std::strtoul(e, nullptr, 10));
+	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
 	const uint32_t cap = chunk_pixels * spp;
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to

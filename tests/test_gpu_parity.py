@@ -714,12 +714,16 @@ def _feature_mix(seed):
                   AA_dark_threshold_factor=float(rng.uniform(0.0, 1.0)), AA_variance_edge_size=int(rng.integers(4, 12)),
                   AA_variance_pixels=int(rng.integers(0, 3)), AA_resampled_floor=float(rng.uniform(0.0, 20.0)),
                   AA_light_sample_multiplier_factor=float(rng.uniform(1.0, 2.0)), AA_sample_multiplier_factor=float(rng.uniform(1.0, 1.6)))
+    if rng.random() < 0.25:      # a crop window of the camera's frame
+        cw, ch = int(rng.integers(8, w - 4)), int(rng.integers(8, h - 4))
+        kw.update(xstart=int(rng.integers(0, w - cw)), ystart=int(rng.integers(0, h - ch)))
+        w, h = cw, ch
     rd = scenes.render_settings(w, h, spp, **kw)
     return sc, rd, w, h, base, kw
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_FUZZ_SEEDS", "16")))))
-def test_random_feature_mixes(seed, pipeline):
+def test_random_feature_mixes(seed, pipeline, monkeypatch):
     """Features are pinned one at a time above; here random combinations of them — materials of every supported type
     on one scene, area + point lights, vertex normals, depth of field, recursion depth, transparent shadows, path
     samples, background alpha modes, adaptive passes — must still equal the oracle: steps share parked records,
@@ -727,6 +731,8 @@ def test_random_feature_mixes(seed, pipeline):
     if pipeline == "megakernel":
         pytest.skip("the one-kernel pipeline renders the single-pass pinhole diffuse subset only")
     sc, rd, w, h, base, kw = _feature_mix(seed)
+    if seed % 2:      # every other seed in several wavefront chunks: chunk borders must not show (pixel lists, frames, lens streams)
+        monkeypatch.setenv("YAFGPU_WF_CHUNK", str([700, 1500, 4000][seed % 3]))
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.render()

@@ -764,3 +764,29 @@ def test_random_feature_mixes(seed, pipeline, monkeypatch):
         assert rays == (ost.rays_closest, ost.rays_shadow)
     elif ok_own.all():
         assert rays == (own_st.rays_closest, own_st.rays_shadow)
+
+
+@pytest.mark.parametrize("seed", [3, 14, 25, 36, 47, 58, 69, 80])
+def test_random_feature_mixes_through_the_xml_loader(seed, pipeline, tmp_path):
+    """The same random scenes written as scene XML and read by the C++ loader (yafaray_xml.cpp): parameter parsing,
+    defaults and list order of the loader against the direct Interface calls of the test above."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline renders the single-pass pinhole diffuse subset only")
+    from tests import xml_writer
+    sc, rd, w, h, base, kw = _feature_mix(seed)
+    sc = dict(sc, vnormals=None)                     # the writer emits positions and faces only
+    path = str(tmp_path / f"mix{seed}.xml")
+    xml_writer.write(path, sc, rd)
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film, st = yi.getFilm(w, h), yi.getRenderStats()
+    direct = Interface()
+    scenes.load_scene(direct, sc, rd)
+    direct.render()
+    dfilm, dst = direct.getFilm(w, h), direct.getRenderStats()
+    assert (st.rays_closest, st.rays_shadow, st.camera_samples) == (dst.rays_closest, dst.rays_shadow, dst.camera_samples)
+    if rd.get("filter_type", "box") == "box" and rd.get("AA_pixelwidth", 1.0) <= 1.002:
+        assert np.array_equal(film, dfilm), "XML-loaded scene renders differently from the same scene set through the Interface"
+    else:                                            # wide filters accumulate through float atomics
+        np.testing.assert_allclose(film, dfilm, rtol=2e-5, atol=1e-6)

@@ -2,7 +2,7 @@
 C++ loader can be driven with every feature of the device path.  Test support only."""
 import numpy as np
 
-_COLORS = {"color", "mirror_color", "diffuse_color", "filter_color"}
+_COLORS = {"color", "mirror_color", "diffuse_color", "filter_color", "absorption"}
 _POINTS = {"from", "to", "up", "corner", "point1", "point2"}
 
 

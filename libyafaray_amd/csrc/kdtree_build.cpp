@@ -141,8 +141,12 @@ Split find_split_binned(const Params &p, const Box &box, const uint32_t *prims, 
 			nl += starts[k - 1];   // prims beginning before plane k
 			nr -= ends[k];         // prims ending at or before plane k no longer reach the right side
 			const float l1 = (float)k / scale;
+			const float pos = lo + l1;
+			// a plane that rounds onto a face of the node splits nothing off (same box, same prims, one level deeper —
+			// and the empty-side bonus would pick it again and again in a node squeezed onto coplanar prims)
+			if(!(pos > box.lo[axis] && pos < box.hi[axis])) continue;
 			const float c = sah_cost(p, d, axis, l1, nl, nr, inv_total_sa, e_bonus);
-			if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = lo + l1; }
+			if(c < best.cost) { best.cost = c; best.axis = axis; best.pos = pos; }
 		}
 	}
 	return best;
@@ -369,7 +373,7 @@ yafgpu_kdtree_t *yafgpu_kdtree_build_device(const float *verts, int32_t n_tris)
 	auto *k = new yafgpu_kdtree();
 	k->n_tris = n_tris;
 	std::string err;
-	if(yafgpu::build_kdtree_device(verts, n_tris, 48, k->t, &err)) { yafgpu_internal_set_error(err.c_str()); delete k; return nullptr; }
+	if(yafgpu::build_kdtree_device_retry(verts, n_tris, 48, k->t, &err)) { yafgpu_internal_set_error(err.c_str()); delete k; return nullptr; }
 	return k;
 }
 void yafgpu_kdtree_info(const yafgpu_kdtree_t *k, yafgpu_tree_info *info)

@@ -31,6 +31,9 @@ void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, Kd
 
 // The same tree built on the GPU (kdtree_build_device.hip): breadth-first binned / exact-candidate SAH with the same
 // parameters and cost model.  Returns 0, or a negative code with *err set (never falls back to the host builder).
-int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err);
+// returns 0, -1 (device error) or -2 (the arrays sized for `room` x 8 references per triangle overflowed)
+int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err, int room = 1);
+// the same with more room on -2 (1, 4, 16), for callers that want a device-built tree or an error
+int build_kdtree_device_retry(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err);
 
 } // namespace yafgpu

@@ -213,9 +213,11 @@ __global__ __launch_bounds__(kBuildBlock) void build_level(const BuildArgs a)
 					uint32_t nl = 0u, nr = np;
 					for(int j = 1; j <= k; ++j) { nl += s_starts[axis][j - 1]; nr -= s_ends[axis][j]; }
 					const float l1 = (float)k / ((float)kBins / d[axis]);
+					const float pos = w.lo[axis] + l1;
+					if(!(pos > w.lo[axis] && pos < w.hi[axis])) continue;      // rounded onto a face of the node: splits nothing off
 					const float c = sah_cost(d, axis, l1, nl, nr, inv_total_sa, e_bonus, a.cost_ratio);
 					const uint32_t key = ((uint32_t)axis << 28) | (uint32_t)k;
-					if(c < my_cost || (c == my_cost && key < my_key)) { my_cost = c; my_pos = w.lo[axis] + l1; my_key = key; }
+					if(c < my_cost || (c == my_cost && key < my_key)) { my_cost = c; my_pos = pos; my_key = key; }
 				}
 			}
 			else
@@ -470,7 +472,7 @@ struct DevBuf
 } // namespace
 
 // returns 0 on success; a negative code and *err on failure (no fallback: the caller decides)
-int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err)
+int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err, int room)
 {
 	// the library's code object is loaded by its first launch (~0.1 s once per process): not build time
 	hipLaunchKernelGGL(init_refs, dim3(1), dim3(64), 0, nullptr, (const float *)nullptr, 0, (Ref *)nullptr);
@@ -495,8 +497,11 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 	if(log_leaves > 16.0) cost_ratio += (float)(0.25 * (log_leaves - 16.0));
 
 	const size_t n = (size_t)n_tris;
-	const uint32_t cap_refs = (uint32_t)std::min<size_t>(8 * n + 16384, 0x7fffffffu), cap_work = (uint32_t)(4 * n + 1024), cap_nodes = (uint32_t)(8 * n + 1024),
-	               cap_leaf = (uint32_t)std::min<size_t>(8 * n + 4096, 0x7fffffffu);
+	// room: references / nodes the arrays hold per triangle (x8).  Overlapping geometry (long needles, stacked sheets)
+	// multiplies references; the caller retries with more room when a build reports -2
+	const size_t r8 = (size_t)std::max(room, 1) * 8;
+	const uint32_t cap_refs = (uint32_t)std::min<size_t>(r8 * n + 16384, 0x7fffffffu), cap_work = (uint32_t)std::min<size_t>(r8 / 2 * n + 1024, 0x7fffffffu),
+	               cap_nodes = (uint32_t)std::min<size_t>(r8 * n + 1024, 0x7fffffffu), cap_leaf = (uint32_t)std::min<size_t>(r8 * n + 4096, 0x7fffffffu);
 	DevBuf d_verts, d_refs[2], d_work[2], d_nodes, d_leaf, d_cnt;
 	if(!d_verts.alloc(n * 9 * sizeof(float)) || !d_refs[0].alloc((size_t)cap_refs * sizeof(Ref)) || !d_refs[1].alloc((size_t)cap_refs * sizeof(Ref)) ||
 	   !d_work[0].alloc((size_t)cap_work * sizeof(Work)) || !d_work[1].alloc((size_t)cap_work * sizeof(Work)) ||
@@ -540,7 +545,7 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 		else hipLaunchKernelGGL(build_level<64>, grid, dim3(64), 0, nullptr, a);
 		if(hipGetLastError() != hipSuccess) return fail("device kd build: launch failed");
 		if(hipMemcpy(counters, d_cnt.p, sizeof counters, hipMemcpyDeviceToHost) != hipSuccess) return fail("device kd build: kernel failed");
-		if(counters[4]) return fail("device kd build: reference / node arrays overflowed");
+		if(counters[4]) { if(err) *err = "device kd build: reference / node arrays overflowed"; return -2; }
 		if(verbose) std::fprintf(stderr, "[kd device] level %d: %u nodes, %u refs out, %.4f s\n", level, n_work, counters[0], since(t_levels));
 		n_work = counters[1]; refs_in_level = counters[0];
 		node_count += n_work;
@@ -601,6 +606,13 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 	for(int k = 0; k < 3; ++k) { out.bound_lo[k] = lo[k]; out.bound_hi[k] = hi[k]; }
 	out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return 0;
+}
+
+int build_kdtree_device_retry(const float *verts, int n_tris, int depth_cap, KdTree &out, std::string *err)
+{
+	int rc = -2;
+	for(int room = 1; room <= 16 && rc == -2; room *= 4) rc = build_kdtree_device(verts, n_tris, depth_cap, out, err, room);
+	return rc;
 }
 
 } // namespace yafgpu

@@ -210,6 +210,16 @@ struct LaneStack
 	}
 };
 
+// Where a kd-restart resumes.  Normally at the exit of the cell just left.  If that cell had zero length (tmax == tmin)
+// the walk may not have advanced at all since the previous restart: a tree with more split planes crossed at one
+// distance than the short stack has slots (a degenerate chain of identical planes) would then restart at the same
+// distance for ever.  Stepping to the next representable distance guarantees progress; what it can skip is a hit at
+// exactly that distance in a zero-length cell of such a tree.
+YG_DEV float restart_from(float tmin, float tmax)
+{
+	return (tmax > tmin) ? tmax : tmax + fmaxf(fabsf(tmax) * 1.2e-7f, 1e-30f);
+}
+
 // Closest hit (kAny == false): TriKdTree::intersect, kdtree_triangle.cc:684-837 — the nearest
 //   triangle with ray_tmin <= t < dist whose material is visible to camera rays (:786).
 // Any hit (kAny == true): TriKdTree::intersectS, :840-977 — any triangle with 0 <= t < dist whose
@@ -277,7 +287,7 @@ YG_DEV bool kd_trace(const DevScene &sc, LaneStack &stk, V3 from, V3 dir, float 
 		{
 			if(!stk.lost() || tmax >= t_exit) break;
 			// kd-restart: pending far-children were lost to the short stack; resume at the cell exit
-			tmin = tmax; tmax = t_exit; node = 0u; stk.reset();
+			tmin = restart_from(tmin, tmax); tmax = t_exit; node = 0u; stk.reset();
 			if(kStats) ++cn.restarts;
 			continue;
 		}
@@ -365,7 +375,7 @@ YG_DEV bool kd_trace_ts(const DevScene &sc, LaneStack &stk, uint32_t *seen /* [k
 		if(stk.empty())
 		{
 			if(!stk.lost() || tmax >= t_exit) break;
-			tmin = tmax; tmax = t_exit; node = 0u; stk.reset();
+			tmin = restart_from(tmin, tmax); tmax = t_exit; node = 0u; stk.reset();
 			continue;
 		}
 		tmin = tmax;
@@ -1126,7 +1136,11 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if(on_device)
 		{
 			std::string err;
-			if(build_kdtree_device(d->verts, d->n_tris, kDepthCap, s->tree, &err)) { delete s; return fail(-20, err); }
+			// heavily overlapping geometry can outgrow the builder's arrays: more room, and past that the host builder
+			// (same format, same cost model) rather than no tree
+			const int brc = build_kdtree_device_retry(d->verts, d->n_tris, kDepthCap, s->tree, &err);
+			if(brc == -2) build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
+			else if(brc) { delete s; return fail(-20, err); }
 		}
 		else build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
 	}

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			const bool emp = stk.empty();
 			const bool restart = emp && stk.lost() && !(tmax >= t_exit);
 			if(kStats && restart && !hit_here) ++cn.restarts;
-			tmin = tmax;
+			tmin = restart ? restart_from(tmin, tmax) : tmax;                          // see restart_from: progress on degenerate trees
 			node = emp ? 0u : top.x;
 			tmax = emp ? t_exit : __uint_as_float(top.y);
 			stk.sp = emp ? 0 : stk.sp - 1;

@@ -100,3 +100,79 @@ def test_render_through_device_tree(pipeline, monkeypatch):
     same = float((film == host_film).all(axis=-1).mean())
     print(f"device-tree film vs host-tree film: {same:.5f} of pixels bit-identical")
     assert same > 0.995 and st.camera_samples == host_st.camera_samples
+
+
+def _odd_geometry(kind, rng, n):
+    """Triangle sets that stress a builder: needles, a dense cluster inside a sparse shell, huge + tiny mixes,
+    coplanar sheets, exact duplicates, axis-aligned grids whose edges coincide with candidate planes."""
+    if kind == "needles":
+        c = rng.uniform(-1, 1, (n, 1, 3)); d = rng.normal(size=(n, 1, 3)); d /= np.linalg.norm(d, axis=2, keepdims=True)
+        return (c + np.concatenate([np.zeros((n, 1, 3)), d * rng.uniform(0.2, 1.5, (n, 1, 1)), d * 0.5 + rng.normal(size=(n, 1, 3)) * 1e-4], axis=1)).astype(np.float32)
+    if kind == "cluster":
+        big = rng.uniform(-10, 10, (n // 4, 1, 3)) + rng.normal(size=(n // 4, 3, 3)) * 1.5
+        small = rng.normal(size=(n - n // 4, 1, 3)) * 0.01 + rng.normal(size=(n - n // 4, 3, 3)) * 0.002 + 3.0
+        return np.concatenate([big, small]).astype(np.float32)
+    if kind == "scales":
+        s = 10.0 ** rng.uniform(-4, 1, (n, 1, 1))
+        return (rng.uniform(-1, 1, (n, 1, 3)) + rng.normal(size=(n, 3, 3)) * s).astype(np.float32)
+    if kind == "sheets":
+        v = rng.uniform(-1, 1, (n, 3, 3)); v[:, :, 2] = rng.choice([-0.5, 0.0, 0.25], size=(n, 1))
+        return v.astype(np.float32)
+    if kind == "duplicates":
+        base = rng.uniform(-1, 1, (n // 8, 3, 3))
+        return np.repeat(base, 8, axis=0).astype(np.float32)
+    g = int(np.sqrt(n / 2))                                     # "grid": a tessellated axis-aligned plane, twice
+    xs = np.linspace(-1, 1, g + 1)
+    tris = []
+    for z in (0.0, 0.5):
+        for i in range(g):
+            for j in range(g):
+                a, b, c, d = (xs[i], xs[j], z), (xs[i + 1], xs[j], z), (xs[i + 1], xs[j + 1], z), (xs[i], xs[j + 1], z)
+                tris += [(a, b, c), (a, c, d)]
+    return np.array(tris, np.float32)
+
+
+@pytest.mark.parametrize("kind", ["needles", "cluster", "scales", "sheets", "duplicates", "grid"])
+@pytest.mark.parametrize("builder", ["device", "host"])
+@pytest.mark.timeout(120)
+def test_builders_on_odd_geometry(kind, builder, monkeypatch):
+    """Both builders on geometry that stresses plane search, clipping and termination; the device traversal over the
+    scene's own tree must answer every ray like brute force (hit triangle, distance, barycentrics, shadow verdict).
+    (Coplanar sheets once made the binned search pick a plane on the node's own face over and over — a chain of
+    identical planes deeper than the traversal's short stack, on which kd-restart never advanced.)"""
+    monkeypatch.setenv("YAFGPU_BUILD", builder)
+    rng = np.random.default_rng({"needles": 1, "cluster": 2, "scales": 3, "sheets": 4, "duplicates": 5, "grid": 6}[kind])
+    verts = _odd_geometry(kind, rng, 6000)
+    sc = scenes.cornell_soup(12, seed=3)
+    sc["verts"] = verts.reshape(-1, 9)
+    sc["tri_mat"] = np.zeros(len(verts), np.int32)
+    sc["vnormals"] = None
+    yi = Interface()
+    scenes.load_scene(yi, sc, scenes.render_settings(16, 16, 1))
+    yi.prepareRender()
+    st = yi.getRenderStats()
+    assert st.n_triangles == len(verts) and st.kd_nodes >= 1
+    lo, hi = verts.reshape(-1, 3).min(axis=0), verts.reshape(-1, 3).max(axis=0)
+    n = 4000
+    o = rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), size=(n, 3)).astype(np.float32)
+    tgt = verts[rng.integers(0, len(verts), n)].mean(axis=1) + rng.normal(size=(n, 3)) * 1e-3      # aim at triangles: most rays hit
+    d = tgt - o
+    d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+    d[::13] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=d[::13].shape[0])]
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32), np.full((n, 1), -1.0, np.float32)], axis=1)
+    tri, t, bary = yi.intersectRays(rays)
+    sh = yi.shadowRays(rays)
+    osc = po.OracleScene(sc)
+    bad = 0
+    for i in range(n):
+        h, oti, ot, ob = osc.intersect(rays[i, :3], rays[i, 3:6], 0.0, -1.0, use_tree=False)
+        same_t = bool(h) and tri[i] >= 0 and t[i] == ot
+        # coincident triangles (duplicates, shared edges): the same distance on another triangle is the same answer
+        if (tri[i] >= 0) != bool(h) or (h and not same_t):
+            bad += 1
+        elif h and tri[i] == oti and not np.array_equal(bary[i], ob):
+            bad += 1
+        if bool(osc.is_shadowed(rays[i, :3], rays[i, 3:6], 0.0, -1.0, use_tree=False)) != bool(sh[i]):
+            bad += 1
+    assert bad == 0, f"{kind} / {builder} builder: {bad} ray answers differ from brute force"
+    assert int((tri >= 0).sum()) > (40 if kind == "needles" else n // 4), "the rays were aimed at triangles"

@@ -611,6 +611,35 @@ def test_xml_scene_with_every_feature(pipeline, tmp_path):
     compare_films(film, ofilm, "xml scene with every feature", exact_weights=False)
 
 
+def assert_matches_an_oracle_render(sc, rd, film, st, what):
+    # Two oracle renders: the reference's traversal over the PRODUCT's tree (exact hit-distance ties — a camera ray into
+    # the shared edge of two wall triangles — resolve by the order leaves are visited in) and over the oracle's own
+    # reference-style tree (the reference's walk skips a leaf the ray enters exactly where it leaves the node above — a
+    # ray into the corner edge of two walls that are both split planes — which its own builder's layout does not expose
+    # but a foreign tree can).  The device must agree with one of them on every pixel and as a whole on the counts.
+    osc = po.OracleScene(sc)
+    own_film, own_st = osc.render(rd)
+    osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4, device=DEVICE_TREE)[:3])
+    ofilm, ost = osc.render(rd)
+    assert st.camera_samples in (ost.camera_samples, own_st.camera_samples), "resampled sets differ"
+    def close(f, o):
+        a, b = po.film_to_rgb(f), po.film_to_rgb(o)
+        rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(b[..., :3]), ABS_FLOOR)
+        return (rel.max(axis=-1) <= RTOL) & np.isclose(a[..., 3], b[..., 3], rtol=1e-5, atol=1e-6) & np.isclose(f[..., 4], o[..., 4], rtol=2e-6)
+    ok_prod, ok_own = close(film, ofilm), close(film, own_film)
+    print(f"{what}: pixels matching product-tree oracle {ok_prod.mean():.4f}, own-tree oracle {ok_own.mean():.4f}")
+    neither = int((~(ok_prod | ok_own)).sum())
+    # a wide filter spreads each of the two artefacts over its neighbours: a pixel that receives both matches neither
+    wide = rd.get("filter_type", "box") != "box" or rd.get("AA_pixelwidth", 1.0) > 1.002
+    assert neither == 0 or (wide and neither <= 4 and not ok_prod.all() and not ok_own.all()), f"{what}: {neither} pixels match neither oracle render"
+    assert ok_prod.mean() > 0.99 or ok_own.mean() > 0.99
+    rays = (st.rays_closest, st.rays_shadow)
+    if ok_prod.all():
+        assert rays == (ost.rays_closest, ost.rays_shadow)
+    elif ok_own.all():
+        assert rays == (own_st.rays_closest, own_st.rays_shadow)
+
+
 def _random_material(rng):
     kind = rng.choice(["sd", "sd_mirror", "sd_transp", "sd_transl", "glossy", "coated", "glass", "glass_abs", "mirror"])
     col = lambda lo=0.2, hi=1.0: tuple(float(x) for x in rng.uniform(lo, hi, 3))
@@ -737,33 +766,7 @@ def test_random_feature_mixes(seed, pipeline, monkeypatch):
     scenes.load_scene(yi, sc, rd)
     yi.render()
     film, st = yi.getFilm(w, h), yi.getRenderStats()
-    # Two oracle renders: the reference's traversal over the PRODUCT's tree (exact hit-distance ties — a camera ray into
-    # the shared edge of two wall triangles — resolve by the order leaves are visited in) and over the oracle's own
-    # reference-style tree (the reference's walk skips a leaf the ray enters exactly where it leaves the node above — a
-    # ray into the corner edge of two walls that are both split planes — which its own builder's layout does not expose
-    # but a foreign tree can).  The device must agree with one of them on every pixel and as a whole on the counts.
-    osc = po.OracleScene(sc)
-    own_film, own_st = osc.render(rd)
-    osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4, device=DEVICE_TREE)[:3])
-    ofilm, ost = osc.render(rd)
-    what = f"feature mix {seed}: {[m['type'] for m in sc['materials'][base:]]} {kw}"
-    assert st.camera_samples in (ost.camera_samples, own_st.camera_samples), "resampled sets differ"
-    def close(f, o):
-        a, b = po.film_to_rgb(f), po.film_to_rgb(o)
-        rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(b[..., :3]), ABS_FLOOR)
-        return (rel.max(axis=-1) <= RTOL) & np.isclose(a[..., 3], b[..., 3], rtol=1e-5, atol=1e-6) & np.isclose(f[..., 4], o[..., 4], rtol=2e-6)
-    ok_prod, ok_own = close(film, ofilm), close(film, own_film)
-    print(f"{what}: pixels matching product-tree oracle {ok_prod.mean():.4f}, own-tree oracle {ok_own.mean():.4f}")
-    neither = int((~(ok_prod | ok_own)).sum())
-    # a wide filter spreads each of the two artefacts over its neighbours: a pixel that receives both matches neither
-    wide = rd.get("filter_type", "box") != "box" or rd.get("AA_pixelwidth", 1.0) > 1.002
-    assert neither == 0 or (wide and neither <= 4 and not ok_prod.all() and not ok_own.all()), f"{what}: {neither} pixels match neither oracle render"
-    assert ok_prod.mean() > 0.99 or ok_own.mean() > 0.99
-    rays = (st.rays_closest, st.rays_shadow)
-    if ok_prod.all():
-        assert rays == (ost.rays_closest, ost.rays_shadow)
-    elif ok_own.all():
-        assert rays == (own_st.rays_closest, own_st.rays_shadow)
+    assert_matches_an_oracle_render(sc, rd, film, st, f"feature mix {seed}: {[m['type'] for m in sc['materials'][base:]]} {kw}")
 
 
 @pytest.mark.parametrize("seed", [3, 14, 25, 36, 47, 58, 69, 80])
@@ -790,3 +793,34 @@ def test_random_feature_mixes_through_the_xml_loader(seed, pipeline, tmp_path):
         assert np.array_equal(film, dfilm), "XML-loaded scene renders differently from the same scene set through the Interface"
     else:                                            # wide filters accumulate through float atomics
         np.testing.assert_allclose(film, dfilm, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("kind", ["needles", "cluster", "scales", "sheets", "duplicates", "grid"])
+def test_render_odd_geometry(kind, pipeline):
+    """A frame of geometry that stresses builder and traversal (tests/test_gpu_device_build.py), lit and path traced:
+    the wavefront traversal with its short stack and restarts, leaves of hundreds of coincident triangles, hit-distance
+    ties between duplicates."""
+    if pipeline == "megakernel":
+        pytest.skip("one pipeline is enough here")
+    from tests.test_gpu_device_build import _odd_geometry
+    rng = np.random.default_rng(11)
+    verts = _odd_geometry(kind, rng, 3000)
+    c = verts.reshape(-1, 3).mean(axis=0); ext = float(np.abs(verts.reshape(-1, 3) - c).max())
+    sc = scenes.cornell_soup(12, seed=3, res=(40, 32))
+    walls = np.asarray(sc["verts"], np.float32).reshape(-1, 3, 3)[:10] * np.float32(1.6 * ext) + c.astype(np.float32)
+    sc["verts"] = np.concatenate([walls, verts]).reshape(-1, 9).astype(np.float32)
+    sc["tri_mat"] = np.concatenate([np.asarray(sc["tri_mat"], np.int32)[:10], rng.integers(0, 3, len(verts)).astype(np.int32)])
+    sc["vnormals"] = None
+    cam = sc["camera"]
+    sc["camera"] = dict(cam, **{"from": tuple(float(x) for x in (c + np.array([0.0, -3.8 * 1.6 * ext, 0.0]))), "to": tuple(float(x) for x in c),
+                               "up": tuple(float(x) for x in (c + np.array([0.0, -3.8 * 1.6 * ext, 1.0])))})
+    sc["lights"] = [{"type": "pointlight", "from": tuple(float(x) for x in (c + np.array([0.1, -0.2, 0.9]) * 1.5 * ext)), "color": (1.0, 1.0, 1.0),
+                     "power": float(8.0 * ext * ext)}]
+    rd = scenes.render_settings(40, 32, 3, bounces=3, background=(0.1, 0.1, 0.2))
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(40, 32), yi.getRenderStats()
+    assert st.rays_closest > 40 * 32 * 3
+    assert_matches_an_oracle_render(sc, rd, film, st, f"odd geometry {kind}")

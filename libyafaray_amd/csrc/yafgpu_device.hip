@@ -1106,6 +1106,11 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 {
 	if(!d || !out) return fail(-1, "null argument");
 	if(d->n_tris < 0 || d->n_materials <= 0) return fail(-2, "scene needs at least one material");
+	{	// a NaN or infinite coordinate poisons the scene bound and with it every ray's clip against it: refuse it here
+		const size_t nf = (size_t)d->n_tris * 9;
+		for(size_t k = 0; k < nf; ++k)
+			if(!std::isfinite(d->verts[k])) return fail(-3, "non-finite vertex coordinate in triangle " + std::to_string(k / 9));
+	}
 	for(int i = 0; i < d->n_tris; ++i)
 		if(d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(-3, "triangle material index out of range");
 	for(int i = 0; i < d->n_materials; ++i)

@@ -121,6 +121,13 @@ def _odd_geometry(kind, rng, n):
     if kind == "duplicates":
         base = rng.uniform(-1, 1, (n // 8, 3, 3))
         return np.repeat(base, 8, axis=0).astype(np.float32)
+    if kind in ("outlier", "nonfinite"):
+        v = rng.uniform(-1, 1, (n, 1, 3)) + rng.normal(size=(n, 3, 3)) * 0.05
+        if kind == "outlier":
+            v[17] = 1e20                                         # squaring the bound's extent overflows float
+        else:
+            v[17, 1, 2] = np.nan; v[33, 0, 0] = np.inf
+        return v.astype(np.float32)
     g = int(np.sqrt(n / 2))                                     # "grid": a tessellated axis-aligned plane, twice
     xs = np.linspace(-1, 1, g + 1)
     tris = []
@@ -132,7 +139,7 @@ def _odd_geometry(kind, rng, n):
     return np.array(tris, np.float32)
 
 
-@pytest.mark.parametrize("kind", ["needles", "cluster", "scales", "sheets", "duplicates", "grid"])
+@pytest.mark.parametrize("kind", ["needles", "cluster", "scales", "sheets", "duplicates", "grid", "outlier", "nonfinite"])
 @pytest.mark.parametrize("builder", ["device", "host"])
 @pytest.mark.timeout(120)
 def test_builders_on_odd_geometry(kind, builder, monkeypatch):
@@ -141,7 +148,7 @@ def test_builders_on_odd_geometry(kind, builder, monkeypatch):
     (Coplanar sheets once made the binned search pick a plane on the node's own face over and over — a chain of
     identical planes deeper than the traversal's short stack, on which kd-restart never advanced.)"""
     monkeypatch.setenv("YAFGPU_BUILD", builder)
-    rng = np.random.default_rng({"needles": 1, "cluster": 2, "scales": 3, "sheets": 4, "duplicates": 5, "grid": 6}[kind])
+    rng = np.random.default_rng({"needles": 1, "cluster": 2, "scales": 3, "sheets": 4, "duplicates": 5, "grid": 6, "outlier": 7, "nonfinite": 8}[kind])
     verts = _odd_geometry(kind, rng, 6000)
     sc = scenes.cornell_soup(12, seed=3)
     sc["verts"] = verts.reshape(-1, 9)
@@ -149,13 +156,18 @@ def test_builders_on_odd_geometry(kind, builder, monkeypatch):
     sc["vnormals"] = None
     yi = Interface()
     scenes.load_scene(yi, sc, scenes.render_settings(16, 16, 1))
+    if kind == "nonfinite":      # a NaN / infinite coordinate would poison the scene bound: refused, loudly
+        with pytest.raises(Exception, match="non-finite vertex"):
+            yi.prepareRender()
+        return
     yi.prepareRender()
     st = yi.getRenderStats()
     assert st.n_triangles == len(verts) and st.kd_nodes >= 1
-    lo, hi = verts.reshape(-1, 3).min(axis=0), verts.reshape(-1, 3).max(axis=0)
-    n = 4000
+    fin = verts[np.isfinite(verts).all(axis=(1, 2)) & (np.abs(verts).max(axis=(1, 2)) < 1e6)]      # rays are aimed at the ordinary triangles
+    lo, hi = fin.reshape(-1, 3).min(axis=0), fin.reshape(-1, 3).max(axis=0)
+    n = 1500 if kind in ("outlier", "nonfinite") else 4000
     o = rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), size=(n, 3)).astype(np.float32)
-    tgt = verts[rng.integers(0, len(verts), n)].mean(axis=1) + rng.normal(size=(n, 3)) * 1e-3      # aim at triangles: most rays hit
+    tgt = fin[rng.integers(0, len(fin), n)].mean(axis=1) + rng.normal(size=(n, 3)) * 1e-3      # aim at triangles: most rays hit
     d = tgt - o
     d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)).astype(np.float32)
     d[::13] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=d[::13].shape[0])]

@@ -526,6 +526,7 @@ YG_DEV void integrate(const RenderArgs &ra, LaneStack &stk, V3 from, V3 dir, flo
 	uint32_t bsdfs0 = 0u;
 	Col path_col = mkc(0.f, 0.f, 0.f), throughput = mkc(1.f, 1.f, 1.f);
 	int path_i = 0, depth = 0;
+	float last_w = 0.f;          // integrate()'s `w`: Material::sample may leave it untouched (see st_extend)
 	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
 	uint32_t offs = 0u;
 	uint32_t sampled_flags = kNone;
@@ -648,9 +649,10 @@ YG_DEV void integrate(const RenderArgs &ra, LaneStack &stk, V3 from, V3 dir, flo
 			bs.s_1 = (float)scr_halton(sc, d_4 + 3, offs);
 			bs.s_2 = (float)scr_halton(sc, d_4 + 4, offs);
 			bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
-			float w = 0.f;
+			float w = last_w;
 			V3 p_dir = r_dir;
 			const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
+			last_w = w;
 			if(is_black(scol)) { ++path_i; start_path = true; }                               // :249 `break`
 			else
 			{
@@ -670,10 +672,11 @@ YG_DEV void integrate(const RenderArgs &ra, LaneStack &stk, V3 from, V3 dir, flo
 			bs.s_2 = (float)scr_halton(sc, 2, offs);
 			bs.pdf = 0.f; bs.sampled = kNone;
 			bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
-			float w = 0.f;
+			float w = last_w;
 			V3 p_dir = mk(0.f, 0.f, 0.f);
 			pwo = wo0;
 			const Col scol = mat_sample(m, dat0, sp0, pwo, p_dir, bs, w) * w;
+			last_w = w;
 			throughput = scol;
 			sampled_flags = bs.sampled;
 			r_from = sp0.p; r_dir = p_dir; r_tmin = ra.ray_min_dist; r_tmax = -1.f;

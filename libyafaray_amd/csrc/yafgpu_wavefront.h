@@ -295,7 +295,8 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	float4 misc = REC(19);
 	V3 pwo = -dir;                                                                              // :271
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
-	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, 0.f); REC(9) = f4(hit.ng, 0.f); REC(10) = f4(pwo, 0.f);
+	// .w of 8..10: p_ray.dir_ of the segment that ended here — what Material::sample leaves in `wi` when it samples nothing
+	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, dir.x); REC(9) = f4(hit.ng, dir.y); REC(10) = f4(pwo, dir.z);
 	HSET(18, z4);
 	if(YAFGPU_FEAT_RECURSE && (mb & kVolumetric) && c.stage == kStDepth && pm.has_vol_i && dot(hit.n, pwo) < 0.f)
 	{	// integrator_path_tracer.cc:276-279: the segment ran inside an absorbing material (lcol does not depend on it)
@@ -491,7 +492,8 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
 	const float4 p = REC(7);
 	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
-	const V3 pwo = v3(REC(10));
+	const float4 r10 = REC(10);
+	const V3 pwo = v3(r10);
 	const yafgpu_material &pm = sc.mats[hit.mat];
 	BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
 	const uint32_t offs = ubits(REC(19).x);
@@ -500,9 +502,13 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	bs.s_1 = (float)scr_halton(sc, d_4 + 3, offs);
 	bs.s_2 = (float)scr_halton(sc, d_4 + 4, offs);
 	bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
-	float w = 0.f;
-	V3 p_dir = mk(0.f, 0.f, 0.f);
+	// `w` and `p_ray.dir_` are variables of integrate() that sample() may leave untouched (a material with no lobe to
+	// sample returns Rgb(1) and nothing else, material_shiny_diffuse.cc sample()): the path then carries on straight
+	// through with the previous weight (integrator_path_tracer.cc:243-249).  They live in REC(6).w and in 8..10.w.
+	float w = REC(6).w;
+	V3 p_dir = mk(REC(8).w, REC(9).w, r10.w);
 	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
+	REC(6).w = w;
 	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
 	const float4 r11 = HGET(11);
 	HSET(11, f4(c3(r11) * scol, r11.w));
@@ -529,9 +535,11 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	bs.s_2 = (float)scr_halton(sc, 2, offs);
 	bs.pdf = 0.f; bs.sampled = kNone;
 	bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
-	float w = 0.f;
+	const float4 r6 = REC(6);
+	float w = r6.w;                                   // integrate()'s `w`: 0 at its start, then whatever the last sample() left
 	V3 p_dir = mk(0.f, 0.f, 0.f);
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
+	REC(6).w = w;
 	REC(10) = f4(wo0, 0.f);                          // pwo = wo
 	HSET(11, f4(scol, HGET(11).w));                   // throughput = scol
 	float4 misc = REC(19);

@@ -16,7 +16,8 @@ def frac(sc, rd, w, h):
     return float(ok.mean()), (st.rays_closest, ost.rays_closest, st.rays_shadow, ost.rays_shadow, st.camera_samples, ost.camera_samples)
 for seed in [int(x) for x in sys.argv[1:]]:
     sc, rd, w, h, base, kw = _feature_mix(seed)
-    print("seed", seed, "full:", frac(sc, rd, w, h), flush=True)
+    full = frac(sc, rd, w, h)
+    print("seed", seed, "full:", full, [m for m in sc["materials"][base:]], flush=True)
     defaults = scenes.render_settings(w, h, rd["AA_minsamples"])
     for k in list(kw):
         if k in ("bounces", "raydepth", "path_samples", "integrator", "background", "bg_transp", "bg_transp_refract", "shadowDepth", "no_recursive", "AA_inc_samples", "AA_threshold"): continue
@@ -28,6 +29,13 @@ for seed in [int(x) for x in sys.argv[1:]]:
             if k in m:
                 sc2 = dict(sc); sc2["materials"] = [dict(x) for x in sc["materials"]]; sc2["materials"][base + i].pop(k)
                 print("   without material", i, k, "=", m[k], ":", frac(sc2, rd, w, h), flush=True)
+    for i, m in enumerate(sc["materials"][base:]):
+        for k, v in m.items():
+            if k == "type" or isinstance(v, (bool, str)): continue
+            sc2 = dict(sc); sc2["materials"] = [dict(x) for x in sc["materials"]]
+            sc2["materials"][base + i][k] = (0.5, 0.6, 0.7) if isinstance(v, tuple) else (1.5 if k == "IOR" else (50.0 if k == "exponent" else 0.5))
+            fr = frac(sc2, rd, w, h)
+            if fr[0] > full[0] + 0.01: print("   material", i, m["type"], k, "=", v, "-> mid value:", fr, flush=True)
     for i, l in enumerate(sc["lights"]):
         for k in ("samples", "cast_shadows"):
             if k in l:

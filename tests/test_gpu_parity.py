@@ -758,6 +758,20 @@ def _feature_mix(seed):
                   AA_dark_threshold_factor=float(rng.uniform(0.0, 1.0)), AA_variance_edge_size=int(rng.integers(4, 12)),
                   AA_variance_pixels=int(rng.integers(0, 3)), AA_resampled_floor=float(rng.uniform(0.0, 20.0)),
                   AA_light_sample_multiplier_factor=float(rng.uniform(1.0, 2.0)), AA_sample_multiplier_factor=float(rng.uniform(1.0, 1.6)))
+    if seed % 3 == 2:            # third stage: camera placement and lens, light geometry and strength
+        eye = rng.uniform(-0.8, 0.8, 3) if rng.random() < 0.4 else np.array([rng.uniform(-1, 1), -rng.uniform(2.5, 6.0), rng.uniform(-0.8, 0.8)])
+        to = rng.uniform(-0.5, 0.5, 3)
+        sc["camera"] = dict(sc["camera"], **{"from": tuple(float(x) for x in eye), "to": tuple(float(x) for x in to),
+                                             "up": tuple(float(x) for x in (eye + np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1.0]))),
+                                             "focal": float(rng.uniform(0.4, 3.0))})
+        if rng.random() < 0.5:
+            sc["camera"]["aspect_ratio"] = float(rng.uniform(0.6, 1.8))
+        for l in sc["lights"]:
+            l["power"] = float(l.get("power", 1.0) * 10.0 ** rng.uniform(-1.5, 1.0))
+            l["color"] = tuple(float(x) for x in rng.uniform(0.0, 1.0, 3))
+            if l["type"] == "arealight" and rng.random() < 0.5:      # a tilted parallelogram instead of the ceiling panel
+                c = rng.uniform(-0.6, 0.6, 3); e1 = rng.normal(size=3) * 0.3; e2 = rng.normal(size=3) * 0.3
+                l["corner"] = tuple(float(x) for x in c); l["point1"] = tuple(float(x) for x in c + e1); l["point2"] = tuple(float(x) for x in c + e2)
     if rng.random() < 0.25:      # a crop window of the camera's frame
         cw, ch = int(rng.integers(8, w - 4)), int(rng.integers(8, h - 4))
         kw.update(xstart=int(rng.integers(0, w - cw)), ystart=int(rng.integers(0, h - ch)))

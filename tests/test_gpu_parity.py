@@ -780,7 +780,7 @@ def _feature_mix(seed):
     return sc, rd, w, h, base, kw
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_FUZZ_SEEDS", "16")))))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_FUZZ_FIRST", "0")), int(__import__("os").environ.get("YAFGPU_FUZZ_SEEDS", "16")))))
 def test_random_feature_mixes(seed, pipeline, monkeypatch):
     """Features are pinned one at a time above; here random combinations of them — materials of every supported type
     on one scene, area + point lights, vertex normals, depth of field, recursion depth, transparent shadows, path

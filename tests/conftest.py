@@ -26,6 +26,7 @@ def pytest_sessionstart(session):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "container: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout); a no-op where the plugin is absent")
 
 
 def pytest_collection_modifyitems(config, items):

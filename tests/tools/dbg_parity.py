@@ -1,5 +1,5 @@
 import numpy as np, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from libyafaray_amd import Interface, scenes
 from oracle import pyoracle as po
 for (n_tris,res,spp,bounces) in [(12,32,4,2),(500,48,16,3),(5000,64,16,3)]:

@@ -1,6 +1,6 @@
 """GPU-box helper: build the kd-tree on the device, check it against brute force through the oracle, compare with the host builder."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libyafaray_amd import scenes, interface
 from oracle import pyoracle as po

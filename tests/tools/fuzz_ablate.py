@@ -1,6 +1,6 @@
 """GPU-box helper: for fuzz seeds, drop one render option at a time and report how much of the frame matches the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libyafaray_amd import Interface, interface, scenes
 from oracle import pyoracle as po

@@ -1,6 +1,6 @@
 """GPU-box helper: for one pixel of a fuzz scene, log the oracle's closest-hit queries and replay them on the GPU's ray API and brute force."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libyafaray_amd import Interface, interface, scenes
 from oracle import pyoracle as po

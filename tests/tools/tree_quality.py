@@ -1,6 +1,6 @@
 """Host-only: walk the product's kd-tree with the oracle's (reference) traversal and report per-ray work."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libyafaray_amd import scenes, interface
 from oracle import pyoracle as po

@@ -1,0 +1,118 @@
+"""Random call sequences against the C API (CPU only, in a child process): whatever an exporter does in whatever order,
+the library answers with a return value and yafaray_getLastError, never with a crash."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent('''
+    import sys, random
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    from libyafaray_amd import Interface
+    seed0, n_seq = int(sys.argv[1]), int(sys.argv[2])
+    names = ["type", "color", "from", "to", "up", "resx", "resy", "focal", "power", "samples", "corner", "point1", "point2", "width", "height",
+             "AA_passes", "AA_minsamples", "camera_name", "integrator_name", "bounces", "path_samples", "IOR", "exponent", "transparency",
+             "filter_type", "AA_pixelwidth", "raydepth", "absorption", "visibility", "aperture", "bokeh_type", "tile_size", "xstart"]
+    strings = ["shinydiffusemat", "glossy", "glass", "mirror", "light_mat", "coated_glossy", "arealight", "pointlight", "perspective", "pathtracing",
+               "directlighting", "constant", "none", "box", "gauss", "nonsense", "", "cam", "default", "blend_mat", "photonmapping", "sunlight"]
+    for seq in range(n_seq):
+        rng = random.Random(seed0 + seq)
+        yi = Interface()
+        handles = [None]
+        for step in range(rng.randint(5, 120)):
+            op = rng.randrange(26)
+            try:
+                if op == 0: yi.startScene(rng.choice([0, 0, 1, -3]))
+                elif op == 1: yi.startGeometry()
+                elif op == 2: yi.endGeometry()
+                elif op == 3: yi.startTriMesh(rng.choice([yi.getNextFreeId(), 0, 7, -1]), rng.choice([0, 3, 30, -5]), rng.choice([0, 1, 10, -2]), rng.random() < 0.2, rng.random() < 0.2, rng.choice([0, 0, 5]))
+                elif op == 4: yi.endTriMesh()
+                elif op == 5: yi.addVertex(rng.uniform(-2, 2), rng.uniform(-2, 2), rng.choice([rng.uniform(-2, 2), float("nan"), float("inf"), 1e30]))
+                elif op == 6: yi.addNormal(rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1))
+                elif op == 7: yi.addTriangle(rng.randint(-2, 40), rng.randint(-2, 40), rng.randint(-2, 40), rng.choice(handles))
+                elif op == 8: yi.smoothMesh(rng.choice([0, 1, 7, -1]), rng.choice([0.0, 30.0, 181.0, -5.0]))
+                elif op == 9: yi.paramsSetString(rng.choice(names), rng.choice(strings))
+                elif op == 10: yi.paramsSetInt(rng.choice(names), rng.choice([0, 1, 2, 64, -1, 2**31 - 1, 100000]))
+                elif op == 11: yi.paramsSetFloat(rng.choice(names), rng.choice([0.0, 1.0, -1.0, 1e30, float("nan"), 0.5]))
+                elif op == 12: yi.paramsSetColor(rng.choice(names), rng.random(), rng.random(), rng.random())
+                elif op == 13: yi.paramsSetPoint(rng.choice(names), rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-3, 3))
+                elif op == 14: yi.paramsSetBool(rng.choice(names), rng.random() < 0.5)
+                elif op == 15: yi.paramsClearAll()
+                elif op == 16: handles.append(yi.createMaterial(rng.choice(["m0", "m1", ""])))
+                elif op == 17: yi.createLight(rng.choice(["l0", "l1", ""]))
+                elif op == 18: yi.createCamera(rng.choice(["cam", "c2", ""]))
+                elif op == 19: yi.createBackground("world_background")
+                elif op == 20: yi.createIntegrator(rng.choice(["default", "volintegr", "x"]))
+                elif op == 21: yi.paramsStartList(); yi.paramsPushList(); yi.paramsEndList()
+                elif op == 22: yi.clearAll()
+                elif op == 23: yi.setShard(rng.randint(-1, 3), rng.randint(-1, 3))
+                elif op == 24: yi.getRenderSize(); yi.getLastError(); yi.getVersion()
+                elif op == 25:
+                    v = np.random.default_rng(seq).uniform(-1, 1, (rng.choice([0, 1, 5]), 3, 3)).astype(np.float32)
+                    yi.addTriangles(v, None, rng.choice(handles)) if hasattr(yi, "addTriangles") else None
+            except Exception:
+                pass              # an error return surfaced as a Python exception: fine
+        try:
+            yi.close()
+        except Exception:
+            pass
+    # mutated valid scripts: a correct export with calls dropped, doubled and swapped
+    def script():
+        return [("startScene", 0),
+                ("paramsClearAll",), ("paramsSetString", "type", "shinydiffusemat"), ("paramsSetColor", "color", 0.8, 0.7, 0.6), ("createMaterial", "m0"),
+                ("paramsClearAll",), ("paramsSetString", "type", "glass"), ("paramsSetFloat", "IOR", 1.5), ("createMaterial", "m1"),
+                ("paramsClearAll",), ("paramsSetString", "type", "pointlight"), ("paramsSetPoint", "from", 0.0, 0.0, 0.9), ("paramsSetFloat", "power", 3.0), ("createLight", "l0"),
+                ("paramsClearAll",), ("paramsSetString", "type", "perspective"), ("paramsSetPoint", "from", 0.0, -3.0, 0.0), ("paramsSetPoint", "to", 0.0, 0.0, 0.0),
+                ("paramsSetPoint", "up", 0.0, -3.0, 1.0), ("paramsSetInt", "resx", 16), ("paramsSetInt", "resy", 12), ("createCamera", "cam"),
+                ("paramsClearAll",), ("paramsSetString", "type", "pathtracing"), ("paramsSetInt", "bounces", 2), ("createIntegrator", "default"),
+                ("paramsClearAll",), ("paramsSetString", "type", "none"), ("createIntegrator", "volintegr"),
+                ("startGeometry",), ("startTriMesh", 1, 4, 2, False, False, 0), ("addVertex", -1.0, 0.0, -1.0), ("addVertex", 1.0, 0.0, -1.0),
+                ("addVertex", 1.0, 0.0, 1.0), ("addVertex", -1.0, 0.0, 1.0), ("addTriangle", 0, 1, 2, "m0"), ("addTriangle", 0, 2, 3, "m1"), ("endTriMesh",),
+                ("smoothMesh", 1, 60.0), ("endGeometry",),
+                ("paramsClearAll",), ("paramsSetString", "camera_name", "cam"), ("paramsSetString", "integrator_name", "default"),
+                ("paramsSetString", "volintegrator_name", "volintegr"), ("paramsSetInt", "width", 16), ("paramsSetInt", "height", 12),
+                ("paramsSetInt", "AA_minsamples", 2), ("prepareRender",), ("getRenderSize",), ("render",)]
+    done = 0
+    for seq in range(n_seq):
+        rng = random.Random(77 + seed0 + seq)
+        calls = script()
+        for _ in range(rng.randint(0, 6)):
+            k = rng.randrange(3)
+            i = rng.randrange(len(calls))
+            if k == 0: del calls[i]
+            elif k == 1: calls.insert(rng.randrange(len(calls)), calls[i])
+            else:
+                j = rng.randrange(len(calls)); calls[i], calls[j] = calls[j], calls[i]
+        yi = Interface(); mats = {}
+        for c in calls:
+            try:
+                if c[0] == "createMaterial": mats[c[1]] = yi.createMaterial(c[1])
+                elif c[0] == "addTriangle": yi.addTriangle(c[1], c[2], c[3], mats.get(c[4]))
+                else: getattr(yi, c[0])(*c[1:])
+                done += 1
+            except Exception:
+                pass
+        try: yi.close()
+        except Exception: pass
+    print("survived", n_seq, "calls that succeeded", done)
+''')
+
+
+def test_random_call_sequences_never_crash():
+    for seed0 in (0, 10_000):
+        r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(seed0), "150"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count("survived 150") == 1 and "calls that succeeded" in r.stdout, f"child died (rc {r.returncode}):\\n{r.stderr[-2000:]}"
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_mutated_exports_render_or_fail_cleanly_on_the_gpu():
+    """The same sequences with a device behind them: prepareRender / render now run on whatever state the mutated
+    export left (no light, no geometry, a material defined twice, triangles before their material ...)."""
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, "3", "120"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "calls that succeeded" in r.stdout, f"child died (rc {r.returncode}):\n{r.stderr[-2000:]}"

@@ -116,3 +116,41 @@ def test_mutated_exports_render_or_fail_cleanly_on_the_gpu():
     export left (no light, no geometry, a material defined twice, triangles before their material ...)."""
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, "3", "120"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "calls that succeeded" in r.stdout, f"child died (rc {r.returncode}):\n{r.stderr[-2000:]}"
+
+
+XML_CHILD = textwrap.dedent('''
+    import sys, random, os, tempfile
+    sys.path.insert(0, %(root)r)
+    from libyafaray_amd import Interface
+    src = open(os.path.join(%(root)r, "tests", "golden", "test01_dl.xml"), "rb").read()
+    n = int(sys.argv[1])
+    tmp = tempfile.mkdtemp()
+    loaded = 0
+    for i in range(n):
+        rng = random.Random(i)
+        data = bytearray(src)
+        for _ in range(rng.randint(1, 8)):
+            k = rng.randrange(5)
+            p = rng.randrange(len(data))
+            if k == 0: del data[p:p + rng.randint(1, 400)]                       # a hole
+            elif k == 1: data[p] = rng.randrange(256)                            # a flipped byte
+            elif k == 2: data = data[:p]                                         # truncated
+            elif k == 3: data[p:p] = data[max(0, p - rng.randint(1, 300)):p]     # a repeated stretch
+            else: data[p:p] = rng.choice([b"<", b">", b'"', b"&", b"\\x00", b"<mesh", b"</scene>", b"1e999", b"-nan"])
+            if not data: data = bytearray(b"<")
+        path = os.path.join(tmp, "m.xml")
+        open(path, "wb").write(bytes(data))
+        yi = Interface()
+        try:
+            yi.loadXml(path); loaded += 1
+        except Exception:
+            pass
+        try: yi.close()
+        except Exception: pass
+    print("survived", n, "loaded", loaded)
+''')
+
+
+def test_damaged_scene_files_never_crash_the_xml_loader():
+    r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "400"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "survived 400" in r.stdout, f"child died (rc {r.returncode}):\n{r.stdout[-500:]}\n{r.stderr[-2000:]}"

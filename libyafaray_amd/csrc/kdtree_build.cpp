@@ -384,8 +384,8 @@ void yafgpu_kdtree_info(const yafgpu_kdtree_t *k, yafgpu_tree_info *info)
 }
 void yafgpu_kdtree_get(const yafgpu_kdtree_t *k, uint32_t *nodes, uint32_t *refs, float bound6[6])
 {
-	if(nodes) std::memcpy(nodes, k->t.nodes.data(), k->t.nodes.size() * sizeof(yafgpu::KdNode));
-	if(refs) std::memcpy(refs, k->t.refs.data(), k->t.refs.size() * sizeof(uint32_t));
+	if(nodes && !k->t.nodes.empty()) std::memcpy(nodes, k->t.nodes.data(), k->t.nodes.size() * sizeof(yafgpu::KdNode));
+	if(refs && !k->t.refs.empty()) std::memcpy(refs, k->t.refs.data(), k->t.refs.size() * sizeof(uint32_t));
 	if(bound6) for(int i = 0; i < 3; ++i) { bound6[i] = k->t.bound_lo[i]; bound6[3 + i] = k->t.bound_hi[i]; }
 }
 void yafgpu_kdtree_destroy(yafgpu_kdtree_t *k) { delete k; }

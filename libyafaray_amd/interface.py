@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libyafaray_gpu.so")
+    # YAFARAY_LIBRARY: test support (tests/asan builds the host side with a device stub under AddressSanitizer)
+    return os.environ.get("YAFARAY_LIBRARY") or os.path.join(_HERE, "libyafaray_gpu.so")
 
 
 class YafaRayError(RuntimeError):

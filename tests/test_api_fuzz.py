@@ -154,3 +154,19 @@ XML_CHILD = textwrap.dedent('''
 def test_damaged_scene_files_never_crash_the_xml_loader():
     r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "400"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "survived 400" in r.stdout, f"child died (rc {r.returncode}):\n{r.stdout[-500:]}\n{r.stderr[-2000:]}"
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """The host side of the C ABI (parameter maps, Interface state machine, geometry assembly, smoothMesh, XML loader,
+    host kd builder) built with a stub for the device unit under AddressSanitizer + UBSan (tests/asan), driven by the
+    same random call sequences and damaged scene files.  GPU code cannot run under sanitizers on this pool."""
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan) or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("no libasan / HIP host headers here")
+    subprocess.run(["bash", os.path.join(ROOT, "tests", "asan", "build.sh")], check=True, timeout=900, capture_output=True)
+    env = dict(os.environ, YAFARAY_LIBRARY=os.path.join(ROOT, "tests", "asan", "libyafaray_host_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, "500", "120"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "calls that succeeded" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "600"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "survived 600" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]

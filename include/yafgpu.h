@@ -206,6 +206,9 @@ int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int
  * stream; the pass then synchronises after each launch, so it is a measurement mode, not a fast path).
  * slots: 0 closest-hit traversal, 1 any-hit traversal, 2 shading, 3 other (ray generation, film). */
 int yafgpu_set_profiling(yafgpu_scene_t *scene, int32_t enable);
+/* Scene::abort (scene.cc:75-89): the render entry points poll *flag between wavefront chunks and between passes and
+ * return -30 ("aborted") once it is non-zero.  The flag stays owned by the caller; NULL detaches it. */
+int yafgpu_scene_set_abort_flag(yafgpu_scene_t *scene, const volatile int32_t *flag);
 int yafgpu_get_profile(const yafgpu_scene_t *scene, double ms[4], uint64_t launches[4]);
 
 /* Component probe for tests: evaluates device-side leaf functions (fast-math, QMC, camera, lights,

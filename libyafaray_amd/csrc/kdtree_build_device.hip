@@ -506,7 +506,12 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 	if(!d_verts.alloc(n * 9 * sizeof(float)) || !d_refs[0].alloc((size_t)cap_refs * sizeof(Ref)) || !d_refs[1].alloc((size_t)cap_refs * sizeof(Ref)) ||
 	   !d_work[0].alloc((size_t)cap_work * sizeof(Work)) || !d_work[1].alloc((size_t)cap_work * sizeof(Work)) ||
 	   !d_nodes.alloc((size_t)cap_nodes * sizeof(BfsNode)) || !d_leaf.alloc((size_t)cap_leaf * sizeof(uint32_t)) || !d_cnt.alloc(8 * sizeof(uint32_t)))
-		return fail("device kd build: out of device memory");
+	{	// -3: no room on the device for the builder's arrays (a bigger retry, or a card shared with a large scene): the caller
+		// takes the host builder, which produces the same format
+		if(err) *err = "device kd build: out of device memory";
+		(void)hipGetLastError();
+		return -3;
+	}
 	if(hipMemcpy(d_verts.p, verts, n * 9 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail("device kd build: vertex upload failed");
 	hipLaunchKernelGGL(init_refs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const float *)d_verts.p, n_tris, (Ref *)d_refs[0].p);
 	Work root{};

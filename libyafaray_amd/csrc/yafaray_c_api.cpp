@@ -99,7 +99,7 @@ struct yafaray_interface
 	int shard_index = 0, shard_count = 1;
 	std::vector<float> film;
 	yafaray_render_stats_t stats{};
-	volatile bool abort_flag = false;
+	volatile int32_t abort_flag = 0;     // Scene::abort: set by yafaray_abort (any thread), polled by the device side between chunks and passes
 	std::string color_space = "Raw_Manual_Gamma"; float gamma = 1.f;
 };
 
@@ -136,6 +136,13 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	p.get("transmit_filter", transmit_filter); p.get("receive_shadows", recv); p.get("flat_material", flat);
 	p.get("visibility", vis); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "shinydiffusemat: wireframe shading is not supported by the GPU path");
+	{	// parameters of recursiveRaytrace the device path does not honour (integrator_montecarlo.cc:791, :1003-1014): refuse them
+		// rather than render something else.  (`samplingfactor` only feeds a debug render pass, integrator_tiled.cc:597.)
+		int add_depth = 0; float tb_factor = 0.f; bool tb_mult = false;
+		p.get("additionaldepth", add_depth); p.get("transparentbias_factor", tb_factor); p.get("transparentbias_multiply_raydepth", tb_mult);
+		if(add_depth != 0) return fail(yi, "shinydiffusemat: additionaldepth is not supported by the GPU path");
+		if(tb_factor != 0.f || tb_mult) return fail(yi, "shinydiffusemat: transparentbias_factor / transparentbias_multiply_raydepth are not supported by the GPU path");
+	}
 	if(!yi->eparams.empty()) return fail(yi, "shinydiffusemat: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
 	std::memset(&m, 0, sizeof m);
 	m.type = YAFGPU_MAT_SHINYDIFFUSE; m.visibility = visibility_from(vis); m.receive_shadows = recv; m.flat = flat;
@@ -198,6 +205,7 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
 	if(aniso) return fail(yi, "glossy: the anisotropic (Ashikhmin-Shirley) lobe is not supported by the GPU path");
 	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
+	{ int add_depth = 0; p.get("additionaldepth", add_depth); if(add_depth != 0) return fail(yi, "glossy: additionaldepth is not supported by the GPU path"); }
 	if(!yi->eparams.empty()) return fail(yi, "glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
 	std::memset(&m, 0, sizeof m);
 	m.type = YAFGPU_MAT_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
@@ -857,6 +865,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	d.build_threads = 0;
 	int threads = -1; p.get("threads", threads); if(threads > 0) d.build_threads = threads;
 	if(yafgpu_scene_create(&d, &yi->gpu)) return fail(yi, std::string("scene upload: ") + yafgpu_last_error());
+	yafgpu_scene_set_abort_flag(yi->gpu, &yi->abort_flag);
 	yafgpu_tree_info ti{};
 	yafgpu_scene_info(yi->gpu, &ti);
 	yi->stats = yafaray_render_stats_t{};
@@ -940,7 +949,8 @@ static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)
 
 yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *output, const yafaray_progress_t *progress)
 {
-	yi->abort_flag = false;
+	// an abort that arrived before this call belongs to an earlier render (Scene::render clears the flag too, scene.cc:1040)
+	yi->abort_flag = 0;
 	if(progress && progress->init) progress->init(progress->user, 100);
 	if(progress && progress->setTag) progress->setTag(progress->user, "Rendering...");
 	if(!yafaray_prepareRender(yi)) return 0;
@@ -967,7 +977,7 @@ yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *o
 	return 1;
 }
 
-void yafaray_abort(yafaray_interface_t *yi) { yi->abort_flag = true; }
+void yafaray_abort(yafaray_interface_t *yi) { yi->abort_flag = 1; }
 void yafaray_internal_set_error(yafaray_interface_t *yi, const char *msg) { if(yi) yi->err = msg ? msg : ""; }
 
 yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output)

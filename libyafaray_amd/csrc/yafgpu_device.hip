@@ -1023,6 +1023,22 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return fail(-100, std::string(#expr) + ": " + hipGetErrorString(e_)); } while(0)
 
+// device allocation released on every exit path of the host entry points
+template<typename T> struct DevMem
+{
+	T *p = nullptr;
+	DevMem() = default;
+	DevMem(const DevMem &) = delete; DevMem &operator=(const DevMem &) = delete;
+	~DevMem() { if(p) (void)hipFree(p); }
+	hipError_t alloc(size_t count) { return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)); }
+	operator T *() const { return p; }
+};
+struct EventPair
+{
+	hipEvent_t e[2] = {nullptr, nullptr};
+	~EventPair() { for(hipEvent_t x : e) if(x) (void)hipEventDestroy(x); }
+};
+
 struct yafgpu_scene
 {
 	DevScene dev{};
@@ -1045,6 +1061,8 @@ struct yafgpu_scene
 	bool has_volumetric = false;
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
+	const volatile int32_t *abort_flag = nullptr;      // polled between chunks and passes (yafgpu_scene_set_abort_flag)
+	bool aborted() const { return abort_flag && *abort_flag != 0; }
 	bool profiling = false;
 	double prof_ms[4] = {0, 0, 0, 0}; uint64_t prof_launches[4] = {0, 0, 0, 0};   // trace closest, trace shadow, shade, other
 };
@@ -1109,6 +1127,9 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 {
 	if(!d || !out) return fail(-1, "null argument");
 	if(d->n_tris < 0 || d->n_materials <= 0) return fail(-2, "scene needs at least one material");
+	// the light-estimate bookkeeping of a parked path packs the light index and the end of its light range in 8 bits each
+	// (pack_dlc, yafgpu_wavefront.h)
+	if(d->n_lights < 0 || d->n_lights > 255) return fail(-2, "more than 255 lights: the device path indexes lights with 8 bits");
 	{	// a NaN or infinite coordinate poisons the scene bound and with it every ray's clip against it: refuse it here
 		const size_t nf = (size_t)d->n_tris * 9;
 		for(size_t k = 0; k < nf; ++k)
@@ -1147,7 +1168,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			// heavily overlapping geometry can outgrow the builder's arrays: more room, and past that the host builder
 			// (same format, same cost model) rather than no tree
 			const int brc = build_kdtree_device_retry(d->verts, d->n_tris, kDepthCap, s->tree, &err);
-			if(brc == -2) build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
+			if(brc == -2 || brc == -3) build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);     // arrays outgrown / no device memory for them
 			else if(brc) { delete s; return fail(-20, err); }
 		}
 		else build_kdtree(d->verts, d->n_tris, kDepthCap, d->build_threads, s->tree);
@@ -1373,7 +1394,11 @@ static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
 	if(rp->filter_type < YAFGPU_FILTER_BOX || rp->filter_type > YAFGPU_FILTER_LANCZOS) return fail(-12, "unknown filter type");
 	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
 	if(rp->integrator != YAFGPU_INTEGRATOR_PATH && rp->integrator != YAFGPU_INTEGRATOR_DIRECT) return fail(-14, "unknown integrator");
-	(void)s;
+	// the sample index of a light estimate in flight is packed in 12 bits (pack_dlc); validate() runs for every pass, so a
+	// light-sample multiplier that grows over the passes of an adaptive render is caught when it gets there
+	for(const yafgpu_light &l : s->h_lights)
+		if(l.type != YAFGPU_LIGHT_POINT && std::ceil((float)l.samples * rp->aa_light_sample_multiplier) > 4095.f)
+			return fail(-19, "an area light with more than 4095 samples per estimate (samples x AA light-sample multiplier): the device path counts them in 12 bits");
 	return 0;
 }
 
@@ -1446,11 +1471,14 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	const uint32_t n_pixels_total = masked ? (uint32_t)listed.size() : pp.back();
 	if(pp.size() > s->pix_prefix_cap)
 	{
+		HIP_OK(hipStreamSynchronize(stream));
 		if(s->d_pix_prefix) (void)hipFree(s->d_pix_prefix);
 		s->pix_prefix_cap = pp.size();
 		HIP_OK(hipMalloc((void **)&s->d_pix_prefix, s->pix_prefix_cap * sizeof(uint32_t)));
 	}
-	HIP_OK(hipMemcpy(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	// on `stream`: kernels of the previous pass may still be reading the table (a null-stream copy does not order against a
+	// non-blocking stream); the source is pageable, so the call returns once it has been staged
+	HIP_OK(hipMemcpyAsync(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 	uint32_t max_paths = kWfMaxPaths;
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
@@ -1460,6 +1488,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	if(frames > 7) return fail(-17, "raydepth > 7 with mirror / transparent materials: the device path keeps at most 7 recursion frames per sample");
 	if(cap > s->wf_cap || frames > s->wf_frames)
 	{
+		HIP_OK(hipStreamSynchronize(stream));
 		if(s->wf_state) (void)hipFree(s->wf_state);
 		if(s->wf_results) (void)hipFree(s->wf_results);
 		if(s->wf_queues) (void)hipFree(s->wf_queues);
@@ -1515,7 +1544,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
 		HIP_OK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
 	}
-	hipEvent_t ev[2] = {nullptr, nullptr};
+	EventPair evp;          // destroyed on every return
+	hipEvent_t (&ev)[2] = evp.e;
 	if(s->profiling) { HIP_OK(hipEventCreate(&ev[0])); HIP_OK(hipEventCreate(&ev[1])); for(int k = 0; k < 4; ++k) { s->prof_ms[k] = 0; s->prof_launches[k] = 0; } }
 	auto timed = [&](int slot, auto &&launch) -> int {
 		if(s->profiling) HIP_OK(hipEventRecord(ev[0], stream));
@@ -1532,6 +1562,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	};
 	for(uint32_t pb = 0; pb < n_pixels_total; pb += chunk_pixels)
 	{
+		if(s->aborted()) return fail(-30, "aborted");
 		WfArgs a{};
 		a.ra = ra;
 		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results; a.frames = frames;
@@ -1602,7 +1633,6 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
 	}
-	if(s->profiling) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
 	return 0;
 }
 
@@ -1630,7 +1660,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 			float table[256];
 			host_filter_table(rp->filter_type, table);
 			if(!s->d_filter_table) HIP_OK(hipMalloc((void **)&s->d_filter_table, sizeof table));
-			HIP_OK(hipMemcpy(s->d_filter_table, table, sizeof table, hipMemcpyHostToDevice));
+			HIP_OK(hipMemcpyAsync(s->d_filter_table, table, sizeof table, hipMemcpyHostToDevice, stream));
 			ra.filter_table = s->d_filter_table;
 		}
 	}
@@ -1668,14 +1698,15 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	{
 		if(s->h_tiles.size() > s->tiles_cap)
 		{
+			HIP_OK(hipStreamSynchronize(stream));      // the previous pass may still read the old arrays
 			if(s->d_tiles) (void)hipFree(s->d_tiles);
 			if(s->d_prefix) (void)hipFree(s->d_prefix);
 			s->tiles_cap = s->h_tiles.size();
 			HIP_OK(hipMalloc((void **)&s->d_tiles, s->tiles_cap * sizeof(int4)));
 			HIP_OK(hipMalloc((void **)&s->d_prefix, (s->tiles_cap + 1) * sizeof(uint32_t)));
 		}
-		HIP_OK(hipMemcpy(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(s->d_prefix, s->h_prefix.data(), s->h_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
+		HIP_OK(hipMemcpyAsync(s->d_prefix, s->h_prefix.data(), s->h_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		std::memcpy(s->tile_key, key, sizeof key);
 	}
 	HIP_OK(hipMemsetAsync(s->d_queue, 0, kQueues * 32 * sizeof(uint32_t), stream));
@@ -1723,11 +1754,12 @@ int yafgpu_film_combine(const float *d_planes, float *d_film, int32_t width, int
 int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, float *h_film, yafgpu_counters *h_counters)
 {
 	if(!s || !rp || !h_film) return fail(-1, "null argument");
-	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
+	if(rp->width <= 0 || rp->height <= 0) return fail(-10, "empty image");
+	DevMem<float> d_planes, d_film; DevMem<yafgpu_counters> d_cnt;
 	const size_t film_bytes = (size_t)rp->width * (size_t)rp->height * YAFGPU_FILM_CHANNELS * sizeof(float);
-	HIP_OK(hipMalloc((void **)&d_planes, yafgpu_planes_bytes(rp->width, rp->height)));
-	HIP_OK(hipMalloc((void **)&d_film, film_bytes));
-	HIP_OK(hipMalloc((void **)&d_cnt, sizeof(yafgpu_counters)));
+	HIP_OK(d_planes.alloc(yafgpu_planes_bytes(rp->width, rp->height) / sizeof(float)));
+	HIP_OK(d_film.alloc(film_bytes / sizeof(float)));
+	HIP_OK(d_cnt.alloc(1));
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
 	int rc = yafgpu_render_tiles(s, rp, d_planes, d_cnt, nullptr);
 	if(!rc) rc = yafgpu_film_combine(d_planes, d_film, rp->width, rp->height, nullptr);
@@ -1741,7 +1773,6 @@ int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, flo
 		if(hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
 		if(h_counters && hipMemcpy(h_counters, d_cnt, sizeof(yafgpu_counters), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "counter download failed");
 	}
-	(void)hipFree(d_planes); (void)hipFree(d_film); (void)hipFree(d_cnt);
 	return rc;
 }
 
@@ -1844,11 +1875,12 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	if(aa.passes > 1 && rp_in->shard_count > 1) return fail(-16, "multi-pass anti-aliasing needs the whole frame on one GPU: the noise detection between passes reads every pixel");
 	yafgpu_render_params rp = *rp_in;
 	const int w = rp.width, h = rp.height;
-	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
+	if(w <= 0 || h <= 0) return fail(-10, "empty image");
+	DevMem<float> d_planes, d_film; DevMem<yafgpu_counters> d_cnt;
 	const size_t film_bytes = (size_t)w * (size_t)h * YAFGPU_FILM_CHANNELS * sizeof(float);
-	HIP_OK(hipMalloc((void **)&d_planes, yafgpu_planes_bytes(w, h)));
-	HIP_OK(hipMalloc((void **)&d_film, film_bytes));
-	HIP_OK(hipMalloc((void **)&d_cnt, sizeof(yafgpu_counters)));
+	HIP_OK(d_planes.alloc(yafgpu_planes_bytes(w, h) / sizeof(float)));
+	HIP_OK(d_film.alloc(film_bytes / sizeof(float)));
+	HIP_OK(d_cnt.alloc(1));
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
 	auto film_now = [&]() -> int {
 		int rc = yafgpu_film_combine(d_planes, d_film, w, h, nullptr);
@@ -1868,6 +1900,7 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	int acum = aa_samples, resampled = 0; bool threshold_changed = true;
 	for(int i = 1; i < aa.passes && !rc; ++i)
 	{
+		if(s->aborted()) { rc = fail(-30, "aborted"); break; }
 		sample_mult *= aa.sample_multiplier_factor;
 		light_mult *= aa.light_sample_multiplier_factor;
 		if(!(resampled <= 0 && !threshold_changed))
@@ -1900,7 +1933,6 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 		if(e != hipSuccess) rc = fail(-100, std::string("render: ") + hipGetErrorString(e));
 	}
 	if(!rc && h_counters && hipMemcpy(h_counters, d_cnt, sizeof(yafgpu_counters), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "counter download failed");
-	(void)hipFree(d_planes); (void)hipFree(d_film); (void)hipFree(d_cnt);
 	return rc;
 }
 
@@ -1908,16 +1940,16 @@ static int trace_batch(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t 
 {
 	if(!s || !rays || n < 0) return fail(-1, "bad argument");
 	if(n == 0) return 0;
-	float *d_rays = nullptr, *d_t = nullptr, *d_b = nullptr; int *d_tri = nullptr, *d_sh = nullptr;
-	HIP_OK(hipMalloc((void **)&d_rays, (size_t)n * 8 * sizeof(float)));
+	DevMem<float> d_rays, d_t, d_b; DevMem<int> d_tri, d_sh;
+	HIP_OK(d_rays.alloc((size_t)n * 8));
 	HIP_OK(hipMemcpy(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
-	HIP_OK(hipMalloc((void **)&d_tri, (size_t)n * sizeof(int)));
-	HIP_OK(hipMalloc((void **)&d_t, (size_t)n * sizeof(float)));
-	HIP_OK(hipMalloc((void **)&d_b, (size_t)n * 3 * sizeof(float)));
-	HIP_OK(hipMalloc((void **)&d_sh, (size_t)n * sizeof(int)));
+	HIP_OK(d_tri.alloc((size_t)n));
+	HIP_OK(d_t.alloc((size_t)n));
+	HIP_OK(d_b.alloc((size_t)n * 3));
+	HIP_OK(d_sh.alloc((size_t)n));
 	const uint32_t grid = (uint32_t)std::min((n + kBlock - 1) / kBlock, 4096);
-	if(any) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays, d_tri, d_t, d_b, d_sh);
-	else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays, d_tri, d_t, d_b, d_sh);
+	if(any) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays.p, d_tri.p, d_t.p, d_b.p, d_sh.p);
+	else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(kBlock), 0, nullptr, s->dev, n, d_rays.p, d_tri.p, d_t.p, d_b.p, d_sh.p);
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipDeviceSynchronize());
 	if(any) HIP_OK(hipMemcpy(shadowed, d_sh, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -1927,7 +1959,6 @@ static int trace_batch(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t 
 		HIP_OK(hipMemcpy(t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
 		HIP_OK(hipMemcpy(bary, d_b, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
 	}
-	(void)hipFree(d_rays); (void)hipFree(d_tri); (void)hipFree(d_t); (void)hipFree(d_b); (void)hipFree(d_sh);
 	return 0;
 }
 
@@ -1940,6 +1971,13 @@ int yafgpu_trace_shadow(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t
 {
 	if(!shadowed) return fail(-1, "null output");
 	return trace_batch(s, n, rays, nullptr, nullptr, nullptr, shadowed, true);
+}
+
+int yafgpu_scene_set_abort_flag(yafgpu_scene_t *s, const volatile int32_t *flag)
+{
+	if(!s) return fail(-1, "null argument");
+	s->abort_flag = flag;
+	return 0;
 }
 
 int yafgpu_set_profiling(yafgpu_scene_t *s, int32_t enable)
@@ -1959,16 +1997,15 @@ int yafgpu_probe(yafgpu_scene_t *s, int32_t op, int32_t n, const float *in, int3
 {
 	if(!s || !in || !out || n < 0 || n_in <= 0 || n_out <= 0) return fail(-1, "bad argument");
 	if(n == 0) return 0;
-	float *d_in = nullptr, *d_out = nullptr;
-	HIP_OK(hipMalloc((void **)&d_in, (size_t)n * (size_t)n_in * sizeof(float)));
-	HIP_OK(hipMalloc((void **)&d_out, (size_t)n * (size_t)n_out * sizeof(float)));
+	DevMem<float> d_in, d_out;
+	HIP_OK(d_in.alloc((size_t)n * (size_t)n_in));
+	HIP_OK(d_out.alloc((size_t)n * (size_t)n_out));
 	HIP_OK(hipMemcpy(d_in, in, (size_t)n * (size_t)n_in * sizeof(float), hipMemcpyHostToDevice));
 	HIP_OK(hipMemset(d_out, 0, (size_t)n * (size_t)n_out * sizeof(float)));
-	hipLaunchKernelGGL(probe_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, s->dev, op, n, d_in, n_in, d_out, n_out);
+	hipLaunchKernelGGL(probe_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, s->dev, op, n, d_in.p, n_in, d_out.p, n_out);
 	HIP_OK(hipGetLastError());
 	HIP_OK(hipDeviceSynchronize());
 	HIP_OK(hipMemcpy(out, d_out, (size_t)n * (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost));
-	(void)hipFree(d_in); (void)hipFree(d_out);
 	return 0;
 }
 

@@ -62,7 +62,7 @@ GPU_ABI_SYMBOLS = [
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host", "yafgpu_render_passes_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
     "yafgpu_kdtree_build", "yafgpu_kdtree_build_device", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
-    "yafgpu_set_profiling", "yafgpu_get_profile",
+    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag",
 ]
 
 

@@ -1,6 +1,7 @@
 """Multi-GPU composition of one frame: pixel tiles are dealt round-robin to the ranks
 (tile t -> rank t % world, yafaray_setShard), every rank renders its tiles into zero-initialised
-full-frame film planes, and ONE sum-reduce to rank 0 assembles the frame — the semantics of the
+full-frame film planes, combines them into one [H][W][5] film (yafgpu_film_combine), and ONE sum-reduce
+of that film (20 MB at 1024^2) to rank 0 assembles the frame — the semantics of the
 reference's own film merge (sum colour, sum weight, normalise afterwards: imagefilm.cc:1467-1557).
 A reduce(sum) rather than a gather because a sample near a pixel's right/lower edge also lands on
 the neighbouring pixel (imagefilm.cc:933-936), which may belong to another rank's tile."""
@@ -12,9 +13,13 @@ def shard_of_tile(tile_index, world_size):
     return tile_index % world_size
 
 
-def reduce_planes(planes: torch.Tensor, dst: int = 0):
-    """Sum the per-rank film planes onto rank `dst` (RCCL over xGMI on GPUs, gloo on CPU tests).
-    Interior pixels are non-zero on exactly one rank, so their sum is exact (x + 0)."""
+def reduce_film(film: torch.Tensor, dst: int = 0):
+    """Sum the per-rank films (or film planes) onto rank `dst` (RCCL over xGMI on GPUs, gloo on CPU tests).
+    Interior pixels are non-zero on exactly one rank, so their sum is exact (x + 0); a tile-border pixel also
+    carries the neighbouring rank's splat, added here instead of inside the combine (<= 1 ulp of order effect)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(planes, dst=dst, op=dist.ReduceOp.SUM)
-    return planes
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    return film
+
+
+reduce_planes = reduce_film      # the same collective on the four uncombined splat planes

@@ -9,7 +9,13 @@ textures on the device path: the six cubes keep their plain material colours).
 
 With --shipped it writes tests/golden/test01_dl.xml instead: the same stripping of textures, but the
 integrator and render settings the reference ships (directlighting, 480x270, 1 spp, gauss filter width 1.5) —
-the configuration BASELINE.md's 0.9 s badge was rendered with."""
+the configuration BASELINE.md's 0.9 s badge was rendered with.
+
+With --expected it copies the one rendered image the reference's tests hold for that scene
+(tests/test01/"test01 - expected render result.png": 480x340 RGBA = a 70-row parameters badge on top of the 480x270
+render, sRGB, 8 bit) to tests/golden/test01_expected.png and writes tests/golden/test01_expected.json: the badge height
+and the names of the materials that carry NO shader node in the shipped scene (their pixels can be compared with a
+render of test01_dl.xml; the six textured cubes cannot until textures exist on the device path)."""
 import os
 import re
 import sys
@@ -18,7 +24,23 @@ SRC = "/root/reference/tests/test01/test01.xml"
 DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test01_pt.xml")
 
 
+def expected():
+    import json
+    import shutil
+    here = os.path.dirname(os.path.abspath(__file__))
+    src_png = os.path.join(os.path.dirname(SRC), "test01 - expected render result.png")
+    shutil.copyfile(src_png, os.path.join(here, "test01_expected.png"))
+    x = re.sub(r"<!--.*?-->", "", open(SRC).read(), flags=re.S)
+    plain = [m.group(1) for m in re.finditer(r'<material name="([^"]*)">(.*?)</material>', x, flags=re.S) if "<list_element>" not in m.group(2)]
+    meta = {"source": "tests/test01/test01 - expected render result.png of the reference", "badge_rows_on_top": 70, "width": 480, "height": 270,
+            "color_space": "sRGB", "untextured_materials": plain}
+    json.dump(meta, open(os.path.join(here, "test01_expected.json"), "w"), indent=1)
+    print(meta)
+
+
 def main():
+    if "--expected" in sys.argv[1:]:
+        return expected()
     shipped = "--shipped" in sys.argv[1:]
     dst = DST.replace("test01_pt", "test01_dl") if shipped else DST
     if not os.path.exists(SRC):

@@ -24,7 +24,7 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from libyafaray_amd import scenes
-    from libyafaray_amd.parallel import reduce_planes, shard_of_tile
+    from libyafaray_amd.parallel import reduce_film, shard_of_tile
     from oracle import pyoracle as po
     sc = scenes.cornell_soup(400, seed=21, res=(48, 40))
     rd = scenes.render_settings(48, 40, 8, bounces=2, tile_size=16, shard_index=rank, shard_count=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, out_path):
             own[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
     assert st.camera_samples == own.sum() * 8
     t = torch.from_numpy(film.copy())
-    reduce_planes(t, dst=0)
+    reduce_film(t, dst=0)
     if rank == 0:
         np.save(out_path, t.numpy())
     dist.barrier()

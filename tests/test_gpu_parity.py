@@ -152,6 +152,28 @@ def test_test01_xml_shipped_settings_direct_lighting_gauss(pipeline):
     compare_films(film, ofilm, "test01 shipped settings", exact_weights=False)
 
 
+def test_device_whole_path_against_the_references_expected_png(pipeline):
+    """The DEVICE render of the reference's shipped test scene (textures stripped) through the reference's output
+    transform, against the expected PNG the reference's tests hold — every pixel whose filter footprint sees only
+    untextured materials (47 % of the frame; tests/png_fixture.py).  The same bounds as the oracle's own check
+    (tests/test_oracle_golden.py): >= 99.5 % within two 8-bit levels, >= 96 % within one, >= 80 % equal."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline implements the narrow box filter only")
+    import os
+    from tests import png_fixture, xml_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test01_dl.xml")
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film = yi.getFilm(480, 270)
+    sc, rd = xml_scene.load(path)
+    st = png_fixture.compare(film, sc, rd, "device")
+    assert st["fraction_of_frame"] > 0.45
+    assert st["within_2"] >= 0.995 * st["pixels_compared"], st
+    assert st["within_1"] >= 0.96 * st["pixels_compared"], st
+    assert st["exact"] >= 0.80 * st["pixels_compared"], st
+
+
 def _sphere_soup(n_lat=10, n_lon=16, radius=0.45, centre=(0.0, 0.1, -0.3)):
     """a tessellated sphere with exported vertex normals (addNormal path, Triangle::getSurface smooth branch)"""
     c = np.array(centre, np.float32)
@@ -239,55 +261,123 @@ def test_reconstruction_filters(filt, width, pipeline):
 # crop's first row and column, which in the full frame also receive the box filter's splats from the pixels
 # above / to the left (ImageFilm::addSample).  That pins the full-size renders to the oracle at a cost of a few
 # tens of thousands of oracle samples per window.
-def _full_size_against_crops(name, crops, size, lights=None):
+def _oracle_threads():
+    import bench
+    return max(1, min(32, bench.host_cpu_share()))
+
+
+def _full_size_against_crops(name, crops, size, lights=None, low_spp=4):
+    """(1) the configuration at its full size on the GPU, pinned to the oracle on crop windows that together cover
+    >= 5 % of the frame; (2) the WHOLE frame at `low_spp` samples per pixel against the oracle's whole frame — in the
+    parity regime the film is a pure function of (pixel, sample index), so every pixel of the full-size frame is
+    checked at its first samples, at the full triangle count (where a traversal leak or a tie would show)."""
     import bench
     w, sc, rd = bench.make_workload(name, lights=lights)
+    W, H = rd["width"], rd["height"]
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.render()
-    film = yi.getFilm(rd["width"], rd["height"])
+    film = yi.getFilm(W, H)
     st = yi.getRenderStats()
-    assert st.camera_samples == rd["width"] * rd["height"] * rd["AA_minsamples"]
+    assert st.camera_samples == W * H * rd["AA_minsamples"]
     assert st.n_triangles == len(sc["verts"])
     # every sample adds weight 1 to its own pixel, and to the right / lower neighbour as well when its offset is
     # >= 0.999 of a pixel (box half-width 0.501): about 0.1 % of the samples per axis
-    n_samples = rd["width"] * rd["height"] * rd["AA_minsamples"]
+    n_samples = W * H * rd["AA_minsamples"]
     extra = float(film[..., 4].astype(np.float64).sum()) - n_samples
     assert 0 <= extra < 0.004 * n_samples, f"film weight {extra} over the sample count"
     yi.render()                                   # determinism: the second pass gives the same bits
-    assert np.array_equal(film, yi.getFilm(rd["width"], rd["height"])), "two passes over the same scene differ"
+    assert np.array_equal(film, yi.getFilm(W, H)), "two passes over the same scene differ"
     osc = po.OracleScene(sc)
+    threads = _oracle_threads()
     bad = total = 0
     for (x0, y0) in crops:
-        ofilm, _ = osc.render(dict(rd, xstart=x0, ystart=y0, width=size, height=size, oracle_threads=8))
+        ofilm, _ = osc.render(dict(rd, xstart=x0, ystart=y0, width=size, height=size, oracle_threads=threads))
         g = film[y0 + 1:y0 + size, x0 + 1:x0 + size]
-        n_bad, exact = compare_films(g, ofilm[1:, 1:], f"{name} full size, window at ({x0},{y0})", max_outliers=2)
+        n_bad, exact = compare_films(g, ofilm[1:, 1:], f"{name} full size, window at ({x0},{y0})", max_outliers=max(2, size * size // 2000))
         bad += n_bad; total += g.shape[0] * g.shape[1]
-    osc.close()
+    assert total >= 0.05 * W * H, f"windows cover {total / (W * H):.3f} of the frame"
     assert bad <= max(1, total // 2000)       # SURVEY 8c: two builds of the reference itself differ on ~3e-5 of pixels
+    # whole frame, few samples
+    rd_low = dict(rd, AA_minsamples=low_spp)
+    yi2 = Interface()
+    scenes.load_scene(yi2, sc, rd_low)
+    yi2.render()
+    film_low, st_low = yi2.getFilm(W, H), yi2.getRenderStats()
+    ofilm, ost = osc.render(dict(rd_low, oracle_threads=threads))
+    osc.close()
+    assert st_low.rays_closest == ost.rays_closest and st_low.rays_shadow == ost.rays_shadow, f"{name} whole frame at {low_spp} spp: ray counts differ"
+    compare_films(film_low, ofilm, f"{name} WHOLE frame {W}x{H} at {low_spp} spp", max_outliers=max(1, W * H // 20000))
     return st
+
+
+def test_full_size_m1_against_oracle_windows(pipeline):
+    """The configuration BASELINE.json's metric is quoted on (bench.py's default): 1M triangles, 512x512, 64 spp,
+    primary + 1 bounce.  4 windows of 64x64 = 6 % of the frame at 64 spp + the whole frame at 4 spp."""
+    if pipeline == "megakernel":
+        pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
+    _full_size_against_crops("m1", [(30, 40), (224, 224), (440, 300), (200, 440)], 64)
 
 
 def test_full_size_c2_against_oracle_windows(pipeline):
     """BASELINE.json configs[1]: 100k triangles, 512x512, 64 spp, primary + 1 bounce."""
     if pipeline == "megakernel":
         pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
-    _full_size_against_crops("c2", [(40, 60), (250, 250), (470, 300), (200, 480)], 24)
+    _full_size_against_crops("c2", [(40, 60), (224, 224), (440, 300), (200, 440)], 64)
 
 
 def test_full_size_c3_against_oracle_windows(pipeline):
-    """BASELINE.json configs[2]: 1M triangles, 1024x1024, 256 spp, 2 bounces."""
+    """BASELINE.json configs[2]: 1M triangles, 1024x1024, 256 spp, 2 bounces.  4 windows of 116x116 = 5.1 % of the
+    frame at 256 spp + the whole frame at 2 spp."""
     if pipeline == "megakernel":
         pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
-    _full_size_against_crops("c3", [(100, 700), (512, 512)], 12)
+    _full_size_against_crops("c3", [(100, 700), (454, 454), (800, 200), (600, 880)], 116, low_spp=2)
 
 
 def test_full_size_c4_one_light_against_oracle_windows(pipeline):
-    """BASELINE.json configs[3] in its parity variant (one area light: SURVEY 8d): 1M triangles, half of them
-    glossy, 1024x1024, 64 spp, 2 bounces, MIS."""
+    """BASELINE.json configs[3] in its one-light variant: 1M triangles, half of them glossy, 1024x1024, 64 spp,
+    2 bounces, MIS.  (The two-light configuration as stated: test_full_size_c4_two_lights_exact_replay.)"""
     if pipeline == "megakernel":
         pytest.skip("full-size runs use the default pipeline; the two are compared bit for bit at small sizes")
-    _full_size_against_crops("c4", [(300, 800), (640, 400)], 16, lights=1)
+    _full_size_against_crops("c4", [(300, 800), (640, 400), (60, 100), (850, 850)], 116, lights=1, low_spp=2)
+
+
+def test_device_shards_sum_to_the_unsharded_frame(pipeline):
+    """The multi-GPU decomposition on ONE GPU: shard 0/2 and 1/2 (tile t -> rank t % 2, yafaray_setShard) rendered by the
+    device one after the other, their films summed as parallel.reduce_film sums them over RCCL — equal to the unsharded
+    device film bit for bit on every pixel that is not on a tile's first row / column (those also take a neighbouring
+    tile's box-filter splat, i.e. one addition in another order), and to 1 ulp there."""
+    if pipeline == "megakernel":
+        pytest.skip("sharding is exercised on the default pipeline")
+    W, H, T = 160, 128, 32
+    sc = scenes.cornell_soup(6000, seed=23, res=(W, H), glossy_fraction=0.3)
+    rd = scenes.render_settings(W, H, 16, bounces=3, tile_size=T)
+    def render(index, count):
+        yi = Interface()
+        scenes.load_scene(yi, sc, rd)
+        yi.setShard(index, count)
+        yi.render()
+        return yi.getFilm(W, H), yi.getRenderStats()
+    full, st_full = render(0, 1)
+    for world in (2, 3):
+        parts = [render(r, world) for r in range(world)]
+        assert sum(p[1].camera_samples for p in parts) == st_full.camera_samples
+        assert sum(p[1].rays_closest for p in parts) == st_full.rays_closest and sum(p[1].rays_shadow for p in parts) == st_full.rays_shadow
+        total = np.zeros_like(full)
+        for f, _ in parts:
+            total = total + f
+        # ownership: a shard's own-pixel weight is zero outside its tiles (up to border splats)
+        ntx = (W + T - 1) // T
+        for r, (f, _) in enumerate(parts):
+            for t in range(ntx * ((H + T - 1) // T)):
+                if t % world != r:
+                    tx, ty = t % ntx, t // ntx
+                    assert not f[ty * T + 1:(ty + 1) * T, tx * T + 1:(tx + 1) * T, 4].any(), "a shard rendered a tile it does not own"
+        interior = np.ones((H, W), bool)
+        interior[::T, :] = False; interior[:, ::T] = False
+        assert np.array_equal(total[interior], full[interior]), f"{world} shards: interior pixels differ from the unsharded frame"
+        assert np.array_equal(total[..., 4], full[..., 4]), "weights differ"
+        np.testing.assert_allclose(total, full, rtol=2.5e-7, atol=1e-7)
 
 
 # ---- multi-pass anti-aliasing: TiledIntegrator::render's pass schedule + ImageFilm::nextPass ----------------

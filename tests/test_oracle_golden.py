@@ -335,3 +335,23 @@ def test_faure_tables_match_reference_file():
         n = C.c_int()
         p = L.yor_faure_perm(dim, C.byref(n))
         assert [p[i] for i in range(n.value)] == arrays[names[dim]], dim
+
+
+def test_whole_path_against_the_references_expected_png():
+    """The only whole-path fixture the reference holds (tests/test01's expected render, see tests/png_fixture.py): the
+    ORACLE's render of the shipped scene (textures stripped), pushed through the reference's output transform, against
+    the PNG on every pixel whose filter footprint sees only untextured materials — 47 % of the frame.  This pins
+    camera, traversal, direct lighting, shadow rays, film filter (gauss 1.5) and the sRGB / 8-bit output together.
+    Observed: 83.6 % of those pixels equal, 97.2 % within one level, 99.67 % within two; the rest (205 pixels) sit on
+    1-spp silhouette and shadow edges, where the reference image shows intermediate values (it was made by a later
+    build, v3.1.1-beta per its badge, and test01.xml asks for the OpenCV denoiser)."""
+    import os
+    from tests import png_fixture, xml_scene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test01_dl.xml")
+    sc, rd = xml_scene.load(path)
+    film, _ = po.OracleScene(sc).render(dict(rd, oracle_threads=4))
+    st = png_fixture.compare(film, sc, rd, "oracle")
+    assert st["fraction_of_frame"] > 0.45
+    assert st["within_2"] >= 0.995 * st["pixels_compared"], st
+    assert st["within_1"] >= 0.96 * st["pixels_compared"], st
+    assert st["exact"] >= 0.80 * st["pixels_compared"], st

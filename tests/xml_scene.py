@@ -65,7 +65,8 @@ def load(path):
     meshes.sort(key=lambda m: m[0])          # Scene::update walks its std::map in object-id order (scene.cc:797)
     verts = np.concatenate([m[1][m[2]] for m in meshes], axis=0).astype(np.float32)
     tri_mat = np.concatenate([m[3] for m in meshes]).astype(np.int32)
-    scene = {"verts": verts, "tri_mat": tri_mat, "vnormals": None, "materials": mats, "lights": lights, "camera": camera}
+    scene = {"verts": verts, "tri_mat": tri_mat, "vnormals": None, "materials": mats, "lights": lights, "camera": camera,
+             "material_names": sorted(mat_index, key=mat_index.get)}
     integ = integrators[render["integrator_name"]]
     rd = dict(render)
     rd["integrator"] = integ["type"]

@@ -27,16 +27,41 @@ for k in sorted(agg):
     print("==", k, "launches", len(launches[k]))
     for c, v in sorted(agg[k].items()):
         print(f"   {c:26s} {v:.6g}")
-# HBM-side traffic of the traversal kernels per launch: (FETCH_SIZE + WRITE_SIZE) KiB -> bytes.
-# MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streams by 2x on gfx950; the traversal's 8/16-byte
-# gathers are an uncalibrated width, so the raw figure is reported.
-tr = [k for k in agg if k.startswith("wf_trace") and ", false>" in k]
-fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in tr) * 1024
-write = sum(agg[k].get("WRITE_SIZE", 0) for k in tr) * 1024
+def ratios(keys):
+    g = lambda c: sum(agg[k].get(c, 0.0) for k in keys)
+    o = {}
+    if g("SQ_ACTIVE_INST_VALU"): o["lane_utilisation"] = round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)
+    if g("SQ_INSTS_VALU"): o["salu_per_valu"] = round(g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"), 4)
+    if g("TCC_HIT_sum") + g("TCC_MISS_sum"): o["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+    return o
+# Memory-side traffic per launch: (FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  MI355X_MICROARCH.md ("HBM"): FETCH_SIZE reports
+# exactly half of a WIDE COALESCED streaming read (16 B/lane) and is uncalibrated for other widths; WRITE_SIZE is exact.
+# The traversal reads are 8/16-byte gathers (uncalibrated width): `traffic` is the raw sum, `traffic_fetch_x2` the upper
+# bound with the streaming correction applied to every fetched byte.  The shade kernel's record loads ARE 16 B/lane
+# coalesced streams, so its corrected figure uses the x2.
+doc = {"source": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE,TCC_HIT,TCC_MISS | SQ set 1 | SQ set 2), tools/pmc.sh",
+       "fetch_correction": "wf_trace: none (8/16-B gathers are an uncalibrated width, MI355X_MICROARCH.md HBM section); x2 upper bound in traffic_fetch_x2"}
+tr = [k for k in agg if k.startswith("wf_trace<") and ", false>" in k]
 n = sum(len(launches[k]) for k in tr)
 if n:
-    json.dump({"kernel": "wf_trace", "launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
-               "traffic_bytes_per_launch": (fetch + write) / n, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), raw"},
-              open(out + "/traffic.json", "w"), indent=1)
-    print("traffic per wf_trace launch: %.3f MB" % ((fetch + write) / n / 1e6))
+    fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in tr) * 1024
+    write = sum(agg[k].get("WRITE_SIZE", 0) for k in tr) * 1024
+    doc.update({"kernel": "wf_trace", "launches": n, "fetch_bytes_per_launch_raw": fetch / n, "write_bytes_per_launch": write / n,
+                "traffic_bytes_per_launch": (fetch + write) / n, "traffic_fetch_x2": (2 * fetch + write) / n})
+    doc.update(ratios(tr))
+    for name, sel in (("closest", "wf_trace<false"), ("any_hit", "wf_trace<true")):
+        ks = [k for k in tr if k.startswith(sel)]
+        m = sum(len(launches[k]) for k in ks)
+        if m:
+            doc[name] = dict(launches=m, fetch_bytes_per_launch_raw=sum(agg[k].get("FETCH_SIZE", 0) for k in ks) * 1024 / m,
+                             write_bytes_per_launch=sum(agg[k].get("WRITE_SIZE", 0) for k in ks) * 1024 / m, **ratios(ks))
+    print("traffic per wf_trace launch: %.3f MB raw" % ((fetch + write) / n / 1e6))
+sh = [k for k in agg if "wf_shade" in k]
+m = sum(len(launches[k]) for k in sh)
+if m:
+    fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in sh) * 1024
+    write = sum(agg[k].get("WRITE_SIZE", 0) for k in sh) * 1024
+    doc["shade"] = dict(launches=m, fetch_bytes_per_launch_raw=fetch / m, write_bytes_per_launch=write / m,
+                        traffic_bytes_per_launch_fetch_x2=(2 * fetch + write) / m, **ratios(sh))
+json.dump(doc, open(out + "/traffic.json", "w"), indent=1)
 PY

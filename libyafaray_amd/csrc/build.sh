@@ -2,7 +2,7 @@
 # Builds libyafaray_gpu.so (HIP kernels + narrow ABI + Interface-shaped C API) for gfx950, in-tree.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../libyafaray_gpu.so"
+OUT="${YAFGPU_OUT:-$HERE/../libyafaray_gpu.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -ffp-contract=off and IEEE divide/sqrt: the shading arithmetic must round like the reference's
 # expressions (discrete hit / lobe / shadow decisions decide image parity)

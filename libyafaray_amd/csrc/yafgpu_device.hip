@@ -1500,7 +1500,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
 		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
 		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
-		HIP_OK(hipMalloc((void **)&s->wf_verdict, (size_t)2 * cap * sizeof(uint32_t)));
+		HIP_OK(hipMalloc((void **)&s->wf_verdict, ((size_t)2 * cap + 31) / 32 * sizeof(uint32_t) + 64));      // one bit per shadow ray
 		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
 	}
@@ -1610,6 +1610,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			// side stream so that its waves fill the closest-hit launch's tail (and vice versa).
 			const bool fork = overlap_now;
 			hipStream_t any_stream = fork ? s->side_stream : stream;
+			if(it > 0) HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * s->wf_cap + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
 			if(it > 0 && (rc = timed(1, [&] {
 				if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
 				else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);

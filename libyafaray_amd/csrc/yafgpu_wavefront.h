@@ -37,7 +37,7 @@ struct WfArgs
 	// MIS pair).  resume queue: the paths (once each) that wait for shadow answers.
 	const uint32_t *q_closest_in, *q_shadow_in, *q_resume_in;   // nullptr closest queue = identity (first iteration)
 	uint32_t *q_closest_out, *q_shadow_out, *q_resume_out;
-	uint32_t *verdict;                // [2*slot + which] any-hit answers
+	uint32_t *verdict;                // any-hit answers: BIT 2*slot + which, set for an occluded ray (zeroed before every any-hit launch)
 	float4 *shadow_filt;              // [2*slot + which] product of the transparencies a shadow ray passed (transparent shadows), or nullptr
 	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
@@ -138,7 +138,8 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int ph
 // ---- the per-path program, cut into steps that talk to each other through the parked records ----
 //
 // Record map (float4 each, record k of path s at state[k*cap + s]):
-//   r0  ray origin | tmin            r1  ray direction | tmax          r2  closest-hit answer (tri, t, u, v)
+//   r0  ray origin | tmin            r1  ray direction | tmax          r2  closest-hit answer (tri, t, u, v) — indexed by QUEUE POSITION, not by path
+//       (the traversal kernel writes entry i of its queue, wf_shade walks the same queue: both sides stream)
 //   r3  sp0.p | mat0     r4 sp0.n    r5  sp0.ng | bsdfs0     r6  wo0                      (camera hit)
 //   r7  hit.p | mat      r8 hit.n    r9  hit.ng              r10 pwo                      (current path vertex)
 //   r11 throughput | rr.x            r12 path_col | rr.c     r13 col | pc,stage,dl_on_sp0,depth,path_i
@@ -232,10 +233,9 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 #define YAFGPU_FEAT_RECURSE 1
 #endif
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
-YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal)
+YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal, const float4 ans)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	const float4 ans = REC(2);
 	const int tri = (int)ubits(ans.x);
 	const bool got = tri >= 0;
 	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -634,7 +634,7 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 #undef FREC
 
 // Resume a parked path and run it to its next kd-tree query (or to its end).
-YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, float result[4], int &out_mask)
+YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, const float4 ans, float result[4], int &out_mask)
 {
 	Ctl c = load_ctl(a, slot);
 	int where = (c.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
@@ -646,11 +646,16 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// 6.9 -> 7.7 ms on C2.)
 	Hot h; h.valid = 0u; h.dirty = 0u;
 	uint2 verdict = make_uint2(0u, 0u);
-	if(where == W_AFTER_SHADOW) { verdict = *(const uint2 *)&a.verdict[2u * slot]; hot_preload(a, slot, h); }
+	if(where == W_AFTER_SHADOW)
+	{	// bit 2*slot + which of the verdict bit array (set by the any-hit kernel for an occluded ray)
+		const uint32_t w = a.verdict[slot >> 4], sh = (slot & 15u) << 1;
+		verdict = make_uint2((w >> sh) & 1u, (w >> (sh + 1u)) & 1u);
+		hot_preload(a, slot, h);
+	}
 	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
 	// order (a dispatch loop makes the optimizer thread the transitions, duplicate the steps and keep the union
 	// of their registers alive: 163 VGPRs against 81 for the widest single step).
-	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal);
+	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal, ans);
 	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
 	while(where == W_DL_NEXT || where == W_DL_EVAL)
 	{
@@ -680,13 +685,13 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 __global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArgs a, int *out)
 {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; float r[4] = {0.f, 0.f, 0.f, 0.f}; int m = 0;
-	out[slot] = wf_advance(a, slot, slot * 3u, slot * 5u, slot * 7u, r, m) + m + (int)r[0] + (int)r[3];
+	out[slot] = wf_advance(a, slot, slot * 3u, slot * 5u, slot * 7u, a.state[2 * (size_t)a.cap + slot], r, m) + m + (int)r[0] + (int)r[3];
 }
 #define PROBE(name, call) __global__ __launch_bounds__(kBlock, PROBE_WAVES) void name(const WfArgs a, int *out) { \
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
 	Hot h; hot_preload(a, slot, h); const int w = call; hot_flush(a, slot, h); \
 	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
-PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u))
+PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot]))
 PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))
 PROBE(probe_dl_next, st_dl_next(a, slot, h))
 PROBE(probe_dl_eval, st_dl_eval(a, slot, h, c, slot * 3u, slot * 5u, m))
@@ -805,8 +810,23 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_REFILL
 #define YAFGPU_REFILL 24               // C2 sweep (voted rounds): 8..32 within 2 %, 48 -> -5 %, 56 -> -12 %
 #endif
+// Postponed leaves.  A lane that reaches a non-empty leaf does not stop there: it notes the leaf as PENDING (its
+// reference range and the exit distance of its cell) and walks on at once, as if the leaf held no terminating hit; only
+// at a second non-empty leaf does it wait.  A lane then usually has both kinds of work on offer — node steps of the
+// walk ahead and triangle tests of the pending leaf — so whichever kind the wave votes for, more lanes take part (the
+// voted rounds alone left half of the lanes idle in every round: PMC lane utilisation 38-44 %).  Nothing about the
+// answer changes: the triangles tested, and their order per ray, are those of TriKdTree::intersect — the pending leaf
+// is always tested before a later one is even noted, a hit inside its cell ends the ray exactly where :822 does, and
+// the walk ahead is thrown away then (its node steps are the price: counted apart in the stats build).  A walk may end
+// early on the hit known so far (`hit && z <= tmax`, `z < tmin`): z only shrinks, so the sequential walk ends there too.
+#ifndef YAFGPU_TRACE_POSTPONE
+#define YAFGPU_TRACE_POSTPONE 1
+#endif
+#ifndef YAFGPU_TRACE_WAVES
+#define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
+#endif
 template<bool kAny, bool kStats>
-__global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
+__global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfArgs a)
 {
 	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];
 	// (origin, 1/direction) of the lane's ray per axis: a node step fetches the pair of its split axis with one
@@ -822,9 +842,8 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 	uint32_t *cursor = kAny ? &a.cnt_in[3] : &a.cnt_in[2];
 	const uint32_t *q = kAny ? a.q_shadow_in : a.q_closest_in;
 	const size_t c = a.cap;
-	// per-lane ray + traversal state
 	bool exhausted = (n == 0u);
-	uint32_t slot = 0u, node = 0u, which = 0u;
+	uint32_t slot = 0u, node = 0u, which = 0u, qi = 0u;      // qi: the ray's position in the queue (where a closest-hit answer goes)
 	uint32_t w_next = 0u, w_end = 0u;      // this wave's reserved queue range (wave-uniform)
 	// reservation size: large enough to keep the counter word off the critical path, small enough that a short queue still spreads over all waves
 	const uint32_t batch = min((uint32_t)kTraceBatch, max((uint32_t)kWave, (n / (gridDim.x * (uint32_t)kWavesPerBlock * 2u)) & ~63u));
@@ -832,13 +851,26 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 	uint32_t dneg = 0u;                    // bit k: direction component k <= 0 (the tie rule at o == split)
 	float ray_tmin = 0.f, dist = 0.f, t_exit = 0.f, tmin = 0.f, tmax = 0.f, z = 0.f, bu = 0.f, bv = 0.f;
 	int tri = -1; bool hit = false;
-	enum : uint32_t { kAtNode = 0u, kAtTri = 1u, kIdle = 2u, kDone = 3u };     // kIdle: no ray; kDone: answer to be written
+	// Answers.  Any-hit: one BIT per ray in a zeroed array, set only for occluded rays (a 4-byte word per ray scattered by
+	// path cost 9x the verdicts' size in HBM writes).  Closest-hit: 16 B at the ray's QUEUE position — waves own contiguous
+	// queue ranges, so the stores of a wave fall into a few lines that complete while still in L2 (by path they were 2.4x).
+	auto answer_any = [&](bool occluded) {
+		const uint32_t bit = 2u * slot + which;
+		if(occluded) atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u));
+	};
+	// the walk: at a node | at a non-empty leaf, waiting for the pending slot | no node left | no ray
+	enum : uint32_t { kWalk = 0u, kBlocked = 1u, kWalkEnd = 2u, kNoRay = 3u };
 	constexpr int kVoteNum = YAFGPU_VOTE_NUM, kVoteDen = YAFGPU_VOTE_DEN, kNodeBurst = YAFGPU_NODE_BURST;
-	uint32_t mode = kIdle, np = 0u, first = 0u, k = 0u, ti = 0u;
+	uint32_t ws = kNoRay;
+	uint32_t p_cur = 0u, p_end = 0u, ti = 0u;       // pending leaf: references [p_cur, p_end) still to test, ti = refs[p_cur] (in flight)
+	float p_tmax = 0.f;                              // exit distance of the pending leaf's cell
+	bool done = false;
+	uint32_t spec = 0u;                              // kStats: node steps + leaves of the walk ahead of the pending leaf
+	uint32_t spec_leaves = 0u;
 	uint32_t rounds_node = 0u, rounds_tri = 0u;     // wave-uniform (kStats)
 	for(;;)
 	{
-		const unsigned long long idle = __ballot(mode == kIdle);
+		const unsigned long long idle = __ballot(ws == kNoRay);
 		const int n_idle = __popcll(idle);
 		if(!exhausted && (n_idle >= YAFGPU_REFILL || n_idle == kWave))
 		{
@@ -855,73 +887,69 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			}
 			const uint32_t avail = w_end - w_next;
 			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-			const uint32_t first = w_next;
+			const uint32_t first_i = w_next;
 			w_next += min(avail, (uint32_t)n_idle);
-			if(mode == kIdle && rank < avail)
+			if(ws == kNoRay && rank < avail)
 			{
-				const uint32_t i = first + rank;
+				const uint32_t i = first_i + rank;
+				slot = q ? q[i] : i;
+				qi = i;
+				which = 0u;
+				if(kAny) { which = slot >> 31; slot &= 0x7fffffffu; }
+				float4 r0 = a.state[slot], r1 = a.state[c + slot];
+				if(kAny && which)
+				{	// second ray of the pair: same origin, direction/tmin in r20, tmax in r21.w
+					const float4 r20 = a.state[20 * c + slot];
+					r1 = make_float4(r20.x, r20.y, r20.z, a.state[21 * c + slot].w);
+					r0.w = r20.w;
+				}
+				from = v3(r0); dir = v3(r1);
+				if(kAny)
 				{
-					slot = q ? q[i] : i;
-					which = 0u;
-					if(kAny) { which = slot >> 31; slot &= 0x7fffffffu; }
-					float4 r0 = a.state[slot], r1 = a.state[c + slot];
-					if(kAny && which)
-					{	// second ray of the pair: same origin, direction/tmin in r20, tmax in r21.w
-						const float4 r20 = a.state[20 * c + slot];
-						r1 = make_float4(r20.x, r20.y, r20.z, a.state[21 * c + slot].w);
-						r0.w = r20.w;
-					}
-					from = v3(r0); dir = v3(r1);
-					if(kAny)
-					{
-						from = from + dir * r0.w;
-						dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
-						// intersectS accepts hits from 0 on, intersectTs (transpShad) from the ray's tmin_ on — measured from
-						// the origin already moved by tmin_ (kdtree_triangle.cc:936 / :1099, scene.cc isShadowed)
-						ray_tmin = a.ra.rp.transp_shad ? r0.w : 0.f;
-						++cn.shadow;
-					}
-					else
-					{
-						dist = (r1.w < 0.f) ? INFINITY : r1.w;
-						ray_tmin = r0.w;
-						++cn.closest;
-					}
-					float ea, eb;
-					tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f;
-					const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
-					if(sc.n_nodes != 0u && bound_cross(sc, from, dir, inv_dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
-					{
-						axis_col[0] = make_float2(from.x, inv_dir.x);
-						axis_col[kWave] = make_float2(from.y, inv_dir.y);
-						axis_col[2 * kWave] = make_float2(from.z, inv_dir.z);
-						dneg = (dir.x <= 0.f ? 1u : 0u) | (dir.y <= 0.f ? 2u : 0u) | (dir.z <= 0.f ? 4u : 0u);
-						t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; mode = kAtNode;
-						stk.reset();
-					}
-					else
-					{	// misses the scene bound: answer at once
-						if(kAny) a.verdict[2u * slot + which] = 0u;
-						else a.state[2 * c + slot] = make_float4(fbits(0xffffffffu), dist, 0.f, 0.f);
-					}
+					from = from + dir * r0.w;
+					dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
+					// intersectS accepts hits from 0 on, intersectTs (transpShad) from the ray's tmin_ on — measured from
+					// the origin already moved by tmin_ (kdtree_triangle.cc:936 / :1099, scene.cc isShadowed)
+					ray_tmin = a.ra.rp.transp_shad ? r0.w : 0.f;
+					++cn.shadow;
+				}
+				else
+				{
+					dist = (r1.w < 0.f) ? INFINITY : r1.w;
+					ray_tmin = r0.w;
+					++cn.closest;
+				}
+				float ea, eb;
+				tri = -1; hit = false; z = dist; bu = 0.f; bv = 0.f; done = false; p_cur = p_end = 0u;
+				const V3 inv_dir = mk(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+				if(sc.n_nodes != 0u && bound_cross(sc, from, dir, inv_dir, dist, ea, eb) && !(dist < smax(ea, 0.f)))   // :717 on entry
+				{
+					axis_col[0] = make_float2(from.x, inv_dir.x);
+					axis_col[kWave] = make_float2(from.y, inv_dir.y);
+					axis_col[2 * kWave] = make_float2(from.z, inv_dir.z);
+					dneg = (dir.x <= 0.f ? 1u : 0u) | (dir.y <= 0.f ? 2u : 0u) | (dir.z <= 0.f ? 4u : 0u);
+					t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; ws = kWalk;
+					stk.reset();
+				}
+				else
+				{	// misses the scene bound: answer at once
+					if(!kAny) a.state[2 * c + qi] = make_float4(fbits(0xffffffffu), dist, 0.f, 0.f);
 				}
 			}
 		}
-		const unsigned long long m_act = __ballot(mode != kIdle);
+		const unsigned long long m_act = __ballot(ws != kNoRay);
 		if(m_act == 0ull) { if(exhausted) break; else continue; }
-		// The kernel is bound by instruction issue, not by memory (PMC: VALU and SALU issue slots 60-70 % busy,
-		// 28 % of lanes active per VALU instruction), so what counts is how many lanes share each instruction.
-		// A lane is either walking down the tree (kAtNode) or standing at a non-empty leaf with triangles to test
-		// (kAtTri).  Each round the WAVE does one kind of work, chosen by vote: a round of triangle tests when
-		// enough lanes stand at leaves, else a burst of node steps during which lanes that reach a leaf with
-		// triangles stop and wait, and lanes that reach an empty leaf pop and walk on.  Per ray the steps and
-		// their order are kd_trace's; only the interleaving between the rays of a wave changes.
-		const unsigned long long m_tri = __ballot(mode == kAtTri);
-		const int n_tri = __popcll(m_tri), n_node = __popcll(m_act) - n_tri;
-		// end of a leaf (kdtree_triangle.cc:822-835 / :936-960): stop on a hit inside the cell, else continue at the
-		// nearest pending far child, or restart at the cell exit if the short stack lost it.  Written with selects:
-		// the wave pays for every branch some lane takes, and exec-mask bookkeeping was as many scalar
-		// instructions as the whole walk had vector ones.
+		// The kernel is bound by instruction issue, not by memory, so what counts is how many lanes share each
+		// instruction.  Each round the WAVE does one kind of work, chosen by vote: a round of triangle tests (lanes with a
+		// pending leaf) when at least as many lanes can take part in it as in node steps, else a burst of node steps (lanes
+		// whose walk stands at a node).  Per ray the steps and their order are kd_trace's.
+		const bool has_pend = p_cur < p_end;
+		const unsigned long long m_tri = __ballot(has_pend);
+		const int n_tri = __popcll(m_tri), n_node = __popcll(__ballot(ws == kWalk));
+		// what follows a leaf in the walk (kdtree_triangle.cc:822-835 / :936-960): the nearest pending far child, or a restart
+		// at the cell exit if the short stack lost it, or the end.  Written with selects: the wave pays for every branch
+		// some lane takes.  `hit && z <= tmax` on the hit known so far ends the walk (not the ray: a pending leaf is still
+		// tested); the leaf's own hits are looked at when its tests are through (see the triangle round).
 		auto leaf_end = [&]() {
 			const uint2 top = stk.col[((stk.sp - 1) & (kStack - 1)) * kWave];        // garbage when empty: unused then
 			const bool hit_here = !kAny && hit && z <= tmax;
@@ -934,15 +962,15 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 			stk.sp = emp ? 0 : stk.sp - 1;
 			stk.lo = emp ? 0 : stk.lo;
 			const bool fin = hit_here || (emp && !restart) || z < tmin;                // z < tmin: :717
-			mode = fin ? kDone : kAtNode;
+			ws = fin ? kWalkEnd : kWalk;
 		};
-		if(n_tri * kVoteNum >= n_node * kVoteDen)
+		if(n_tri * kVoteNum >= n_node * kVoteDen && n_tri > 0)
 		{
 			if(kStats) ++rounds_tri;
-			if(mode == kAtTri)
+			if(has_pend)
 			{
 				uint32_t ref_v = 0u;
-				if(k + 1u < np) ref_v = sc.refs[first + k + 1u];
+				if(p_cur + 1u < p_end) ref_v = sc.refs[p_cur + 1u];
 				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
 				float t, u, v;
 				if(kStats) ++cn.tests;
@@ -950,16 +978,30 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 				// end (a wave of 30 rays almost never leaves early as a whole), the rejections folded into one predicate
 				const bool ok = tri_test_flat(r0, r1, r2, from, dir, t, u, v);
 				const uint32_t vis = __float_as_uint(r1.w) >> 30;
-				bool found = false;
-				if(kAny) found = ok && t < dist && t >= ray_tmin && (vis == 0u || vis == 2u);
+				if(kAny)
+				{
+					const bool found = ok && t < dist && t >= ray_tmin && (vis == 0u || vis == 2u);
+					hit = hit || found; done = done || found;
+				}
 				else
 				{
 					const bool better = ok && t < z && t >= ray_tmin && (vis == 0u || vis == 1u);
 					z = better ? t : z; tri = better ? (int)ti : tri; bu = better ? u : bu; bv = better ? v : bv; hit = hit || better;
 				}
-				if(kAny && found) { hit = true; mode = kDone; }
-				else if(++k < np) ti = ref_v;
-				else leaf_end();
+				++p_cur; ti = ref_v;
+				if(p_cur >= p_end)
+				{	// the leaf is through: :822 (a hit inside its cell ends the ray), else the walk ahead stands
+					if(YAFGPU_TRACE_POSTPONE)
+					{
+						const bool ends = !kAny && hit && z <= p_tmax;
+						done = done || ends;
+						if(kStats) { if(done) { cn.interior -= spec; cn.leaves -= spec_leaves; } spec = 0u; spec_leaves = 0u; }
+						// the walk ahead was led by the hit known then; it may be over by what this leaf found (:717)
+						if(!kAny && ws != kWalkEnd && z < tmin) ws = kWalkEnd;
+						ws = (ws == kBlocked) ? kWalk : ws;      // a leaf it waited at can be noted now
+					}
+					else if(!done) leaf_end();                  // (comparison build) the lane stood at the leaf: go on from it
+				}
 			}
 		}
 		else
@@ -967,8 +1009,8 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 #pragma unroll 1
 			for(int s = 0; s < kNodeBurst; ++s)
 			{
-				if(kStats && __ballot(mode == kAtNode) != 0ull) ++rounds_node;
-				if(mode == kAtNode)
+				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
+				if(ws == kWalk)
 				{
 					const uint2 nd = sc.nodes[node];
 					if((nd.y & 3u) != 3u)
@@ -978,10 +1020,12 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 						const float2 oi = axis_col[axis * kWave];
 						const float o = oi.x;
 						const float tplane = (split - o) * oi.y;
-						const bool below = (o < split) || (o == split && ((dneg >> axis) & 1u) != 0u);
+						// (o < split) || (o == split && d <= 0), kdtree_triangle.cc:725-760, without the short-circuit branches
+						const bool dn = ((dneg >> axis) & 1u) != 0u;
+						const bool below = dn ? (o <= split) : (o < split);
 						const uint32_t left = node + 1u, right = nd.y >> 2;
 						const uint32_t near_c = below ? left : right, far_c = below ? right : left;
-						if(kStats) ++cn.interior;
+						if(kStats) { ++cn.interior; if(p_cur < p_end) ++spec; }
 						const bool near_only = !(tplane <= tmax) || tplane <= 0.f;        // plane beyond the cell or behind the origin (also NaN)
 						const bool far_only = !near_only && tplane < tmin;
 						const bool both = !near_only && !far_only;
@@ -995,19 +1039,30 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const WfArgs a)
 					}
 					else
 					{
-						np = nd.y >> 2; first = nd.x; k = 0u;
-						if(kStats) ++cn.leaves;
-						if(np == 0u) leaf_end();
-						else { ti = sc.refs[first]; mode = kAtTri; }     // in flight while the lane waits for the triangle round
+						const uint32_t np = nd.y >> 2;
+						if(np == 0u) { if(kStats) { ++cn.leaves; if(p_cur < p_end) ++spec_leaves; } leaf_end(); }
+						else if(!YAFGPU_TRACE_POSTPONE)
+						{	// (comparison build) stop at every non-empty leaf until its tests are through
+							if(p_cur < p_end) ws = kBlocked;
+							else { if(kStats) ++cn.leaves; p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax; ti = sc.refs[nd.x]; ws = kBlocked; }
+						}
+						else if(p_cur < p_end) ws = kBlocked;          // a second non-empty leaf: wait for the pending one (the node is read again then)
+						else
+						{
+							if(kStats) ++cn.leaves;
+							p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax;
+							ti = sc.refs[nd.x];                           // in flight while the lane walks on
+							leaf_end();
+						}
 					}
 				}
 			}
 		}
-		if(mode == kDone)
+		if(done || (ws == kWalkEnd && p_cur >= p_end))
 		{
-			if(kAny) a.verdict[2u * slot + which] = hit ? 1u : 0u;
-			else a.state[2 * c + slot] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
-			mode = kIdle;
+			if(kAny) answer_any(hit);
+			else a.state[2 * c + qi] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
+			ws = kNoRay; done = false; p_cur = p_end = 0u;
 		}
 	}
 	if(a.ra.counters != nullptr)
@@ -1060,7 +1115,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 		const float dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
 		Col filt;
 		const bool sh = kd_trace_ts(sc, stk, seen, from, dir, r0.w, dist, a.ra.rp.shadow_depth, filt);     // sray keeps ray.tmin_ (:998-999)
-		a.verdict[2u * slot + which] = sh ? 1u : 0u;
+		if(sh) { const uint32_t bit = 2u * slot + which; atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u)); }
 		a.shadow_filt[2u * slot + which] = f4(filt, 0.f);
 		++count;
 	}
@@ -1105,11 +1160,14 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 			if(live)
 			{
 				slot = (i < nc) ? (a.q_closest_in ? a.q_closest_in[i] : i) : a.q_resume_in[i - nc];
+				// the closest-hit answer of queue entry i (the traversal kernel wrote it at the ray's queue position)
+				float4 ans = make_float4(0.f, 0.f, 0.f, 0.f);
+				if(i < nc) ans = a.state[2 * (size_t)a.cap + i];
 				int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
 				wf_identity<true>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
 				float res[4];
 				int m = 0;
-				const int req = wf_advance(a, slot, pixel_sample, sampling_offs, ordinal, res, m);
+				const int req = wf_advance(a, slot, pixel_sample, sampling_offs, ordinal, ans, res, m);
 				if(req == kReqDone)
 				{
 					if(res[3] > 1.f) res[3] = 1.f;    // integrator_tiled.cc:459

@@ -62,6 +62,7 @@ class RenderDesc(C.Structure):
         ("shadow_bias_auto", C.c_int32), ("shadow_bias", C.c_float), ("min_raydist_auto", C.c_int32),
         ("min_raydist", C.c_float), ("aa_light_sample_multiplier", C.c_float),
         ("background", f3), ("has_background", C.c_int32), ("tile_seed_rand", C.c_uint32),
+        ("rand_srand", C.c_int32), ("rand_skip", C.c_int32),
         ("n_threads", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
         ("aa_inc_samples", C.c_int32), ("aa_threshold", C.c_float), ("aa_resampled_floor", C.c_float),
         ("aa_sample_multiplier_factor", C.c_float), ("aa_light_sample_multiplier_factor", C.c_float),
@@ -304,6 +305,8 @@ def render_desc(r):
         d.background = f3(*bg)
         d.has_background = 1
     d.tile_seed_rand = r.get("tile_seed_rand", 0)
+    d.rand_srand = r.get("rand_srand", -1)
+    d.rand_skip = r.get("rand_skip", 0)
     d.n_threads = r.get("oracle_threads", 1)
     d.shard_index = r.get("shard_index", 0)
     d.shard_count = r.get("shard_count", 1)

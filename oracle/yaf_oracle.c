@@ -246,6 +246,31 @@ static double mwc_next(mwc_t *p)
 	if(xl * yal >= ~p->c + 1) p->c++;
 	return (double)p->x * MULT_RATIO;
 }
+/* glibc's rand() / srand() (stdlib/random_r.c, the default TYPE_3 state of 31 words): third-party arithmetic the
+ * reference's tile seeds are drawn from (integrator_tiled.cc:319).  Restated from its published algorithm and pinned
+ * against this machine's libc in tests/test_oracle_golden.py. */
+typedef struct { int32_t r[34]; uint32_t *buf; int n, pos; } grand_t;
+void yor_glibc_rand(uint32_t seed, int count, int32_t *out)
+{
+	if(count <= 0) return;
+	size_t total = (size_t)count + 344;
+	uint32_t *r = (uint32_t *)malloc(total * sizeof(uint32_t));
+	if(seed == 0) seed = 1;
+	r[0] = seed;
+	for(int i = 1; i < 31; ++i)
+	{	/* 16807 * r[i-1] % 2147483647 by Schrage's method, as random_r.c does it */
+		int32_t word = (int32_t)r[i - 1];
+		long hi = word / 127773, lo = word % 127773;
+		word = (int32_t)(16807 * lo - 2836 * hi);
+		if(word < 0) word += 2147483647;
+		r[i] = (uint32_t)word;
+	}
+	for(int i = 31; i < 34; ++i) r[i] = r[i - 31];
+	for(size_t i = 34; i < total; ++i) r[i] = r[i - 31] + r[i - 3];
+	for(int k = 0; k < count; ++k) out[k] = (int32_t)(r[(size_t)k + 344] >> 1);
+	free(r);
+}
+
 void yor_mwc_seq(uint32_t seed, int count, float *out)
 {
 	mwc_t p; mwc_init(&p, seed);
@@ -2626,6 +2651,11 @@ typedef struct
 	splat_list deferred;
 	/* the pass being rendered: renderPass(samples, offset, adaptive) (integrator_tiled.cc:261-307) */
 	int pass_samples, pass_offset, pass_adaptive; float light_mult;
+	/* correlative_sample_number_[thread] (integrator_tiled.h:91): zeroed once per render, before the first pass
+	 * (integrator_tiled.cc:192-194), and carried over the passes */
+	unsigned correlative_sample_number;
+	/* per-tile rand() values for the tile seeds (integrator_tiled.cc:319), drawn in the order tiles are started; NULL: rd->tile_seed_rand for all */
+	const int *tile_rand; int *tile_rand_next;
 } worker_t;
 
 static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
@@ -2643,7 +2673,9 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 	float wt;
 	mwc_t prng;
 	/* :319 — rand() of libc is replaced by rd->tile_seed_rand; only Russian roulette consumes the stream */
-	mwc_init(&prng, (uint32_t)((int)rd->tile_seed_rand + offset * (x * ay + ax) + 123));
+	int tile_rand = (int)rd->tile_seed_rand;
+	if(wk->tile_rand) tile_rand = wk->tile_rand[__atomic_fetch_add(wk->tile_rand_next, 1, __ATOMIC_RELAXED)];
+	mwc_init(&prng, (uint32_t)(tile_rand + offset * (x * ay + ax) + 123));
 	st->prng = &prng;
 	int pass_offs = offset;
 	for(int i = ay; i < end_y; ++i)
@@ -2694,6 +2726,7 @@ static void *worker_main(void *arg)
 	st.shadow_bias = rd->shadow_bias_auto ? (float)YAF_SHADOW_BIAS : rd->shadow_bias;   /* scene.cc:825 */
 	st.ray_min_dist = rd->min_raydist_auto ? (float)MIN_RAYDIST : rd->min_raydist;      /* scene.cc:826 */
 	st.light_mult = wk->light_mult;
+	st.correlative_sample_number = wk->correlative_sample_number;
 	int n_tiles = wk->n_tiles_x * wk->n_tiles_y;
 	int shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
 	if(wk->n_threads == 1)
@@ -2715,6 +2748,7 @@ static void *worker_main(void *arg)
 		}
 	}
 	wk->cn = st.cn;
+	wk->correlative_sample_number = st.correlative_sample_number;
 	return NULL;
 }
 
@@ -2889,10 +2923,21 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 	counters_t total; memset(&total, 0, sizeof total);
 	uint64_t camera_samples = 0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
+	int *tile_rand = NULL, tile_rand_next = 0;
+	if(rd->rand_srand >= 0)
+	{	/* one rand() per tile started, over all passes, after the values the constructors consumed */
+		int total = (rd->rand_skip > 0 ? rd->rand_skip : 0) + ntx * nty * rd->aa_passes;
+		int32_t *all = (int32_t *)malloc((size_t)total * sizeof(int32_t));
+		yor_glibc_rand((uint32_t)rd->rand_srand, total, all);
+		tile_rand = (int *)malloc((size_t)(ntx * nty * rd->aa_passes) * sizeof(int));
+		for(int i = 0; i < ntx * nty * rd->aa_passes; ++i) tile_rand[i] = all[i + (rd->rand_skip > 0 ? rd->rand_skip : 0)];
+		free(all);
+	}
 	for(int i = 0; i < nthreads; ++i)
 	{
 		wk[i].s = s; wk[i].rd = rd; wk[i].film = &film; wk[i].n_tiles_x = ntx; wk[i].n_tiles_y = nty;
 		wk[i].thread_id = i; wk[i].n_threads = nthreads;
+		wk[i].tile_rand = tile_rand; wk[i].tile_rand_next = &tile_rand_next;
 	}
 #define TALLY() do { for(int i = 0; i < nthreads; ++i) { total.rays_closest += wk[i].cn.rays_closest; total.rays_shadow += wk[i].cn.rays_shadow; \
 	total.interior += wk[i].cn.interior; total.leaves += wk[i].cn.leaves; total.tests += wk[i].cn.tests; camera_samples += wk[i].camera_samples; wk[i].camera_samples = 0; } } while(0)
@@ -2946,7 +2991,7 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 		stats->build_seconds = s->build_seconds;
 		stats->render_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 	}
-	free(wk); free(th);
+	free(wk); free(th); free(tile_rand);
 	return 0;
 }
 

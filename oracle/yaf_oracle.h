@@ -128,7 +128,11 @@ typedef struct yor_render_desc
 	float aa_light_sample_multiplier; /* 1 for a single pass */
 	float background[3];       /* constant background colour*power; used on primary misses */
 	int32_t has_background;
-	uint32_t tile_seed_rand;   /* stands for libc rand() of integrator_tiled.cc:319; only used when RR is on */
+	uint32_t tile_seed_rand;   /* stands for libc rand() of integrator_tiled.cc:319 (every tile the same value); only used when RR is on */
+	/* ... or the libc stream itself (glibc's rand(), restated: see yor_glibc_rand): srand(rand_srand) as the last Material /
+	 * ObjectGeometric constructor left it (material.cc:56, object_geom.cc:42), rand_skip values consumed since (the
+	 * constructor's colour loop), then one value per tile started, over all passes.  rand_srand < 0: tile_seed_rand. */
+	int32_t rand_srand, rand_skip;
 	int32_t n_threads;         /* oracle worker threads (1 = reference's single-thread linear order) */
 	/* tile subset for sharded renders: tile t is rendered iff (t % shard_count) == shard_index */
 	int32_t shard_index, shard_count;
@@ -191,6 +195,8 @@ float yor_fcos(float x);
 float yor_fexp2(float x);
 float yor_flog2(float x);
 float yor_fpow(float a, float b);
+/* glibc rand() after srand(seed) (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31], output >> 1): out[k] = k-th value */
+void yor_glibc_rand(uint32_t seed, int count, int32_t *out);
 float yor_fsqrt(float x);
 float yor_facos(float x);
 float yor_ri_vdc(uint32_t bits, uint32_t r);

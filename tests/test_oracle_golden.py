@@ -355,3 +355,21 @@ def test_whole_path_against_the_references_expected_png():
     assert st["within_2"] >= 0.995 * st["pixels_compared"], st
     assert st["within_1"] >= 0.96 * st["pixels_compared"], st
     assert st["exact"] >= 0.80 * st["pixels_compared"], st
+
+
+def test_glibc_rand_restatement_against_this_machines_libc():
+    """The tile seeds of the Russian-roulette streams come from libc's rand() (integrator_tiled.cc:319), whose state the
+    last Material / ObjectGeometric constructor set with srand() (material.cc:56, object_geom.cc:42).  glibc is a third
+    party: its generator is restated (oracle yor_glibc_rand, host side libyafaray_amd) and pinned here against the
+    libc this process runs on."""
+    L = po.lib()
+    L.yor_glibc_rand.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_int32)]
+    try:
+        libc = C.CDLL("libc.so.6")
+    except OSError:
+        pytest.skip("no glibc on this machine")
+    for seed in (0, 1, 2, 3, 9, 74, 12345, 2 ** 31 - 1, 2 ** 31 + 5):
+        out = (C.c_int32 * 400)()
+        L.yor_glibc_rand(seed, 400, out)
+        libc.srand(C.c_uint(seed))
+        assert list(out) == [libc.rand() for _ in range(400)], f"seed {seed}"

@@ -123,6 +123,14 @@ yafaray_bool_t yafaray_getFilm(yafaray_interface_t *yi, float *film, int width, 
 yafaray_bool_t yafaray_getRenderStats(yafaray_interface_t *yi, yafaray_render_stats_t *stats);
 /* pixel-tile sharding: must be set before render; tile t belongs to shard t % count */
 void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count);
+/* Exact replay of the reference's serial render state (on by default): the per-tile Random that Russian roulette draws from
+ * (integrator_tiled.cc:319, seeded from libc rand() as the last Material / ObjectGeometric constructor left it;
+ * integrator_path_tracer.cc:282-288) and the estimateOneDirectLight counter (integrator_montecarlo.cc:62-76), both as a
+ * single-threaded render with tiles_order = linear consumes them.  Costs a record pass of closest-hit rays per chunk when a
+ * render consumes either (RR active, or more than one light).  Off: per-sample streams — the same estimator, other pixels. */
+void yafaray_setSerialReplay(yafaray_interface_t *yi, yafaray_bool_t on);
+/* srand() seed and values consumed since, of the libc stream the next render's tile seeds continue (-1: nothing created yet) */
+void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip);
 /* Two-step render for drivers that own device memory and streams (bench.py, RCCL reduce):
  * prepare = setupScene + Scene::update (tree build, upload); renderPass launches one pass
  * asynchronously on `stream` into caller-owned device memory d_planes (yafgpu_planes_bytes). */

@@ -136,6 +136,13 @@ typedef struct yafgpu_render_params
 	int32_t shadow_depth;          /* s_depth_: more distinct transparent surfaces than this along a shadow ray block it; at most 8 */
 	int32_t raydepth;              /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791): levels of perfect specular
 	                                  reflection / filtered transmission followed from a camera hit; at most 7 */
+	int32_t serial_replay;         /* 1: replay the reference's serial state as its single-threaded render consumes it — the per-tile
+	                                  MWC stream of Russian roulette (integrator_tiled.cc:319, integrator_path_tracer.cc:282-288) and
+	                                  the estimateOneDirectLight counter (integrator_montecarlo.cc:62-76) — with a record pass, a scan
+	                                  in the reference's sample order and the final pass (yafgpu_wavefront.h, WfArgs::replay).
+	                                  0: per-sample streams (same distribution, not the reference's pixels). */
+	const int32_t *tile_rand;      /* HOST pointer, one value per tile of the frame (row-major tile order): the libc rand() value
+	                                  TiledIntegrator::renderTile seeds that tile's Random with in THIS pass; NULL = 0 for all */
 	const uint8_t *resample_mask;  /* HOST pointer, width*height bytes, row-major in window coordinates: the pixels that
 	                                  get samples in this pass (ImageFilm::doMoreSamples, imagefilm.cc:917-920); NULL = all */
 } yafgpu_render_params;
@@ -150,6 +157,10 @@ typedef struct yafgpu_aa_schedule
 	int32_t dark_detection_type;   /* 0 none, 1 linear, 2 curve */
 	float dark_threshold_factor;
 	int32_t variance_edge_size, variance_pixels;
+	/* libc state behind the tile seeds (used with yafgpu_render_params::serial_replay): srand(rand_srand) by the last
+	   Material / ObjectGeometric constructor (material.cc:56, object_geom.cc:42), rand_skip values consumed by its colour
+	   loop since; then one rand() per tile per pass that runs.  rand_srand < 0: every tile draws 0. */
+	int32_t rand_srand, rand_skip;
 } yafgpu_aa_schedule;
 
 typedef struct yafgpu_counters   /* device atomics, accumulated per launch */
@@ -206,6 +217,9 @@ int yafgpu_trace_shadow(yafgpu_scene_t *scene, int32_t n, const float *rays, int
  * stream; the pass then synchronises after each launch, so it is a measurement mode, not a fast path).
  * slots: 0 closest-hit traversal, 1 any-hit traversal, 2 shading, 3 other (ray generation, film). */
 int yafgpu_set_profiling(yafgpu_scene_t *scene, int32_t enable);
+/* glibc's rand() after srand(seed) (TYPE_3 additive feedback generator, restated; pinned against libc in the tests):
+ * out[k] = the k-th value.  The tile seeds of a render are drawn from it (integrator_tiled.cc:319). */
+void yafgpu_glibc_rand(uint32_t seed, int32_t count, int32_t *out);
 /* Scene::abort (scene.cc:75-89): the render entry points poll *flag between wavefront chunks and between passes and
  * return -30 ("aborted") once it is non-zero.  The flag stays owned by the caller; NULL detaches it. */
 int yafgpu_scene_set_abort_flag(yafgpu_scene_t *scene, const volatile int32_t *flag);

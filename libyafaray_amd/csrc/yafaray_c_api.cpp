@@ -26,8 +26,9 @@ constexpr double kPi = 3.14159265358979323846;
 // ---- ParamMap (include/common/param.h:37-107): strictly typed values, as Parameter::getVal (param.cc:49-53)
 struct Param
 {
-	enum Type { None, Int, Bool, Float, String, Point, Color } type = None;
+	enum Type { None, Int, Bool, Float, String, Point, Color, Matrix } type = None;
 	int i = 0; bool b = false; double f = 0; std::string s; float v[4] = {0, 0, 0, 0};
+	float m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // Matrix4, row major
 };
 struct ParamMap
 {
@@ -49,6 +50,12 @@ struct Mesh
 	std::vector<int> tri_mat;
 	bool normals_exported = false, smooth = false, visible = true, base = false;
 	std::vector<float> smooth_normals; // per triangle corner, filled by smoothMesh
+	// texture coordinates as the exporter gives them (TriangleObject::points_ interleaves orco, uv_values_ / uv_offsets_;
+	// object_geom/object_geom_mesh.cc): kept for the shader nodes; untextured shading never reads them
+	bool has_orco = false, has_uv = false;
+	std::vector<float> orco;          // xyz per vertex
+	std::vector<float> uv;            // u, v per addUv
+	std::vector<int> tri_uv;          // uv_a, uv_b, uv_c per triangle (when has_uv)
 };
 
 struct IntegratorCfg
@@ -99,13 +106,42 @@ struct yafaray_interface
 	int shard_index = 0, shard_count = 1;
 	std::vector<float> film;
 	yafaray_render_stats_t stats{};
+	// libc state behind the tile seeds of the Russian-roulette streams (integrator_tiled.cc:319): the reference's last
+	// Material / ObjectGeometric constructor calls srand(its running index) and then draws a random colour
+	// (material.cc:53-66, object_geom.cc:39-51); whichever object was made last leaves the state rand() continues from
+	uint32_t last_srand = 0u; bool have_srand = false;
+	bool serial_replay = true;           // yafaray_setSerialReplay
+	std::vector<int32_t> tile_rand0;     // the first pass's value per tile (yafaray_renderPassDevice)
 	volatile int32_t abort_flag = 0;     // Scene::abort: set by yafaray_abort (any thread), polled by the device side between chunks and passes
 	std::string color_space = "Raw_Manual_Gamma"; float gamma = 1.f;
+	std::string color_space2 = "Raw_Manual_Gamma"; float gamma2 = 1.f;
+	// Interface::setInputColorSpace (interface.cc:292-301): how paramsSetColor reads its arguments; the ctor's default is
+	// RawManualGamma with gamma 1 (interface.cc:73), i.e. values are taken as linear
+	int input_color_space = 3; float input_gamma = 1.f;       // 0 sRGB, 1 XYZ (D65), 2 LinearRGB, 3 RawManualGamma
+	yafaray_output_t output2{}; bool has_output2 = false;
+	bool interactive = false; std::string badge_position = "none";
 };
 
 namespace {
 
 bool fail(yafaray_interface *yi, const std::string &m) { yi->err = m; return false; }
+
+// Material::material_index_auto_ / ObjectGeometric::object_index_auto_ (common/material.cc:33, object_geom.cc:29): static,
+// process-wide, never reset — like the reference, one process is assumed to build its scenes one after the other
+unsigned int g_material_index_auto = 0u, g_object_index_auto = 0u;
+void note_srand(yafaray_interface *yi, unsigned int seed) { yi->last_srand = seed; yi->have_srand = true; }
+// values the constructor's colour loop consumed after its srand(): do { r, g, b = rand() % 8 / 8 } while(r + g + b < 0.5)
+int colour_loop_draws(uint32_t seed)
+{
+	int32_t v[3 * 64];
+	yafgpu_glibc_rand(seed, 3 * 64, v);
+	for(int k = 0; k < 64; ++k)
+	{
+		const float r = (float)(v[3 * k] % 8) / 8.f, g = (float)(v[3 * k + 1] % 8) / 8.f, b = (float)(v[3 * k + 2] % 8) / 8.f;
+		if(!(r + g + b < 0.5f)) return 3 * (k + 1);
+	}
+	return 3 * 64;
+}
 
 inline void cross3(const float a[3], const float b[3], float o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
 inline void normalize3(float v[3]) // Vec3::normalize, vector.h:227-238
@@ -422,11 +458,11 @@ yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, in
 {
 	if(yi->state != 1) return fail(yi, "startTriMesh: wrong state");
 	if((type & 0xFF) != 0) return fail(yi, "startTriMesh: only TRIM meshes (type 0) are supported");
-	if(has_orco) return fail(yi, "startTriMesh: orco coordinates are not supported");
-	(void)has_uv; // UVs are accepted and ignored: no textures on the GPU path
+	note_srand(yi, ++g_object_index_auto);          // ObjectGeometric::ObjectGeometric, object_geom.cc:39-43
 	Mesh &m = yi->meshes[id];
 	m = Mesh();
 	m.visible = !(type & 0x0100); m.base = (type & 0x0200) != 0;
+	m.has_orco = has_orco != 0; m.has_uv = has_uv != 0;
 	m.points.reserve((size_t)std::max(vertices, 0) * 3); m.tri.reserve((size_t)std::max(triangles, 0) * 3); m.tri_mat.reserve((size_t)std::max(triangles, 0));
 	yi->cur = &m; yi->last = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
 	return 1;
@@ -645,6 +681,7 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
 	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }
 	if(!ok) return nullptr;
+	note_srand(yi, ++g_material_index_auto);        // Material::Material, material.cc:53-57
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();
 	yi->material_order.push_back(raw);
@@ -749,6 +786,12 @@ void yafaray_clearAll(yafaray_interface_t *yi)
 	yi->state = -1; yi->prepared = false; yi->geometry_changed = true; yi->film.clear();
 }
 
+void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip)
+{
+	if(srand_seed) *srand_seed = yi->have_srand ? (int)(yi->last_srand & 0x7fffffffu) : -1;
+	if(skip) *skip = yi->have_srand ? colour_loop_draws(yi->last_srand) : 0;
+}
+void yafaray_setSerialReplay(yafaray_interface_t *yi, yafaray_bool_t on) { yi->serial_replay = on != 0; yi->prepared = false; }
 void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count) { yi->shard_index = shard_index; yi->shard_count = std::max(1, shard_count); }
 
 // RenderEnvironment::setupScene (environment.cc:679-813) + createImageFilm (:456-584) + Scene::update (scene.cc:784-894)
@@ -801,6 +844,8 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 		aa.dark_detection_type = dark == "linear" ? 1 : (dark == "curve" ? 2 : 0);
 		aa.dark_threshold_factor = dark_factor; aa.variance_edge_size = var_edge; aa.variance_pixels = var_pix;
 		if(aa_passes < 1) return fail(yi, "render: AA_passes must be at least 1");
+		aa.rand_srand = -1; aa.rand_skip = 0;
+		if(yi->have_srand) { aa.rand_srand = (int32_t)(yi->last_srand & 0x7fffffffu); aa.rand_skip = colour_loop_draws(yi->last_srand); }
 	}
 	int filter_type = YAFGPU_FILTER_BOX;      // RenderEnvironment::createImageFilm, environment.cc:537-541: unknown names default to box
 	if(filter == "mitchell") filter_type = YAFGPU_FILTER_MITCHELL;
@@ -824,6 +869,17 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.transp_shad = ic.transp_shad ? 1 : 0; rp.shadow_depth = ic.shadow_depth;
 	if(bg) { rp.has_background = 1; for(int k = 0; k < 3; ++k) rp.background[k] = bg->color[k]; }
 	rp.shard_index = yi->shard_index; rp.shard_count = yi->shard_count;
+	rp.serial_replay = yi->serial_replay ? 1 : 0;
+	{	// the first pass's rand() per tile, for callers that run single passes themselves (yafaray_renderPassDevice)
+		const int nt = ((width + tile_size - 1) / std::max(tile_size, 1)) * ((height + tile_size - 1) / std::max(tile_size, 1));
+		yi->tile_rand0.assign((size_t)std::max(nt, 0), 0);
+		if(yi->aa.rand_srand >= 0 && nt > 0)
+		{
+			std::vector<int32_t> v((size_t)yi->aa.rand_skip + (size_t)nt);
+			yafgpu_glibc_rand((uint32_t)yi->aa.rand_srand, (int32_t)v.size(), v.data());
+			std::copy(v.begin() + yi->aa.rand_skip, v.end(), yi->tile_rand0.begin());
+		}
+	}
 
 	// Scene::update: flatten visible non-base meshes in object-id order (scene.cc:797-817)
 	if(yi->state != 0) return fail(yi, "render: scene is not in the ready state (missing endGeometry?)");
@@ -888,6 +944,7 @@ yafaray_bool_t yafaray_renderPassDevice(yafaray_interface_t *yi, float *d_planes
 {
 	if(!yi->prepared) return fail(yi, "renderPassDevice: call prepareRender first");
 	yi->rp.shard_index = yi->shard_index; yi->rp.shard_count = yi->shard_count;
+	yi->rp.tile_rand = yi->tile_rand0.empty() ? nullptr : yi->tile_rand0.data();
 	if(yafgpu_render_tiles(yi->gpu, &yi->rp, d_planes, (yafgpu_counters *)d_counters, stream)) return fail(yi, std::string("render: ") + yafgpu_last_error());
 	return 1;
 }

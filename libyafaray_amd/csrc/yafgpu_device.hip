@@ -1061,6 +1061,9 @@ struct yafgpu_scene
 	bool has_volumetric = false;
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
+	// serial-state replay tables (WfArgs::replay)
+	uint32_t *rp_flags = nullptr; float *rp_p = nullptr; uint8_t *rp_kill = nullptr, *rp_calls = nullptr; uint32_t *rp_base = nullptr; size_t rp_ents = 0; uint32_t rp_prob = 0;
+	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
 	const volatile int32_t *abort_flag = nullptr;      // polled between chunks and passes (yafgpu_scene_set_abort_flag)
 	bool aborted() const { return abort_flag && *abort_flag != 0; }
 	bool profiling = false;
@@ -1303,6 +1306,8 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->ev_fork) (void)hipEventDestroy(s->ev_fork);
 	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
+	for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base, (void *)s->rp_seg_begin,
+	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_counter}) if(q) (void)hipFree(q);
 	delete s;
 }
 
@@ -1458,17 +1463,21 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	pp.assign(1, 0u);
 	for(const int4 &r : s->h_tiles) pp.push_back(pp.back() + (uint32_t)(r.z * r.w));
 	// a resample mask (adaptive pass): the pixels of this shard's tiles that are flagged, in tile order
-	std::vector<uint32_t> listed;
+	std::vector<uint32_t> listed, listed_prefix(1, 0u);
 	const bool masked = rp.resample_mask != nullptr;
 	if(masked)
 	{
 		for(const int4 &r : s->h_tiles)
+		{
 			for(int y = r.y; y < r.y + r.w; ++y)
 				for(int x = r.x; x < r.x + r.z; ++x)
 					if(rp.resample_mask[(size_t)(y - rp.ystart) * (size_t)rp.width + (size_t)(x - rp.xstart)]) listed.push_back((uint32_t)x | ((uint32_t)y << 16));
+			listed_prefix.push_back((uint32_t)listed.size());
+		}
 		if(listed.empty()) return 0;
 	}
-	const uint32_t n_pixels_total = masked ? (uint32_t)listed.size() : pp.back();
+	const std::vector<uint32_t> &tile_px = masked ? listed_prefix : pp;      // pixels of the pass before every tile of the shard
+	const uint32_t n_pixels_total = tile_px.back();
 	if(pp.size() > s->pix_prefix_cap)
 	{
 		HIP_OK(hipStreamSynchronize(stream));
@@ -1481,11 +1490,46 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	HIP_OK(hipMemcpyAsync(s->d_pix_prefix, pp.data(), pp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 	uint32_t max_paths = kWfMaxPaths;
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
-	const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
-	const uint32_t cap = chunk_pixels * spp;
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
 	const int frames = (s->has_specular && rp.raydepth > 0) ? rp.raydepth : 0;
 	if(frames > 7) return fail(-17, "raydepth > 7 with mirror / transparent materials: the device path keeps at most 7 recursion frames per sample");
+	// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
+	// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
+	// (more than one light).  Not with recursiveRaytrace frames (a sample's events are then a tree, not a list: the
+	// per-sample streams stand in), and the light counter only on one GPU (a tile's starting value is the sum
+	// over all tiles before it, other ranks' included).
+	const bool path = rp.integrator == YAFGPU_INTEGRATOR_PATH;
+	const bool need_rr = path && rp.bounces - 1 > rp.rr_min_bounces;
+	const bool need_lc = path && s->n_lights > 1;
+	bool replay = rp.serial_replay != 0 && frames == 0 && (need_rr || need_lc);
+	if(const char *e = std::getenv("YAFGPU_SERIAL_REPLAY")) if(std::atoi(e) == 0) replay = false;
+	const bool replay_lights = replay && need_lc && rp.shard_count == 1;
+	if(replay && !need_rr && !replay_lights) replay = false;
+	const uint32_t n_ps = (uint32_t)std::max(rp.path_samples, 1), n_prob = (uint32_t)std::max(rp.bounces - 1, 1);
+	// chunks: runs of pixels whose paths are in flight together.  With the replay a chunk is a run of whole tiles (a tile's
+	// stream is walked in one go); without it any run of at most max_paths / spp pixels.
+	struct Chunk { uint32_t pixel_begin, n_pixels, tile_begin, tile_end; };
+	std::vector<Chunk> chunks;
+	if(replay)
+	{
+		const uint32_t n_t = (uint32_t)s->h_tiles.size();
+		for(uint32_t t0 = 0; t0 < n_t;)
+		{
+			uint32_t t1 = t0 + 1;
+			while(t1 < n_t && (uint64_t)(tile_px[t1 + 1] - tile_px[t0]) * spp <= max_paths) ++t1;
+			chunks.push_back({tile_px[t0], tile_px[t1] - tile_px[t0], t0, t1});
+			t0 = t1;
+		}
+	}
+	else
+	{
+		const uint32_t chunk_pixels = std::max(1u, std::min(n_pixels_total, std::max(1u, max_paths / spp)));
+		for(uint32_t pb = 0; pb < n_pixels_total; pb += chunk_pixels) chunks.push_back({pb, std::min(chunk_pixels, n_pixels_total - pb), 0u, 0u});
+	}
+	uint32_t cap_pixels = 1u;
+	for(const Chunk &ch : chunks) cap_pixels = std::max(cap_pixels, ch.n_pixels);
+	if((uint64_t)cap_pixels * spp > (1ull << 27)) return fail(-23, "one tile's samples exceed the 2^27 paths a wavefront chunk can hold: reduce tile_size or the samples per pass");
+	const uint32_t cap = cap_pixels * spp;
 	if(cap > s->wf_cap || frames > s->wf_frames)
 	{
 		HIP_OK(hipStreamSynchronize(stream));
@@ -1503,6 +1547,36 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->wf_verdict, ((size_t)2 * cap + 31) / 32 * sizeof(uint32_t) + 64));      // one bit per shadow ray
 		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
+	}
+	if(replay)
+	{	// event tables of the record pass, per path sample; segment tables per tile
+		const size_t ents = (size_t)s->wf_cap * n_ps;
+		if(ents > s->rp_ents || n_prob > s->rp_prob)
+		{
+			HIP_OK(hipStreamSynchronize(stream));
+			for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base}) if(q) (void)hipFree(q);
+			s->rp_flags = nullptr; s->rp_p = nullptr; s->rp_kill = nullptr; s->rp_calls = nullptr; s->rp_base = nullptr; s->rp_ents = 0;
+			HIP_OK(hipMalloc((void **)&s->rp_flags, ents * sizeof(uint32_t)));
+			HIP_OK(hipMalloc((void **)&s->rp_p, ents * n_prob * sizeof(float)));
+			HIP_OK(hipMalloc((void **)&s->rp_kill, ents));
+			HIP_OK(hipMalloc((void **)&s->rp_calls, ents));
+			HIP_OK(hipMalloc((void **)&s->rp_base, (size_t)s->wf_cap * sizeof(uint32_t)));
+			s->rp_ents = ents; s->rp_prob = n_prob;
+		}
+		const size_t segs = s->h_tiles.size() + 1;
+		if(segs > s->rp_segs)
+		{
+			HIP_OK(hipStreamSynchronize(stream));
+			for(void *q : {(void *)s->rp_seg_begin, (void *)s->rp_seg_seed, (void *)s->rp_seg_total}) if(q) (void)hipFree(q);
+			s->rp_seg_begin = nullptr; s->rp_seg_seed = nullptr; s->rp_seg_total = nullptr; s->rp_segs = 0;
+			HIP_OK(hipMalloc((void **)&s->rp_seg_begin, segs * sizeof(uint32_t)));
+			HIP_OK(hipMalloc((void **)&s->rp_seg_seed, segs * sizeof(uint32_t)));
+			HIP_OK(hipMalloc((void **)&s->rp_seg_total, segs * sizeof(uint32_t)));
+			s->rp_segs = segs;
+		}
+		if(!s->rp_counter) HIP_OK(hipMalloc((void **)&s->rp_counter, sizeof(uint32_t)));
+		// correlative_sample_number_ is zeroed once per render, before its first pass (integrator_tiled.cc:192-194)
+		if(!rp.accumulate) HIP_OK(hipMemsetAsync(s->rp_counter, 0, sizeof(uint32_t), stream));
 	}
 	// transparent shadows only cost anything when a material can be transparent to a shadow ray
 	const bool transp = rp.transp_shad != 0 && s->has_transparent;
@@ -1522,7 +1596,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	const int g_trace_c = stats ? wf_grid((const void *)wf_trace<false, true>, cus) : wf_grid((const void *)wf_trace<false, false>, cus);
 	const int g_trace_s = stats ? wf_grid((const void *)wf_trace<true, true>, cus) : wf_grid((const void *)wf_trace<true, false>, cus);
 	const ShadeVariant *shade_variant = pick_shade_variant(s, frames);
-	if(std::getenv("YAFGPU_VERBOSE")) std::fprintf(stderr, "[yafgpu] shading kernel: %s (materials 0x%x, frames %d)\n", shade_variant ? shade_variant->name : "general", s->mat_mask, frames);
+	if(std::getenv("YAFGPU_VERBOSE")) std::fprintf(stderr, "[yafgpu] shading kernel: %s (materials 0x%x, frames %d), serial replay: %s\n", shade_variant ? shade_variant->name : "general", s->mat_mask, frames,
+	                                               replay ? (replay_lights ? (need_rr ? "roulette + light counter" : "light counter") : "roulette") : "off");
 	const int g_shade = wf_grid(shade_variant ? shade_variant->kernel() : (const void *)wf_shade, cus);
 	// upper bound of kd-tree queries per path = iterations needed (every path advances one query per iteration)
 	int r_all = 0, r_one = 0;
@@ -1535,6 +1610,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	int iters = 1 + r_all;
 	if(rp.integrator == YAFGPU_INTEGRATOR_PATH)
 		iters += std::max(1, rp.path_samples) * ((1 + r_one) + std::max(0, rp.bounces - 1) * (1 + r_one));
+	// a record pass asks for closest hits only: the camera ray + per path sample one query per segment
+	const int iters_record = 1 + (path ? std::max(1, rp.path_samples) * std::max(1, rp.bounces) : 0);
 	// opt-in (YAFGPU_OVERLAP=1): +2-4 % on the bench scenes, but per-kernel durations then overlap in a profiler trace, so
 	// the default keeps one kernel on the GPU at a time and the roofline numbers comparable with rocprofv3's
 	const bool overlap = std::getenv("YAFGPU_OVERLAP") != nullptr;
@@ -1560,77 +1637,124 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		}
 		return 0;
 	};
-	for(uint32_t pb = 0; pb < n_pixels_total; pb += chunk_pixels)
+	std::vector<uint32_t> seg_begin, seg_seed;
+	for(const Chunk &ch : chunks)
 	{
 		if(s->aborted()) return fail(-30, "aborted");
 		WfArgs a{};
 		a.ra = ra;
 		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results; a.frames = frames;
-		a.pixel_begin = pb; a.n_pixels = std::min(chunk_pixels, n_pixels_total - pb); a.n_paths = a.n_pixels * spp;
+		a.pixel_begin = ch.pixel_begin; a.n_pixels = ch.n_pixels; a.n_paths = a.n_pixels * spp;
 		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy; a.pix_listed = masked ? 1 : 0;
-		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + pb, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		a.ev_flags = s->rp_flags; a.ev_p = s->rp_p; a.ev_kill = s->rp_kill; a.ev_calls = s->rp_calls; a.lc_base = s->rp_base;
+		a.replay_lights = replay_lights ? 1 : 0;
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
 		uint32_t *cnt[2] = {s->wf_counts, s->wf_counts + 32};
 		a.verdict = s->wf_verdict; a.shadow_filt = transp ? s->wf_filt : nullptr;
-		a.cnt_in = cnt[0]; a.cnt_out = cnt[1];
-		a.q_closest_in = nullptr; a.q_shadow_in = qset[0][1]; a.q_resume_in = qset[0][2];
-		a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
 		const uint32_t g_gen = std::min<uint32_t>((a.n_paths + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		int rc;
-		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
-		int cur = 0;
-		// Without recursion the number of queries per path is bounded a priori (iters) and the loop never asks the
-		// device anything.  With recursiveRaytrace a sample may visit up to 2^raydepth levels, so past that bound the
-		// loop runs on while any queue is non-empty (one 20-byte read-back per iteration).
-		const int iter_cap = iters * (frames > 0 ? (1 << (frames + 1)) : 1);
-		for(int it = 0; it < iter_cap; ++it)
+		// one run of the path program over the chunk: generate, then iterations of {closest-hit, any-hit, shade} until
+		// every path has ended.  Without recursion the number of queries per path is bounded a priori (n_iters) and the
+		// loop never asks the device anything.  With recursiveRaytrace a sample may visit up to 2^raydepth levels, so past
+		// that bound the loop runs on while any queue is non-empty (one 20-byte read-back per iteration).
+		auto run = [&](int n_iters, bool record) -> int {
+			a.cnt_in = cnt[0]; a.cnt_out = cnt[1];
+			a.q_closest_in = nullptr; a.q_shadow_in = qset[0][1]; a.q_resume_in = qset[0][2];
+			a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
+			if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
+			int cur = 0;
+			const int iter_cap = n_iters * (frames > 0 ? (1 << (frames + 1)) : 1);
+			for(int it = 0; it < iter_cap; ++it)
+			{
+				if(frames > 0 && it >= n_iters)
+				{
+					uint32_t pending[5];
+					HIP_OK(hipMemcpyAsync(pending, a.cnt_in, sizeof pending, hipMemcpyDeviceToHost, stream));
+					HIP_OK(hipStreamSynchronize(stream));
+					if(pending[0] == 0u && pending[1] == 0u && pending[4] == 0u) break;
+				}
+				else if(frames == 0 && it >= n_iters) break;
+				HIP_OK(hipMemsetAsync(a.cnt_out, 0, 8 * sizeof(uint32_t), stream));
+				const bool overlap_now = overlap && it > 0 && !s->profiling && !record;
+				if(overlap_now)
+				{	// fork point: everything enqueued so far (the previous shade, the counter reset) precedes both launches
+					HIP_OK(hipEventRecord(s->ev_fork, stream));
+					HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
+				}
+				if((rc = timed(0, [&] {
+					if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
+					else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
+				// The two traversal launches of an iteration are independent (each drains its own queue, writes its own
+				// answers), and a persistent kernel's tail leaves CUs idle: outside profiling the any-hit launch goes to a
+				// side stream so that its waves fill the closest-hit launch's tail (and vice versa).
+				const bool fork = overlap_now;
+				hipStream_t any_stream = fork ? s->side_stream : stream;
+				if(it > 0 && !record)      // (a record pass has no shadow rays)
+				{
+					HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * s->wf_cap + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
+					if((rc = timed(1, [&] {
+						if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
+						else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);
+						else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a); }))) return rc;
+				}
+				if(fork)
+				{
+					HIP_OK(hipEventRecord(s->ev_join, s->side_stream));
+					HIP_OK(hipStreamWaitEvent(stream, s->ev_join, 0));
+				}
+				int variant_rc = 0;
+				if((rc = timed(2, [&] {
+					if(shade_variant) variant_rc = shade_variant->launch(&a, sizeof a, g_shade, stream);
+					else hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
+				if(variant_rc) return fail(-21, "shading kernel variant and main unit disagree on the argument layout");
+				// swap queues: what shade produced is the next iteration's input
+				cur ^= 1;
+				a.cnt_in = cnt[cur]; a.cnt_out = cnt[cur ^ 1];
+				a.q_closest_in = qset[cur][0]; a.q_shadow_in = qset[cur][1]; a.q_resume_in = qset[cur][2];
+				a.q_closest_out = qset[cur ^ 1][0]; a.q_shadow_out = qset[cur ^ 1][1]; a.q_resume_out = qset[cur ^ 1][2];
+			}
+			return 0;
+		};
+		if(replay)
 		{
-			if(frames > 0 && it >= iters)
+			// record pass: the paths alone (no light estimates, no roulette kills), rays not counted
+			a.replay = 1;
+			yafgpu_counters *const keep = a.ra.counters;
+			a.ra.counters = nullptr;
+			HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * n_ps * sizeof(uint32_t), stream));
+			if((rc = run(iters_record, true))) return rc;
+			a.ra.counters = keep;
+			// the tiles of the chunk as segments, each with the seed of its Random:
+			// rand() + offset * (resx * tile.y + tile.x) + 123 (integrator_tiled.cc:319), offset = pass offset + base sampling offset (:203,263)
+			const uint32_t n_seg = ch.tile_end - ch.tile_begin;
+			seg_begin.assign(n_seg + 1, 0u); seg_seed.assign(n_seg + 1, 0u);
+			const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size;
+			const uint32_t offset = rp.pass_offset + rp.base_sampling_offset;
+			for(uint32_t k = 0; k <= n_seg; ++k) seg_begin[k] = tile_px[ch.tile_begin + k] - ch.pixel_begin;
+			for(uint32_t k = 0; k < n_seg; ++k)
 			{
-				uint32_t pending[5];
-				HIP_OK(hipMemcpyAsync(pending, a.cnt_in, sizeof pending, hipMemcpyDeviceToHost, stream));
-				HIP_OK(hipStreamSynchronize(stream));
-				if(pending[0] == 0u && pending[1] == 0u && pending[4] == 0u) break;
+				const int4 &r = s->h_tiles[ch.tile_begin + k];
+				const int t_global = ((r.y - rp.ystart) / rp.tile_size) * ntx + (r.x - rp.xstart) / rp.tile_size;
+				const uint32_t rnd = rp.tile_rand ? (uint32_t)rp.tile_rand[t_global] : 0u;
+				seg_seed[k] = rnd + offset * ((uint32_t)s->dev.cam.resx * (uint32_t)r.y + (uint32_t)r.x) + 123u;
 			}
-			else if(frames == 0 && it >= iters) break;
-			HIP_OK(hipMemsetAsync(a.cnt_out, 0, 8 * sizeof(uint32_t), stream));
-			const bool overlap_now = overlap && it > 0 && !s->profiling;
-			if(overlap_now)
-			{	// fork point: everything enqueued so far (the previous shade, the counter reset) precedes both launches
-				HIP_OK(hipEventRecord(s->ev_fork, stream));
-				HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
-			}
-			if((rc = timed(0, [&] {
-				if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
-				else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
-			// The two traversal launches of an iteration are independent (each drains its own queue, writes its own
-			// answers), and a persistent kernel's tail leaves CUs idle: outside profiling the any-hit launch goes to a
-			// side stream so that its waves fill the closest-hit launch's tail (and vice versa).
-			const bool fork = overlap_now;
-			hipStream_t any_stream = fork ? s->side_stream : stream;
-			if(it > 0) HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * s->wf_cap + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
-			if(it > 0 && (rc = timed(1, [&] {
-				if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
-				else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);
-				else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a); }))) return rc;
-			if(fork)
-			{
-				HIP_OK(hipEventRecord(s->ev_join, s->side_stream));
-				HIP_OK(hipStreamWaitEvent(stream, s->ev_join, 0));
-			}
-			int variant_rc = 0;
-			if((rc = timed(2, [&] {
-				if(shade_variant) variant_rc = shade_variant->launch(&a, sizeof a, g_shade, stream);
-				else hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
-			if(variant_rc) return fail(-21, "shading kernel variant and main unit disagree on the argument layout");
-			// swap queues: what shade produced is the next iteration's input
-			cur ^= 1;
-			a.cnt_in = cnt[cur]; a.cnt_out = cnt[cur ^ 1];
-			a.q_closest_in = qset[cur][0]; a.q_shadow_in = qset[cur][1]; a.q_resume_in = qset[cur][2];
-			a.q_closest_out = qset[cur ^ 1][0]; a.q_shadow_out = qset[cur ^ 1][1]; a.q_resume_out = qset[cur ^ 1][2];
+			HIP_OK(hipMemcpyAsync(s->rp_seg_begin, seg_begin.data(), (n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			HIP_OK(hipMemcpyAsync(s->rp_seg_seed, seg_seed.data(), (n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			ReplayArgs r{};
+			r.seg_begin = s->rp_seg_begin; r.seg_seed = s->rp_seg_seed; r.n_seg = n_seg; r.spp = spp; r.n_paths = n_ps; r.n_prob = n_prob;
+			r.bounces = (uint32_t)std::max(rp.bounces, 1);
+			r.ev_flags = s->rp_flags; r.ev_p = s->rp_p; r.ev_kill = s->rp_kill; r.ev_calls = s->rp_calls; r.lc_base = s->rp_base;
+			r.seg_total = s->rp_seg_total; r.lc_counter = s->rp_counter;
+			if((rc = timed(3, [&] {
+				hipLaunchKernelGGL(wf_replay_tiles, dim3(n_seg), dim3(kWave), 0, stream, r);
+				hipLaunchKernelGGL(wf_replay_bases, dim3(1), dim3(1), 0, stream, r);
+				hipLaunchKernelGGL(wf_replay_samples, dim3(n_seg), dim3(kWave), 0, stream, r); }))) return rc;
+			a.replay = 2;
 		}
+		if((rc = run(iters, false))) return rc;
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
 	}
@@ -1895,6 +2019,17 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	const int floor_pixels = (int)std::floor(aa.resampled_floor * (float)(w * h) / 100.f);
 	rp.aa_minsamples = aa_samples; rp.multi_pass = aa.passes > 1 ? 1 : 0; rp.pass_offset = 0u; rp.accumulate = 0; rp.resample_mask = nullptr;
 	if(aa.passes > 1) rp.aa_light_sample_multiplier = light_mult;
+	// the libc rand() stream the tile seeds come from (integrator_tiled.cc:319): one value per tile per pass that runs, after
+	// the values the last Material / ObjectGeometric constructor consumed (aa.rand_skip)
+	std::vector<int32_t> rand_stream;
+	const int n_tiles_frame = ((w + rp.tile_size - 1) / std::max(rp.tile_size, 1)) * ((h + rp.tile_size - 1) / std::max(rp.tile_size, 1));
+	size_t rand_pos = (size_t)std::max(aa.rand_skip, 0);
+	if(aa.rand_srand >= 0 && rp.tile_size > 0)
+	{
+		rand_stream.resize(rand_pos + (size_t)n_tiles_frame * (size_t)aa.passes);
+		yafgpu_glibc_rand((uint32_t)aa.rand_srand, (int32_t)rand_stream.size(), rand_stream.data());
+		rp.tile_rand = rand_stream.data() + rand_pos; rand_pos += (size_t)n_tiles_frame;
+	}
 	int rc = yafgpu_render_tiles(s, &rp, d_planes, d_cnt, nullptr);
 	if(resampled_out) resampled_out[0] = w * h;
 	std::vector<uint8_t> mask;
@@ -1917,6 +2052,7 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 			rp.aa_minsamples = n; rp.pass_offset = (uint32_t)acum; rp.accumulate = 1;
 			rp.aa_light_sample_multiplier = light_mult;
 			rp.resample_mask = threshold > 0.f ? mask.data() : nullptr;
+			if(!rand_stream.empty()) { rp.tile_rand = rand_stream.data() + rand_pos; rand_pos += (size_t)n_tiles_frame; }
 			rc = yafgpu_render_tiles(s, &rp, d_planes, d_cnt, nullptr);
 		}
 		acum += n;
@@ -1972,6 +2108,26 @@ int yafgpu_trace_shadow(yafgpu_scene_t *s, int32_t n, const float *rays, int32_t
 {
 	if(!shadowed) return fail(-1, "null output");
 	return trace_batch(s, n, rays, nullptr, nullptr, nullptr, shadowed, true);
+}
+
+void yafgpu_glibc_rand(uint32_t seed, int32_t count, int32_t *out)
+{	// glibc stdlib/random_r.c, TYPE_3: 31 words seeded by the Lehmer generator 16807 x mod 2^31 - 1 (Schrage's method), then
+	// r[i] = r[i-3] + r[i-31]; the first 310 values are discarded; rand() returns r >> 1
+	if(count <= 0 || !out) return;
+	std::vector<uint32_t> r((size_t)count + 344);
+	if(seed == 0u) seed = 1u;
+	r[0] = seed;
+	for(int i = 1; i < 31; ++i)
+	{
+		int32_t word = (int32_t)r[(size_t)i - 1];
+		const long hi = word / 127773, lo = word % 127773;
+		word = (int32_t)(16807 * lo - 2836 * hi);
+		if(word < 0) word += 2147483647;
+		r[(size_t)i] = (uint32_t)word;
+	}
+	for(size_t i = 31; i < 34; ++i) r[i] = r[i - 31];
+	for(size_t i = 34; i < r.size(); ++i) r[i] = r[i - 31] + r[i - 3];
+	for(int32_t k = 0; k < count; ++k) out[k] = (int32_t)(r[(size_t)k + 344] >> 1);
 }
 
 int yafgpu_scene_set_abort_flag(yafgpu_scene_t *s, const volatile int32_t *flag)

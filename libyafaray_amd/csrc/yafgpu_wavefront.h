@@ -39,6 +39,20 @@ struct WfArgs
 	uint32_t *q_closest_out, *q_shadow_out, *q_resume_out;
 	uint32_t *verdict;                // any-hit answers: BIT 2*slot + which, set for an occluded ray (zeroed before every any-hit launch)
 	float4 *shadow_filt;              // [2*slot + which] product of the transparencies a shadow ray passed (transparent shadows), or nullptr
+	// Serial-state replay (DESIGN.md "serial state").  The reference keeps two pieces of state that run
+	// through the samples of a render in order: the per-tile MWC stream Russian roulette draws from (integrator_tiled.cc:319,
+	// integrator_path_tracer.cc:282-288) and the per-thread counter estimateOneDirectLight picks its light with
+	// (integrator_montecarlo.cc:62-76).  replay 1 = RECORD pass: paths run without light estimates and without roulette
+	// kills and note, per path sample, at which depths estimateOneDirectLight is called and the survival probability of
+	// every roulette test; wf_replay_scan then walks each tile's samples in the reference's order with the tile's stream
+	// and leaves the depth each path is killed at and the counter value each sample starts with; replay 2 = FINAL pass:
+	// the program proper, taking both from those tables.  replay 0: per-sample streams (no serial state).
+	int replay, replay_lights;        // replay_lights: the counter is replayed too (one GPU; else the per-sample ordinal)
+	uint32_t *ev_flags;               // [path * P + path_sample]: bit d = light call at depth d, bit 16 + d = roulette test at depth d
+	float *ev_p;                      // [(path * P + path_sample) * (bounces - 1) + d - 1]: probability of the test at depth d
+	uint8_t *ev_kill;                 // [path * P + path_sample]: depth of the test that kills it (255: none)
+	uint8_t *ev_calls;                // [path * P + path_sample]: light calls it makes (up to the kill)
+	uint32_t *lc_base;                // [path]: correlative_sample_number_ when the sample starts
 	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
@@ -274,7 +288,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(0u), alpha);
 		HSET(18, z4);
 		c.path_i = 0; c.depth = 0;
-		if((bsdfs0 & kDiffuse) && sc.n_lights > 0)
+		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
 		{
 			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0))));
 			HSET(15, z4); HSET(16, z4); HSET(17, z4);
@@ -304,14 +318,24 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		HSET(11, f4(c3(r11) * beer_transmittance(pm.beer_sigma, ans.y), r11.w));
 	}
 	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
+	if(want_dl && a.replay == 1)
+	{	// record pass: note the call (its depth: 0 at the first hit), skip the estimate — it does not steer the path
+		const uint32_t e = slot * (uint32_t)max(rp.path_samples, 1) + (uint32_t)c.path_i;
+		a.ev_flags[e] |= 1u << (c.stage == kStFirst ? 0 : c.depth);
+		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
+		return W_DL_DONE;
+	}
 	if(want_dl)
 	{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
 		const uint32_t calls = ubits(misc.z);
 		int lnum = 0;
 		if(sc.n_lights > 1)
 		{
+			// correlative_sample_number_[thread]: the number of calls before this one in the reference's single-thread
+			// order, replayed (lc_base: where this sample starts); without the replay a per-sample ordinal stands in
+			const uint32_t counter = (a.replay == 2 && a.replay_lights) ? a.lc_base[slot] + calls : ordinal * 16u + calls;
 			Halton h2; h2.init(2u);
-			h2.set_start(rp.base_sampling_offset + (ordinal * 16u + calls) - 1u);
+			h2.set_start(rp.base_sampling_offset + counter - 1u);
 			lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
 		}
 		misc.z = fbits(calls + 1u);
@@ -468,12 +492,27 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	bool alive = true;
 	if(c.depth > rp.rr_min_bounces)
 	{	// Russian roulette :282-288
-		Mwc rr; rr.x = ubits(r11.w); rr.c = ubits(r12.w);
-		const float random_value = (float)rr.next();
-		r11.w = fbits(rr.x); r12.w = fbits(rr.c);
 		const float probability = smax(throughput.r, smax(throughput.g, throughput.b));
-		if(probability <= 0.f || probability < random_value) alive = false;
-		else throughput = throughput * (1.f / probability);
+		if(a.replay != 0)
+		{
+			const uint32_t e = slot * (uint32_t)max(rp.path_samples, 1) + (uint32_t)c.path_i;
+			if(a.replay == 1)
+			{	// record: the test and its probability; the draw is the tile stream's, made by wf_replay_scan in sample order
+				a.ev_p[(size_t)e * (size_t)max(rp.bounces - 1, 1) + (size_t)(c.depth - 1)] = probability;
+				a.ev_flags[e] |= 1u << (16 + c.depth);
+				alive = probability > 0.f;
+			}
+			else alive = (int)a.ev_kill[e] != c.depth;
+			if(alive) throughput = throughput * (1.f / probability);
+		}
+		else
+		{
+			Mwc rr; rr.x = ubits(r11.w); rr.c = ubits(r12.w);
+			const float random_value = (float)rr.next();
+			r11.w = fbits(rr.x); r12.w = fbits(rr.c);
+			if(probability <= 0.f || probability < random_value) alive = false;
+			else throughput = throughput * (1.f / probability);
+		}
 	}
 	if(alive)
 	{
@@ -822,6 +861,9 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_POSTPONE
 #define YAFGPU_TRACE_POSTPONE 1
 #endif
+#ifndef YAFGPU_TRACE_FUSED
+#define YAFGPU_TRACE_FUSED 0
+#endif
 #ifndef YAFGPU_TRACE_WAVES
 #define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
 #endif
@@ -964,6 +1006,107 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			const bool fin = hit_here || (emp && !restart) || z < tmin;                // z < tmin: :717
 			ws = fin ? kWalkEnd : kWalk;
 		};
+		// one triangle test of the pending leaf, on the fetched record (r0, r1, r2) and the next reference
+		auto tri_step = [&](const float4 r0, const float4 r1, const float4 r2, const uint32_t ref_v) {
+			float t, u, v;
+			if(kStats) ++cn.tests;
+			// Triangle::intersect without its early returns: the same operations in the same order, every lane to the
+			// end (a wave of 30 rays almost never leaves early as a whole), the rejections folded into one predicate
+			const bool ok = tri_test_flat(r0, r1, r2, from, dir, t, u, v);
+			const uint32_t vis = __float_as_uint(r1.w) >> 30;
+			if(kAny)
+			{
+				const bool found = ok && t < dist && t >= ray_tmin && (vis == 0u || vis == 2u);
+				hit = hit || found; done = done || found;
+			}
+			else
+			{
+				const bool better = ok && t < z && t >= ray_tmin && (vis == 0u || vis == 1u);
+				z = better ? t : z; tri = better ? (int)ti : tri; bu = better ? u : bu; bv = better ? v : bv; hit = hit || better;
+			}
+			++p_cur; ti = ref_v;
+			if(p_cur >= p_end)
+			{	// the leaf is through: :822 (a hit inside its cell ends the ray), else the walk ahead stands
+				if(YAFGPU_TRACE_POSTPONE)
+				{
+					const bool ends = !kAny && hit && z <= p_tmax;
+					done = done || ends;
+					if(kStats) { if(done) { cn.interior -= spec; cn.leaves -= spec_leaves; } spec = 0u; spec_leaves = 0u; }
+					// the walk ahead was led by the hit known then; it may be over by what this leaf found (:717)
+					if(!kAny && ws != kWalkEnd && z < tmin) ws = kWalkEnd;
+					ws = (ws == kBlocked) ? kWalk : ws;      // a leaf it waited at can be noted now
+				}
+				else if(!done) leaf_end();                  // (comparison build) the lane stood at the leaf: go on from it
+			}
+		};
+		// one step of the walk on the fetched node
+		auto node_step = [&](const uint2 nd) {
+			if((nd.y & 3u) != 3u)
+			{
+				const uint32_t axis = nd.y & 3u;
+				const float split = __uint_as_float(nd.x);
+				const float2 oi = axis_col[axis * kWave];
+				const float o = oi.x;
+				const float tplane = (split - o) * oi.y;
+				// (o < split) || (o == split && d <= 0), kdtree_triangle.cc:725-760, without the short-circuit branches
+				const bool dn = ((dneg >> axis) & 1u) != 0u;
+				const bool below = dn ? (o <= split) : (o < split);
+				const uint32_t left = node + 1u, right = nd.y >> 2;
+				const uint32_t near_c = below ? left : right, far_c = below ? right : left;
+				if(kStats) { ++cn.interior; if(p_cur < p_end) ++spec; }
+				const bool near_only = !(tplane <= tmax) || tplane <= 0.f;        // plane beyond the cell or behind the origin (also NaN)
+				const bool far_only = !near_only && tplane < tmin;
+				const bool both = !near_only && !far_only;
+				// the slot above the top is always free (at most kStack-1 live entries), so the far child is written
+				// unconditionally and only the stack pointer says whether it was a push
+				stk.col[(stk.sp & (kStack - 1)) * kWave] = make_uint2(far_c, __float_as_uint(tmax));
+				stk.sp += both ? 1 : 0;
+				stk.lo = max(stk.lo, stk.sp - (kStack - 1));
+				node = far_only ? far_c : near_c;
+				tmax = both ? tplane : tmax;
+			}
+			else
+			{
+				const uint32_t np = nd.y >> 2;
+				if(np == 0u) { if(kStats) { ++cn.leaves; if(p_cur < p_end) ++spec_leaves; } leaf_end(); }
+				else if(!YAFGPU_TRACE_POSTPONE)
+				{	// (comparison build) stop at every non-empty leaf until its tests are through
+					if(kStats) ++cn.leaves;
+					p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax; ti = sc.refs[nd.x]; ws = kBlocked;
+				}
+				else if(p_cur < p_end) ws = kBlocked;          // a second non-empty leaf: wait for the pending one (the node is read again then)
+				else
+				{
+					if(kStats) ++cn.leaves;
+					p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax;
+					ti = sc.refs[nd.x];                           // in flight while the lane walks on
+					leaf_end();
+				}
+			}
+		};
+#if YAFGPU_TRACE_FUSED
+		// Fused rounds: every lane fetches what it can use — the node its walk stands at AND the next triangle of its pending
+		// leaf — the wave waits once, then runs the node section and the triangle section one after the other.  More
+		// instructions per round than a voted round (both sections are always issued), half as many memory round trips per
+		// ray: the better trade when the tree does not fit the L2s and waves spend most of their time in s_waitcnt
+		// (1M triangles: PMC SQ_WAIT_ANY 65 % of wave cycles, L2 hit rate 75-83 %).
+		{
+			const bool walking = ws == kWalk;
+			uint2 nd = make_uint2(0u, 3u);
+			float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+			uint32_t ref_v = 0u;
+			if(walking) nd = sc.nodes[node];
+			if(has_pend)
+			{
+				if(p_cur + 1u < p_end) ref_v = sc.refs[p_cur + 1u];
+				r0 = sc.tri[3u * ti]; r1 = sc.tri[3u * ti + 1u]; r2 = sc.tri[3u * ti + 2u];
+			}
+			if(kStats) { ++rounds_node; ++rounds_tri; }
+			if(walking) node_step(nd);
+			if(has_pend) tri_step(r0, r1, r2, ref_v);
+			(void)n_tri; (void)n_node;
+		}
+#else
 		if(n_tri * kVoteNum >= n_node * kVoteDen && n_tri > 0)
 		{
 			if(kStats) ++rounds_tri;
@@ -972,36 +1115,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				uint32_t ref_v = 0u;
 				if(p_cur + 1u < p_end) ref_v = sc.refs[p_cur + 1u];
 				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
-				float t, u, v;
-				if(kStats) ++cn.tests;
-				// Triangle::intersect without its early returns: the same operations in the same order, every lane to the
-				// end (a wave of 30 rays almost never leaves early as a whole), the rejections folded into one predicate
-				const bool ok = tri_test_flat(r0, r1, r2, from, dir, t, u, v);
-				const uint32_t vis = __float_as_uint(r1.w) >> 30;
-				if(kAny)
-				{
-					const bool found = ok && t < dist && t >= ray_tmin && (vis == 0u || vis == 2u);
-					hit = hit || found; done = done || found;
-				}
-				else
-				{
-					const bool better = ok && t < z && t >= ray_tmin && (vis == 0u || vis == 1u);
-					z = better ? t : z; tri = better ? (int)ti : tri; bu = better ? u : bu; bv = better ? v : bv; hit = hit || better;
-				}
-				++p_cur; ti = ref_v;
-				if(p_cur >= p_end)
-				{	// the leaf is through: :822 (a hit inside its cell ends the ray), else the walk ahead stands
-					if(YAFGPU_TRACE_POSTPONE)
-					{
-						const bool ends = !kAny && hit && z <= p_tmax;
-						done = done || ends;
-						if(kStats) { if(done) { cn.interior -= spec; cn.leaves -= spec_leaves; } spec = 0u; spec_leaves = 0u; }
-						// the walk ahead was led by the hit known then; it may be over by what this leaf found (:717)
-						if(!kAny && ws != kWalkEnd && z < tmin) ws = kWalkEnd;
-						ws = (ws == kBlocked) ? kWalk : ws;      // a leaf it waited at can be noted now
-					}
-					else if(!done) leaf_end();                  // (comparison build) the lane stood at the leaf: go on from it
-				}
+				tri_step(r0, r1, r2, ref_v);
 			}
 		}
 		else
@@ -1010,54 +1124,10 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			for(int s = 0; s < kNodeBurst; ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
-				if(ws == kWalk)
-				{
-					const uint2 nd = sc.nodes[node];
-					if((nd.y & 3u) != 3u)
-					{
-						const uint32_t axis = nd.y & 3u;
-						const float split = __uint_as_float(nd.x);
-						const float2 oi = axis_col[axis * kWave];
-						const float o = oi.x;
-						const float tplane = (split - o) * oi.y;
-						// (o < split) || (o == split && d <= 0), kdtree_triangle.cc:725-760, without the short-circuit branches
-						const bool dn = ((dneg >> axis) & 1u) != 0u;
-						const bool below = dn ? (o <= split) : (o < split);
-						const uint32_t left = node + 1u, right = nd.y >> 2;
-						const uint32_t near_c = below ? left : right, far_c = below ? right : left;
-						if(kStats) { ++cn.interior; if(p_cur < p_end) ++spec; }
-						const bool near_only = !(tplane <= tmax) || tplane <= 0.f;        // plane beyond the cell or behind the origin (also NaN)
-						const bool far_only = !near_only && tplane < tmin;
-						const bool both = !near_only && !far_only;
-						// the slot above the top is always free (at most kStack-1 live entries), so the far child is written
-						// unconditionally and only the stack pointer says whether it was a push
-						stk.col[(stk.sp & (kStack - 1)) * kWave] = make_uint2(far_c, __float_as_uint(tmax));
-						stk.sp += both ? 1 : 0;
-						stk.lo = max(stk.lo, stk.sp - (kStack - 1));
-						node = far_only ? far_c : near_c;
-						tmax = both ? tplane : tmax;
-					}
-					else
-					{
-						const uint32_t np = nd.y >> 2;
-						if(np == 0u) { if(kStats) { ++cn.leaves; if(p_cur < p_end) ++spec_leaves; } leaf_end(); }
-						else if(!YAFGPU_TRACE_POSTPONE)
-						{	// (comparison build) stop at every non-empty leaf until its tests are through
-							if(p_cur < p_end) ws = kBlocked;
-							else { if(kStats) ++cn.leaves; p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax; ti = sc.refs[nd.x]; ws = kBlocked; }
-						}
-						else if(p_cur < p_end) ws = kBlocked;          // a second non-empty leaf: wait for the pending one (the node is read again then)
-						else
-						{
-							if(kStats) ++cn.leaves;
-							p_cur = nd.x; p_end = nd.x + np; p_tmax = tmax;
-							ti = sc.refs[nd.x];                           // in flight while the lane walks on
-							leaf_end();
-						}
-					}
-				}
+				if(ws == kWalk) node_step(sc.nodes[node]);
 			}
 		}
+#endif
 		if(done || (ws == kWalkEnd && p_cur >= p_end))
 		{
 			if(kAny) answer_any(hit);
@@ -1314,6 +1384,113 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(const WfArgs a)
 	}
 	if(a.ra.counters != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
 		atomicAdd((unsigned long long *)&a.ra.counters->camera_samples, (unsigned long long)a.n_paths);
+}
+
+// ---- serial-state replay between the record pass and the final pass (see WfArgs::replay) ----------------------------
+struct ReplayArgs
+{
+	const uint32_t *seg_begin;     // n_seg + 1: first pixel (chunk-local) of every tile segment of the chunk, in the reference's tile order
+	const uint32_t *seg_seed;      // n_seg: seed of the tile's Random (integrator_tiled.cc:319)
+	uint32_t n_seg, spp, n_paths, n_prob;   // path samples per camera sample; probabilities per entry (bounces - 1, at least 1)
+	uint32_t bounces;
+	const uint32_t *ev_flags; const float *ev_p; uint8_t *ev_kill; uint8_t *ev_calls; uint32_t *lc_base;
+	uint32_t *seg_total;           // n_seg: light calls per segment, then (wf_replay_bases) the counter value the segment starts with
+	uint32_t *lc_counter;          // correlative_sample_number_ so far (carried over chunks and passes)
+};
+
+// One wave per tile.  Entries (camera sample x path sample) of a tile are contiguous and already in the reference's
+// order (pixels row by row, samples, path samples); lanes fetch 64 of them at a time, lane 0 walks them with the tile's
+// MWC stream: one draw per roulette test of a path that is still alive, exactly as integrate() draws them
+// (integrator_path_tracer.cc:282-288: `probability <= 0 || probability < random_value` kills), and counts the
+// estimateOneDirectLight calls made up to the kill (the call of the killing depth comes before the test, :273 / :282).
+__global__ __launch_bounds__(kWave) void wf_replay_tiles(const ReplayArgs r)
+{
+	__shared__ uint32_t s_flags[kWave];
+	__shared__ float s_p[kWave][12];
+	__shared__ uint8_t s_kill[kWave], s_calls[kWave];
+	const int lane = (int)threadIdx.x;
+	for(uint32_t seg = blockIdx.x; seg < r.n_seg; seg += gridDim.x)
+	{
+		const uint32_t per_px = r.spp * r.n_paths;
+		const uint32_t e0 = r.seg_begin[seg] * per_px, n_ent = (r.seg_begin[seg + 1u] - r.seg_begin[seg]) * per_px;
+		Mwc rr; rr.init(r.seg_seed[seg]);
+		uint32_t total = 0u;
+		for(uint32_t base = 0u; base < n_ent; base += kWave)
+		{
+			const uint32_t e = e0 + base + (uint32_t)lane;
+			const bool live = base + (uint32_t)lane < n_ent;
+			const uint32_t flags = live ? r.ev_flags[e] : 0u;
+			const uint32_t tests = flags >> 16;
+			if(__ballot(tests != 0u) == 0ull)
+			{	// no roulette test among these 64: nothing serial to do
+				const uint32_t calls = (uint32_t)__popc(flags & 0xffffu);
+				if(live) { r.ev_kill[e] = 255u; r.ev_calls[e] = (uint8_t)calls; }
+				total += wave_sum(calls);
+				continue;
+			}
+			s_flags[lane] = flags;
+			for(uint32_t d = 1u; d < r.bounces; ++d)
+				if((tests >> d) & 1u) s_p[lane][d] = r.ev_p[(size_t)e * r.n_prob + (d - 1u)];
+			__syncthreads();
+			if(lane == 0)
+			{
+				const uint32_t cnt = min((uint32_t)kWave, n_ent - base);
+				for(uint32_t j = 0u; j < cnt; ++j)
+				{
+					const uint32_t f = s_flags[j];
+					uint32_t kill = 255u, calls = f & 1u;
+					for(uint32_t d = 1u; d < r.bounces; ++d)
+					{
+						calls += (f >> d) & 1u;
+						if((f >> (16u + d)) & 1u)
+						{
+							const float random_value = (float)rr.next();
+							const float probability = s_p[j][d];
+							if(probability <= 0.f || probability < random_value) { kill = d; break; }
+						}
+					}
+					s_kill[j] = (uint8_t)kill; s_calls[j] = (uint8_t)calls;
+					total += calls;
+				}
+			}
+			__syncthreads();
+			if(live) { r.ev_kill[e] = s_kill[lane]; r.ev_calls[e] = s_calls[lane]; }
+			__syncthreads();
+		}
+		if(lane == 0) r.seg_total[seg] = total;
+	}
+}
+
+// exclusive scan of the segments' call counts in tile order, on top of the counter so far (a few hundred to a few thousand values)
+__global__ void wf_replay_bases(const ReplayArgs r)
+{
+	if(blockIdx.x != 0 || threadIdx.x != 0) return;
+	uint32_t run = *r.lc_counter;
+	for(uint32_t k = 0u; k < r.n_seg; ++k) { const uint32_t t = r.seg_total[k]; r.seg_total[k] = run; run += t; }
+	*r.lc_counter = run;
+}
+
+// the counter value every camera sample starts with: the segment's base + the calls of the samples before it in the tile
+__global__ __launch_bounds__(kWave) void wf_replay_samples(const ReplayArgs r)
+{
+	const int lane = (int)threadIdx.x;
+	for(uint32_t seg = blockIdx.x; seg < r.n_seg; seg += gridDim.x)
+	{
+		const uint32_t s0 = r.seg_begin[seg] * r.spp, n_slots = (r.seg_begin[seg + 1u] - r.seg_begin[seg]) * r.spp;
+		uint32_t run = r.seg_total[seg];
+		for(uint32_t base = 0u; base < n_slots; base += kWave)
+		{
+			const uint32_t slot = s0 + base + (uint32_t)lane;
+			const bool live = base + (uint32_t)lane < n_slots;
+			uint32_t calls = 0u;
+			if(live) for(uint32_t i = 0u; i < r.n_paths; ++i) calls += r.ev_calls[(size_t)slot * r.n_paths + i];
+			uint32_t incl = calls;
+#pragma unroll
+			for(int o = 1; o < kWave; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, kWave); if(lane >= o) incl += v; }
+			if(live) r.lc_base[slot] = run + incl - calls;
+			run += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+		}
+	}
 }
 
 #endif // YAFGPU_VARIANT_TU

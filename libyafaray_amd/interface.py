@@ -54,7 +54,7 @@ C_API_SYMBOLS = [
     "yafaray_paramsPushList", "yafaray_paramsEndList",
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
-    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_prepareRender",
+    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_prepareRender",
     "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
 ]
 GPU_ABI_SYMBOLS = [
@@ -62,7 +62,7 @@ GPU_ABI_SYMBOLS = [
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host", "yafgpu_render_passes_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
     "yafgpu_kdtree_build", "yafgpu_kdtree_build_device", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
-    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag",
+    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag", "yafgpu_glibc_rand",
 ]
 
 
@@ -98,9 +98,9 @@ def load():
         "yafaray_render": (ci, [vp, C.POINTER(Output), vp]), "yafaray_abort": (None, [vp]),
         "yafaray_getRenderedImage": (ci, [vp, ci, C.POINTER(Output)]),
         "yafaray_getFilm": (ci, [vp, C.POINTER(cf), ci, ci]), "yafaray_getRenderStats": (ci, [vp, C.POINTER(RenderStats)]),
-        "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_prepareRender": (ci, [vp]),
+        "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_setSerialReplay": (None, [vp, ci]), "yafaray_prepareRender": (ci, [vp]),
         "yafaray_renderPassDevice": (ci, [vp, vp, vp, vp]), "yafaray_getRenderSize": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
-        "yafaray_loadXml": (ci, [vp, cp]),
+        "yafaray_loadXml": (ci, [vp, cp]), "yafaray_getRandState": (None, [vp, C.POINTER(ci), C.POINTER(ci)]),
         "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
         "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
         "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
@@ -292,6 +292,16 @@ class Interface:
     # -- additions (measurement / multi-GPU)
     def setShard(self, index, count):
         self._L.yafaray_setShard(self._h, index, count)
+
+    def setSerialReplay(self, on):
+        self._L.yafaray_setSerialReplay(self._h, int(bool(on)))
+
+    def getRandState(self):
+        """(srand seed, values consumed since) of the libc stream the tile seeds continue — what the oracle needs to
+        render the same scene (`rand_srand`, `rand_skip`)"""
+        a, b = C.c_int(), C.c_int()
+        self._L.yafaray_getRandState(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def prepareRender(self):
         return self._ok(self._L.yafaray_prepareRender(self._h), "prepareRender")

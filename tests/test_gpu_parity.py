@@ -342,6 +342,67 @@ def test_full_size_c4_one_light_against_oracle_windows(pipeline):
     _full_size_against_crops("c4", [(300, 800), (640, 400), (60, 100), (850, 850)], 116, lights=1, low_spp=2)
 
 
+# ---- serial-state replay: the reference's per-tile roulette stream and its light counter -------------
+def _render_with_rand_state(sc, rd, replay=True):
+    """device render + the oracle's SINGLE-THREADED render of the same scene with the libc state the device side derived
+    for it (srand seed of the last constructor, values its colour loop consumed): the reference's serial semantics"""
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.setSerialReplay(replay)
+    seed, skip = yi.getRandState()
+    assert seed > 0 and skip >= 3
+    yi.render()
+    film, st = yi.getFilm(rd["width"], rd["height"]), yi.getRenderStats()
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=1, rand_srand=seed, rand_skip=skip))
+    return film, st, ofilm, ost
+
+
+@pytest.mark.parametrize("case", [
+    dict(n_lights=1, bounces=4, rr=0, path_samples=1),                 # the reference's default: roulette from depth 1 on
+    dict(n_lights=1, bounces=6, rr=2, path_samples=3),
+    dict(n_lights=2, bounces=3, rr=3, path_samples=1),                 # roulette off, two lights: the counter alone
+    dict(n_lights=2, bounces=5, rr=0, path_samples=2, glossy=0.4),     # both, MIS on glossy
+    dict(n_lights=2, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02)),   # adaptive passes
+])
+def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, monkeypatch):
+    """Russian roulette ON (the reference's default, integrator_path_tracer.cc:355) and / or more than one light: the
+    film depends on state that runs through the samples in the reference's order — the tile's MWC stream
+    (integrator_tiled.cc:319, seeded from libc rand()) and correlative_sample_number_ (integrator_montecarlo.cc:62-76).
+    The device replays both (record pass, per-tile scan, final pass) and must reproduce the oracle's one-thread render:
+    same ray counts, same film."""
+    if pipeline == "megakernel":
+        pytest.skip("the replay belongs to the wavefront pipeline")
+    sc = scenes.cornell_soup(1500, seed=41 + case["bounces"], res=(72, 56), n_lights=case["n_lights"], glossy_fraction=case.get("glossy", 0.0))
+    rd = scenes.render_settings(72, 56, 6, bounces=case["bounces"], path_samples=case["path_samples"], tile_size=16,
+                                russian_roulette_min_bounces=case["rr"], **case.get("aa", {}))
+    film, st, ofilm, ost = _render_with_rand_state(sc, rd)
+    assert st.camera_samples == ost.camera_samples
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow, "ray counts differ from the oracle's single-thread render"
+    compare_films(film, ofilm, f"serial replay {case}")
+    # chunk borders (whole tiles per chunk) do not change anything
+    monkeypatch.setenv("YAFGPU_WF_CHUNK", "4096")
+    film2, st2, _, _ = _render_with_rand_state(sc, rd)
+    assert st2.rays_closest == st.rays_closest and st2.rays_shadow == st.rays_shadow
+    assert np.array_equal(film, film2), "chunked replay differs"
+    monkeypatch.delenv("YAFGPU_WF_CHUNK")
+    # and the per-sample streams (replay off) render something else: the state does matter in this scene
+    film3, st3, _, _ = _render_with_rand_state(sc, rd, replay=False)
+    assert not np.array_equal(film3, film)
+
+
+def test_full_size_c4_two_lights_exact_replay(pipeline):
+    """BASELINE.json configs[3] AS STATED — 1M triangles, half of them glossy, TWO area lights, 1024x1024 — whole frame
+    at 2 spp against the oracle's single-threaded render (with two lights the light a path vertex samples depends on
+    the number of estimateOneDirectLight calls before it in the whole frame, so windows cannot stand in for the frame)."""
+    if pipeline == "megakernel":
+        pytest.skip("the replay belongs to the wavefront pipeline")
+    import bench
+    w, sc, rd = bench.make_workload("c4", spp=2)
+    film, st, ofilm, ost = _render_with_rand_state(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "c4 two lights 1024x1024 2 spp, exact replay", max_outliers=1024 * 1024 // 20000)
+
+
 def test_device_shards_sum_to_the_unsharded_frame(pipeline):
     """The multi-GPU decomposition on ONE GPU: shard 0/2 and 1/2 (tile t -> rank t % 2, yafaray_setShard) rendered by the
     device one after the other, their films summed as parallel.reduce_film sums them over RCCL — equal to the unsharded

@@ -10,9 +10,10 @@
  * yafaray_getLastError() returns the diagnostic the reference would have logged.
  *
  * Scope: scenes of type "triangle"; materials shinydiffusemat / glossy(as_diffuse) /
- * light_mat; lights arealight / pointlight; camera perspective (pinhole); background constant;
- * integrators pathtracing / directlighting; volume integrator none.  Anything else fails loudly
- * at create* or render time — nothing falls back to a CPU path.
+ * coated_glossy(as_diffuse) / glass / mirror / light_mat; lights arealight / pointlight; camera perspective (with depth of
+ * field); background constant; integrators pathtracing / directlighting; volume integrator none.  Every method of
+ * Interface has a function here: what lies outside the scope fails loudly (0 / NULL + yafaray_getLastError) at the call
+ * or at render time — nothing falls back to a CPU path, and nothing is silently dropped.
  */
 #ifndef YAFARAY_C_API_H
 #define YAFARAY_C_API_H
@@ -57,10 +58,10 @@ typedef struct yafaray_progress
 yafaray_interface_t *yafaray_createInterface(void);
 void yafaray_destroyInterface(yafaray_interface_t *yi);
 const char *yafaray_getLastError(const yafaray_interface_t *yi);
-const char *yafaray_getVersion(void);                                            /* interface.h:116 */
+const char *yafaray_getVersion(void);                                            /* interface.h:117 */
 
 /* scene state machine — Interface::startScene .. endGeometry, interface.cc:113-219 */
-yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type);            /* interface.h:107 */
+yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type);            /* interface.h:103 */
 yafaray_bool_t yafaray_startGeometry(yafaray_interface_t *yi);                   /* :54 */
 yafaray_bool_t yafaray_endGeometry(yafaray_interface_t *yi);                     /* :55 */
 unsigned int yafaray_getNextFreeId(yafaray_interface_t *yi);                     /* :60 */
@@ -71,6 +72,16 @@ int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z);   
 void yafaray_addNormal(yafaray_interface_t *yi, double nx, double ny, double nz);/* :68 */
 yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c, const yafaray_material_t *mat); /* :69 */
 yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, double angle); /* :72 */
+yafaray_bool_t yafaray_startTriMeshPtr(yafaray_interface_t *yi, unsigned int *id, int vertices, int triangles,
+                                       yafaray_bool_t has_orco, yafaray_bool_t has_uv, int type, int obj_pass_index); /* :63 */
+int yafaray_addVertexWithOrco(yafaray_interface_t *yi, double x, double y, double z, double ox, double oy, double oz); /* :67, the orco overload of addVertex */
+int yafaray_addUv(yafaray_interface_t *yi, float u, float v);                    /* :71 */
+yafaray_bool_t yafaray_addTriangleWithUv(yafaray_interface_t *yi, int a, int b, int c, int uv_a, int uv_b, int uv_c,
+                                         const yafaray_material_t *mat);          /* :70, the UV overload of addTriangle */
+/* refused with a diagnostic (outside the path's scope): */
+yafaray_bool_t yafaray_startCurveMesh(yafaray_interface_t *yi, unsigned int id, int vertices, int obj_pass_index);       /* :62 */
+yafaray_bool_t yafaray_endCurveMesh(yafaray_interface_t *yi, const yafaray_material_t *mat, float strand_start, float strand_end, float strand_shape); /* :65 */
+yafaray_bool_t yafaray_addInstance(yafaray_interface_t *yi, unsigned int base_object_id, const float *obj_to_world_16); /* :73 */
 /* extension (test support): the per-triangle-corner normals smoothMesh computed, n_tris*9 floats; an all-zero triple = geometric normal */
 yafaray_bool_t yafaray_getMeshCornerNormals(yafaray_interface_t *yi, unsigned int id, float *out, int n_floats);
 /* extension (not in the reference): bulk form of addVertex/addTriangle for large meshes;
@@ -85,6 +96,12 @@ void yafaray_paramsSetBool(yafaray_interface_t *yi, const char *name, yafaray_bo
 void yafaray_paramsSetInt(yafaray_interface_t *yi, const char *name, int i);                            /* :79 */
 void yafaray_paramsSetFloat(yafaray_interface_t *yi, const char *name, double f);                       /* :80 */
 void yafaray_paramsSetColor(yafaray_interface_t *yi, const char *name, float r, float g, float b, float a); /* :81 */
+void yafaray_paramsSetColorArray(yafaray_interface_t *yi, const char *name, const float *rgb, yafaray_bool_t with_alpha); /* :82 */
+void yafaray_paramsSetMatrix(yafaray_interface_t *yi, const char *name, const float *m16, yafaray_bool_t transpose);   /* :83, :85 (paramsSetMemMatrix): 16 floats, row major */
+void yafaray_paramsSetMatrixD(yafaray_interface_t *yi, const char *name, const double *m16, yafaray_bool_t transpose); /* :84, :86 */
+/* Interface::setInputColorSpace (:127; interface.cc:292-301): the colour space paramsSetColor reads its arguments in
+ * ("sRGB" | "XYZ" | "LinearRGB" | "Raw_Manual_Gamma"; converted to linear RGB on entry, interface.cc:247-252) */
+void yafaray_setInputColorSpace(yafaray_interface_t *yi, const char *color_space_string, float gamma_val);
 void yafaray_paramsClearAll(yafaray_interface_t *yi);                                                   /* :87 */
 void yafaray_paramsStartList(yafaray_interface_t *yi);                                                  /* :88 */
 void yafaray_paramsPushList(yafaray_interface_t *yi);                                                   /* :89 */
@@ -99,6 +116,26 @@ yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name
 yafaray_background_t *yafaray_createBackground(yafaray_interface_t *yi, const char *name);  /* :96 */
 yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const char *name);  /* :97 */
 void yafaray_clearAll(yafaray_interface_t *yi);                                             /* :101 */
+/* refused with a diagnostic (NULL / 0 and yafaray_getLastError): */
+unsigned int yafaray_createObject(yafaray_interface_t *yi, const char *name);               /* :100 */
+void *yafaray_createVolumeRegion(yafaray_interface_t *yi, const char *name);                /* :98 */
+void *yafaray_createImageHandler(yafaray_interface_t *yi, const char *name, yafaray_bool_t add_to_table); /* :99 */
+/* the calls exporters make around a render besides render() itself */
+yafaray_bool_t yafaray_setLoggingAndBadgeSettings(yafaray_interface_t *yi);                 /* :104: accepted; no badge is drawn, no log file written */
+yafaray_bool_t yafaray_setupRenderPasses(yafaray_interface_t *yi);                          /* :105: accepted for the combined pass alone; any other enabled pass is refused */
+yafaray_bool_t yafaray_setInteractive(yafaray_interface_t *yi, yafaray_bool_t interactive); /* :106 */
+int yafaray_getRenderParameters(yafaray_interface_t *yi, char *buf, int len);               /* :108: the render ParamMap as "name=value" lines; returns the bytes needed */
+void yafaray_setConsoleVerbosityLevel(yafaray_interface_t *yi, const char *level);          /* :111 */
+void yafaray_setLogVerbosityLevel(yafaray_interface_t *yi, const char *level);              /* :112 */
+void yafaray_setParamsBadgePosition(yafaray_interface_t *yi, const char *badge_position);   /* :114 */
+yafaray_bool_t yafaray_getDrawParams(yafaray_interface_t *yi);                              /* :115 */
+void yafaray_printDebug(yafaray_interface_t *yi, const char *msg);                          /* :120-125 */
+void yafaray_printVerbose(yafaray_interface_t *yi, const char *msg);
+void yafaray_printInfo(yafaray_interface_t *yi, const char *msg);
+void yafaray_printParams(yafaray_interface_t *yi, const char *msg);
+void yafaray_printWarning(yafaray_interface_t *yi, const char *msg);
+void yafaray_printError(yafaray_interface_t *yi, const char *msg);
+void yafaray_setOutput2(yafaray_interface_t *yi, const yafaray_output_t *out_2);            /* :128: second output, in color_space2 / gamma2 */
 
 /* Interface::render, interface.cc:411-418 = RenderEnvironment::setupScene (environment.cc:679-813)
  * + Scene::render (scene.cc:1037-1067).  Blocking.  Reads the render settings from the current
@@ -106,8 +143,8 @@ void yafaray_clearAll(yafaray_interface_t *yi);                                 
  * xstart, ystart, AA_*, filter_type, AA_pixelwidth, tile_size, tiles_order, threads, adv_*).
  * Returns void in the reference; here 1 on success, 0 on failure (yafaray_getLastError). */
 yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *output, const yafaray_progress_t *progress);
-void yafaray_abort(yafaray_interface_t *yi);                                                 /* :110 */
-yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output); /* :112 */
+void yafaray_abort(yafaray_interface_t *yi);                                                 /* :107 */
+yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output); /* :109 */
 
 /* ---- additions for measurement and multi-GPU drivers (no reference counterpart) ---- */
 typedef struct yafaray_render_stats

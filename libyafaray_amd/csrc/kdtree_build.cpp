@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <thread>
@@ -340,6 +341,7 @@ void build_kdtree(const float *verts, int n_tris, int depth_cap, int threads, Kd
 	p.cost_ratio = 0.8f; p.empty_bonus = 0.33f;             // scene.cc:818
 	const double log_leaves = 1.442695f * std::log((double)n_tris); // kdtree_triangle.cc:90,100
 	if(log_leaves > 16.0) p.cost_ratio += (float)(0.25 * (log_leaves - 16.0));
+	if(const char *e = std::getenv("YAFGPU_COST_RATIO")) p.cost_ratio = (float)std::atof(e);      // experiments: node-step cost / triangle-test cost
 	if(threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
 	int fan_depth = 0;
 	while((1 << fan_depth) < 2 * threads && fan_depth < 8) ++fan_depth;

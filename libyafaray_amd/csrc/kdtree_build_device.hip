@@ -495,6 +495,7 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 	float cost_ratio = 0.8f;
 	const double log_leaves = 1.442695f * std::log((double)n_tris);
 	if(log_leaves > 16.0) cost_ratio += (float)(0.25 * (log_leaves - 16.0));
+	if(const char *e = std::getenv("YAFGPU_COST_RATIO")) cost_ratio = (float)std::atof(e);      // experiments: node-step cost / triangle-test cost
 
 	const size_t n = (size_t)n_tris;
 	// room: references / nodes the arrays hold per triangle (x8).  Overlapping geometry (long needles, stacked sheets)

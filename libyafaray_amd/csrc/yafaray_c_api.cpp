@@ -126,6 +126,33 @@ namespace {
 
 bool fail(yafaray_interface *yi, const std::string &m) { yi->err = m; return false; }
 
+// fPow__ = fExp2__(fLog2__(a) * b), util_math_optimizations.h:116-142,176-183 (FAST_MATH is on in the reference's build)
+float host_fexp2(float x)
+{
+	x = std::min(x, 129.00000f);
+	x = std::max(x, -126.99999f);
+	const int ipart = (int)(x - 0.5f);
+	const float p = (x - (float)ipart);
+	const int bits = (int)((unsigned)(ipart + 127) << 23);
+	float expi; std::memcpy(&expi, &bits, 4);
+	const float poly = (p * (p * (p * (p * (p * 1.8775767e-3f + 8.9893397e-3f) + 5.5826318e-2f) + 2.4015361e-1f) + 6.9315308e-1f) + 9.9999994e-1f);
+	return expi * poly;
+}
+float host_flog2(float x)
+{
+	int i; std::memcpy(&i, &x, 4);
+	const float e = (float)(((i & 0x7F800000) >> 23) - 127);
+	const int mi = (i & 0x7FFFFF) | 0x3F800000;
+	float m; std::memcpy(&m, &mi, 4);
+	const float a = m * -3.4436006e-2f + 3.1821337e-1f;
+	const float b = m * a + -1.2315303f;
+	const double c = (double)(m * b) + 2.5988452;
+	const double d = (double)m * c + (double)-3.3241990f;
+	const double ee = (double)m * d + (double)3.1157899f;
+	return ((float)ee * (m - 1.0f) + e);
+}
+float host_fpow(float a, float b) { return host_fexp2(host_flog2(a) * b); }
+
 // Material::material_index_auto_ / ObjectGeometric::object_index_auto_ (common/material.cc:33, object_geom.cc:29): static,
 // process-wide, never reset — like the reference, one process is assumed to build its scenes one after the other
 unsigned int g_material_index_auto = 0u, g_object_index_auto = 0u;
@@ -495,6 +522,51 @@ yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c,
 	m.tri.push_back(a); m.tri.push_back(b); m.tri.push_back(c); m.tri_mat.push_back(mat->index);
 	return 1;
 }
+int yafaray_addVertexWithOrco(yafaray_interface_t *yi, double x, double y, double z, double ox, double oy, double oz)
+{	// Interface::addVertex(x, y, z, ox, oy, oz) -> Scene::addVertex(p, orco), scene.cc:352-366
+	if(yi->state != 2) { fail(yi, "addVertex: wrong state"); return -1; }
+	Mesh &m = *yi->cur;
+	if(!m.has_orco) { fail(yi, "addVertex: the mesh was started without orco coordinates"); return -1; }
+	m.points.push_back((float)x); m.points.push_back((float)y); m.points.push_back((float)z);
+	m.orco.resize(m.points.size(), 0.f);
+	const size_t k = m.points.size() - 3;
+	m.orco[k] = (float)ox; m.orco[k + 1] = (float)oy; m.orco[k + 2] = (float)oz;
+	return (int)(m.points.size() / 3) - 1;
+}
+int yafaray_addUv(yafaray_interface_t *yi, float u, float v)
+{	// Scene::addUv, scene.cc:545-560
+	if(yi->state != 2 || !yi->cur) { fail(yi, "addUv: wrong state"); return -1; }
+	Mesh &m = *yi->cur;
+	m.uv.push_back(u); m.uv.push_back(v);
+	return (int)(m.uv.size() / 2) - 1;
+}
+yafaray_bool_t yafaray_addTriangleWithUv(yafaray_interface_t *yi, int a, int b, int c, int uv_a, int uv_b, int uv_c, const yafaray_material_t *mat)
+{	// Interface::addTriangle(a, b, c, uv_a, uv_b, uv_c, mat) -> Scene::addTriangle, scene.cc:491-543
+	if(yi->state != 2) return fail(yi, "addTriangle: wrong state");
+	Mesh &m = *yi->cur;
+	if(!m.has_uv) return fail(yi, "addTriangle: the mesh was started without UV coordinates");
+	const int nuv = (int)(m.uv.size() / 2);
+	if(uv_a < 0 || uv_b < 0 || uv_c < 0 || uv_a >= nuv || uv_b >= nuv || uv_c >= nuv) return fail(yi, "addTriangle: UV index out of range");
+	if(!yafaray_addTriangle(yi, a, b, c, mat)) return 0;
+	m.tri_uv.resize(m.tri.size(), 0);
+	const size_t k = m.tri.size() - 3;
+	m.tri_uv[k] = uv_a; m.tri_uv[k + 1] = uv_b; m.tri_uv[k + 2] = uv_c;
+	return 1;
+}
+yafaray_bool_t yafaray_startTriMeshPtr(yafaray_interface_t *yi, unsigned int *id, int vertices, int triangles, yafaray_bool_t has_orco, yafaray_bool_t has_uv, int type, int obj_pass_index)
+{	// interface.cc:153-160: the scene picks the id
+	if(!id) return fail(yi, "startTriMeshPtr: null id");
+	*id = yafaray_getNextFreeId(yi);
+	return yafaray_startTriMesh(yi, *id, vertices, triangles, has_orco, has_uv, type, obj_pass_index);
+}
+// outside the hot path's scope: refused with a diagnostic, never routed anywhere else
+yafaray_bool_t yafaray_startCurveMesh(yafaray_interface_t *yi, unsigned int, int, int) { return fail(yi, "startCurveMesh: curve (strand) meshes are outside the GPU path's scope"); }
+yafaray_bool_t yafaray_endCurveMesh(yafaray_interface_t *yi, const yafaray_material_t *, float, float, float) { return fail(yi, "endCurveMesh: curve (strand) meshes are outside the GPU path's scope"); }
+yafaray_bool_t yafaray_addInstance(yafaray_interface_t *yi, unsigned int, const float *) { return fail(yi, "addInstance: instanced base meshes are outside the GPU path's scope"); }
+unsigned int yafaray_createObject(yafaray_interface_t *yi, const char *) { fail(yi, "createObject: parametric objects (sphere) are outside the GPU path's scope (triangle meshes only)"); return 0u; }
+void *yafaray_createVolumeRegion(yafaray_interface_t *yi, const char *) { fail(yi, "createVolumeRegion: volume regions are outside the GPU path's scope (volume integrator \"none\" only)"); return nullptr; }
+void *yafaray_createImageHandler(yafaray_interface_t *yi, const char *, yafaray_bool_t) { fail(yi, "createImageHandler: image files are written by the caller from the ColorOutput callbacks; no image handlers on the GPU path"); return nullptr; }
+
 yafaray_bool_t yafaray_addTriangles(yafaray_interface_t *yi, int n_verts, const float *verts, int n_tris, const int *indices, const yafaray_material_t *mat)
 {
 	if(yi->state != 2) return fail(yi, "addTriangles: wrong state");
@@ -657,8 +729,49 @@ void yafaray_paramsSetBool(yafaray_interface_t *yi, const char *name, yafaray_bo
 void yafaray_paramsSetInt(yafaray_interface_t *yi, const char *name, int i) { Param p; p.type = Param::Int; p.i = i; set_param(yi, name, p); }
 void yafaray_paramsSetFloat(yafaray_interface_t *yi, const char *name, double f) { Param p; p.type = Param::Float; p.f = f; set_param(yi, name, p); }
 void yafaray_paramsSetColor(yafaray_interface_t *yi, const char *name, float r, float g, float b, float a)
-{	// interface.cc:247-252; the default input colour space (RawManualGamma, gamma 1) leaves values unchanged
-	Param p; p.type = Param::Color; p.v[0] = r; p.v[1] = g; p.v[2] = b; p.v[3] = a; set_param(yi, name, p);
+{	// interface.cc:247-252: Rgba::linearRgbFromColorSpace(input_color_space_, input_gamma_) (color.h:366-386); alpha stays
+	float c[3] = {r, g, b};
+	if(yi->input_color_space == 0)
+	{	// linearRgbFromSRgb, color.h:352-357
+		for(float &v : c) v = (v <= 0.04045f) ? (v / 12.92f) : host_fpow(((v + 0.055f) / 1.055f), 2.4f);
+	}
+	else if(yi->input_color_space == 1)
+	{	// XYZ (D65) -> linear RGB, color.h:337-342,375-381
+		static const float m[3][3] = {{3.2406255f, -1.537208f, -0.4986286f}, {-0.9689307f, 1.8757561f, 0.0415175f}, {0.0557101f, -0.2040211f, 1.0569959f}};
+		const float o[3] = {c[0], c[1], c[2]};
+		for(int k = 0; k < 3; ++k) c[k] = m[k][0] * o[0] + m[k][1] * o[1] + m[k][2] * o[2];
+	}
+	else if(yi->input_color_space == 3 && yi->input_gamma != 1.f)
+		for(float &v : c) v = host_fpow(v, yi->input_gamma);      // gammaAdjust, color.h:101
+	Param p; p.type = Param::Color; p.v[0] = c[0]; p.v[1] = c[1]; p.v[2] = c[2]; p.v[3] = a; set_param(yi, name, p);
+}
+void yafaray_paramsSetColorArray(yafaray_interface_t *yi, const char *name, const float *rgb, yafaray_bool_t with_alpha)
+{	// interface.cc:254-259
+	if(rgb) yafaray_paramsSetColor(yi, name, rgb[0], rgb[1], rgb[2], with_alpha ? rgb[3] : 1.f);
+}
+void yafaray_paramsSetMatrix(yafaray_interface_t *yi, const char *name, const float *m16, yafaray_bool_t transpose)
+{	// interface.cc:260-289 (paramsSetMatrix / paramsSetMemMatrix, float): 16 values, row major
+	if(!m16) return;
+	Param p; p.type = Param::Matrix;
+	for(int i = 0; i < 4; ++i) for(int j = 0; j < 4; ++j) p.m[4 * i + j] = transpose ? m16[4 * j + i] : m16[4 * i + j];
+	set_param(yi, name, p);
+}
+void yafaray_paramsSetMatrixD(yafaray_interface_t *yi, const char *name, const double *m16, yafaray_bool_t transpose)
+{	// the double overloads, interface.cc:266-289
+	if(!m16) return;
+	float f[16];
+	for(int k = 0; k < 16; ++k) f[k] = (float)m16[k];
+	yafaray_paramsSetMatrix(yi, name, f, transpose);
+}
+void yafaray_setInputColorSpace(yafaray_interface_t *yi, const char *color_space_string, float gamma_val)
+{	// interface.cc:292-301
+	const std::string cs = color_space_string ? color_space_string : "";
+	if(cs == "sRGB") yi->input_color_space = 0;
+	else if(cs == "XYZ") yi->input_color_space = 1;
+	else if(cs == "LinearRGB") yi->input_color_space = 2;
+	else if(cs == "Raw_Manual_Gamma") yi->input_color_space = 3;
+	else yi->input_color_space = 0;
+	yi->input_gamma = gamma_val;
 }
 void yafaray_paramsClearAll(yafaray_interface_t *yi) { yi->params.dicc.clear(); yi->eparams.clear(); yi->cparams = &yi->params; }
 void yafaray_paramsStartList(yafaray_interface_t *yi) { yi->eparams.emplace_back(); yi->cparams = &yi->eparams.back(); }
@@ -829,6 +942,8 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	p.get("adv_auto_min_raydist_enabled", auto_dist); p.get("adv_min_raydist_value", min_raydist);
 	p.get("adv_base_sampling_offset", base_offset); p.get("adv_computer_node", node);
 	p.get("color_space", yi->color_space); p.get("gamma", yi->gamma);
+	yi->color_space2 = "Raw_Manual_Gamma"; yi->gamma2 = 1.f;
+	p.get("color_space2", yi->color_space2); p.get("gamma2", yi->gamma2);
 	// Scene::setAntialiasing (scene.cc:761-778), defaults of RenderEnvironment::setupScene (environment.cc:682-695,747-762)
 	{
 		yafgpu_aa_schedule &aa = yi->aa;
@@ -980,10 +1095,28 @@ yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float
 	return 1;
 }
 
-static float srgb_from_linear(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f; }
-
-static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)
-{	// ImageFilm::flush (imagefilm.cc:640-900), combined pass only
+// ImageFilm::flush (imagefilm.cc:737-772), combined pass: Pixel::normalized -> clampRgb0 -> Rgb::colorSpaceFromLinearRgb
+// (color.h:388-411: sRGB via the polynomial fPow__, XYZ D65 by matrix, RawManualGamma by gammaAdjust(1 / gamma)) -> alpha
+// clamped to [0, 1]
+static void to_output_space(const std::string &cs, float gamma, float c[4])
+{
+	if(cs == "sRGB") { for(int k = 0; k < 3; ++k) c[k] = (c[k] <= 0.0031308f) ? (c[k] * 12.92f) : ((1.055f * host_fpow(c[k], 0.416667f)) - 0.055f); }
+	else if(cs == "XYZ")
+	{
+		static const float m[3][3] = {{0.412400f, 0.357600f, 0.180500f}, {0.212600f, 0.715200f, 0.072200f}, {0.019300f, 0.119200f, 0.950500f}};
+		const float o[3] = {c[0], c[1], c[2]};
+		for(int k = 0; k < 3; ++k) c[k] = m[k][0] * o[0] + m[k][1] * o[1] + m[k][2] * o[2];
+	}
+	else if(cs == "Raw_Manual_Gamma" && gamma != 1.f)
+	{
+		if(gamma <= 0.f) gamma = 1.0e-2f;
+		const float inv = 1.f / gamma;
+		for(int k = 0; k < 3; ++k) c[k] = host_fpow(c[k], inv);
+	}
+	if(c[3] < 0.f) c[3] = 0.f; else if(c[3] > 1.f) c[3] = 1.f;
+}
+static void deliver_to(yafaray_interface_t *yi, const yafaray_output_t *out, const std::string &cs, float gamma)
+{
 	if(!out) return;
 	const int w = yi->rp.width, h = yi->rp.height;
 	if(out->putPixel)
@@ -993,15 +1126,81 @@ static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)
 			{
 				const float *px = &yi->film[5 * ((size_t)y * (size_t)w + (size_t)x)];
 				float c[4] = {0, 0, 0, 0};
-				if(px[4] != 0.f) for(int k = 0; k < 4; ++k) c[k] = px[k] / px[4];   // Pixel::normalized
+				if(px[4] != 0.f) { const float f = (float)(1.0 / (double)px[4]); for(int k = 0; k < 4; ++k) c[k] = px[k] * f; }   // Pixel::normalized, Rgba / float (color.h:310-314)
 				for(int k = 0; k < 3; ++k) c[k] = std::max(0.f, c[k]);              // clampRgb0
-				if(yi->color_space == "sRGB") for(int k = 0; k < 3; ++k) c[k] = srgb_from_linear(c[k]);
-				else if(yi->color_space == "Raw_Manual_Gamma" && yi->gamma > 0.f && std::fabs(1.f - yi->gamma) > 0.001f)
-					for(int k = 0; k < 3; ++k) c[k] = std::pow(c[k], 1.f / yi->gamma);
+				to_output_space(cs, gamma, c);
 				out->putPixel(out->user, 0, x, y, c[0], c[1], c[2], c[3]);
 			}
 	}
 	if(out->flush) out->flush(out->user, 0);
+}
+static void deliver(yafaray_interface_t *yi, const yafaray_output_t *out)
+{
+	deliver_to(yi, out, yi->color_space, yi->gamma);
+	if(yi->has_output2) deliver_to(yi, &yi->output2, yi->color_space2, yi->gamma2);      // Interface::setOutput2, interface.cc:420-423
+}
+
+// ---- the rest of Interface's surface (interface.h:62-128): honoured where it touches this path, accepted where it only
+// concerns logging / image decoration, refused with a diagnostic where it asks for something outside the scope
+yafaray_bool_t yafaray_setLoggingAndBadgeSettings(yafaray_interface_t *yi)
+{	// interface.cc:131-135 -> RenderEnvironment::setupLoggingAndBadge: log files and the parameters badge drawn onto saved
+	// images — decoration of the output, not of the film; the settings are read and dropped
+	std::string pos;
+	if(yi->params.get("logging_paramsBadgePosition", pos)) yi->badge_position = pos;
+	return 1;
+}
+yafaray_bool_t yafaray_setupRenderPasses(yafaray_interface_t *yi)
+{	// interface.cc:137-141 -> RenderEnvironment::setupRenderPasses (environment.cc:598-677): with pass_enable the external
+	// passes named by pass_* are rendered beside the combined one.  The GPU path produces the combined pass only.
+	bool enable = false;
+	yi->params.get("pass_enable", enable);
+	if(!enable) return 1;
+	for(const auto &kv : yi->params.dicc)
+		if(kv.first.compare(0, 5, "pass_") == 0 && kv.second.type == Param::String && kv.second.s != "disabled" && kv.second.s != "combined")
+			return fail(yi, "setupRenderPasses: render pass \"" + kv.first + "\" = \"" + kv.second.s + "\": the GPU path renders the combined pass only");
+	return 1;
+}
+yafaray_bool_t yafaray_setInteractive(yafaray_interface_t *yi, yafaray_bool_t interactive) { yi->interactive = interactive != 0; return 1; }   // interface.cc:143-151
+void yafaray_setConsoleVerbosityLevel(yafaray_interface_t *, const char *) {}      // interface.cc:374-377: console log level
+void yafaray_setLogVerbosityLevel(yafaray_interface_t *, const char *) {}          // :379-382
+void yafaray_setParamsBadgePosition(yafaray_interface_t *yi, const char *badge_position) { yi->badge_position = badge_position ? badge_position : "none"; }   // :384-387
+yafaray_bool_t yafaray_getDrawParams(yafaray_interface_t *) { return 0; }           // :389-396: no badge is drawn
+static void print_line(const char *level, const char *msg) { std::fprintf(stderr, "%s: %s\n", level, msg ? msg : ""); }
+void yafaray_printDebug(yafaray_interface_t *, const char *msg) { if(std::getenv("YAFGPU_VERBOSE")) print_line("DEBUG", msg); }     // :425-449
+void yafaray_printVerbose(yafaray_interface_t *, const char *msg) { if(std::getenv("YAFGPU_VERBOSE")) print_line("VERB", msg); }
+void yafaray_printInfo(yafaray_interface_t *, const char *msg) { if(std::getenv("YAFGPU_VERBOSE")) print_line("INFO", msg); }
+void yafaray_printParams(yafaray_interface_t *, const char *msg) { if(std::getenv("YAFGPU_VERBOSE")) print_line("PARM", msg); }
+void yafaray_printWarning(yafaray_interface_t *, const char *msg) { print_line("WARNING", msg); }
+void yafaray_printError(yafaray_interface_t *, const char *msg) { print_line("ERROR", msg); }
+void yafaray_setOutput2(yafaray_interface_t *yi, const yafaray_output_t *out_2)
+{	// interface.cc:420-423: a second ColorOutput, fed in colour space `color_space2` / `gamma2`
+	yi->has_output2 = out_2 != nullptr;
+	if(out_2) yi->output2 = *out_2;
+}
+int yafaray_getRenderParameters(yafaray_interface_t *yi, char *buf, int len)
+{	// Interface::getRenderParameters (interface.h:111) hands out the ParamMap; across a C ABI: "name=value" lines.
+	// Returns the number of bytes needed (excluding the terminator); writes at most len - 1 of them.
+	std::string out;
+	for(const auto &kv : yi->params.dicc)
+	{
+		out += kv.first + "=";
+		const Param &q = kv.second;
+		char tmp[160];
+		switch(q.type)
+		{
+			case Param::Int: std::snprintf(tmp, sizeof tmp, "%d", q.i); out += tmp; break;
+			case Param::Bool: out += q.b ? "true" : "false"; break;
+			case Param::Float: std::snprintf(tmp, sizeof tmp, "%.9g", q.f); out += tmp; break;
+			case Param::String: out += q.s; break;
+			case Param::Point: std::snprintf(tmp, sizeof tmp, "%.9g %.9g %.9g", q.v[0], q.v[1], q.v[2]); out += tmp; break;
+			case Param::Color: std::snprintf(tmp, sizeof tmp, "%.9g %.9g %.9g %.9g", q.v[0], q.v[1], q.v[2], q.v[3]); out += tmp; break;
+			case Param::Matrix: for(int k = 0; k < 16; ++k) { std::snprintf(tmp, sizeof tmp, k ? " %.9g" : "%.9g", q.m[k]); out += tmp; } break;
+			default: break;
+		}
+		out += "\n";
+	}
+	if(buf && len > 0) { const size_t n = std::min(out.size(), (size_t)len - 1); std::memcpy(buf, out.data(), n); buf[n] = 0; }
+	return (int)out.size();
 }
 
 yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *output, const yafaray_progress_t *progress)

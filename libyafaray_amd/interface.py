@@ -49,6 +49,14 @@ C_API_SYMBOLS = [
     "yafaray_startScene", "yafaray_startGeometry", "yafaray_endGeometry", "yafaray_getNextFreeId",
     "yafaray_startTriMesh", "yafaray_endTriMesh", "yafaray_addVertex", "yafaray_addNormal", "yafaray_addTriangle",
     "yafaray_smoothMesh", "yafaray_getMeshCornerNormals", "yafaray_addTriangles",
+    "yafaray_startTriMeshPtr", "yafaray_addVertexWithOrco", "yafaray_addUv", "yafaray_addTriangleWithUv",
+    "yafaray_startCurveMesh", "yafaray_endCurveMesh", "yafaray_addInstance",
+    "yafaray_paramsSetColorArray", "yafaray_paramsSetMatrix", "yafaray_paramsSetMatrixD", "yafaray_setInputColorSpace",
+    "yafaray_createObject", "yafaray_createVolumeRegion", "yafaray_createImageHandler",
+    "yafaray_setLoggingAndBadgeSettings", "yafaray_setupRenderPasses", "yafaray_setInteractive", "yafaray_getRenderParameters",
+    "yafaray_setConsoleVerbosityLevel", "yafaray_setLogVerbosityLevel", "yafaray_setParamsBadgePosition", "yafaray_getDrawParams",
+    "yafaray_printDebug", "yafaray_printVerbose", "yafaray_printInfo", "yafaray_printParams", "yafaray_printWarning", "yafaray_printError",
+    "yafaray_setOutput2",
     "yafaray_paramsSetPoint", "yafaray_paramsSetString", "yafaray_paramsSetBool", "yafaray_paramsSetInt",
     "yafaray_paramsSetFloat", "yafaray_paramsSetColor", "yafaray_paramsClearAll", "yafaray_paramsStartList",
     "yafaray_paramsPushList", "yafaray_paramsEndList",
@@ -87,6 +95,21 @@ def load():
         "yafaray_addTriangle": (ci, [vp, ci, ci, ci, vp]), "yafaray_smoothMesh": (ci, [vp, C.c_uint, cd]),
         "yafaray_getMeshCornerNormals": (ci, [vp, C.c_uint, C.POINTER(cf), ci]),
         "yafaray_addTriangles": (ci, [vp, ci, C.POINTER(cf), ci, C.POINTER(ci), vp]),
+        "yafaray_startTriMeshPtr": (ci, [vp, C.POINTER(C.c_uint), ci, ci, ci, ci, ci, ci]),
+        "yafaray_addVertexWithOrco": (ci, [vp, cd, cd, cd, cd, cd, cd]), "yafaray_addUv": (ci, [vp, cf, cf]),
+        "yafaray_addTriangleWithUv": (ci, [vp, ci, ci, ci, ci, ci, ci, vp]),
+        "yafaray_startCurveMesh": (ci, [vp, C.c_uint, ci, ci]), "yafaray_endCurveMesh": (ci, [vp, vp, cf, cf, cf]),
+        "yafaray_addInstance": (ci, [vp, C.c_uint, C.POINTER(cf)]),
+        "yafaray_paramsSetColorArray": (None, [vp, cp, C.POINTER(cf), ci]), "yafaray_paramsSetMatrix": (None, [vp, cp, C.POINTER(cf), ci]),
+        "yafaray_paramsSetMatrixD": (None, [vp, cp, C.POINTER(cd), ci]), "yafaray_setInputColorSpace": (None, [vp, cp, cf]),
+        "yafaray_createObject": (C.c_uint, [vp, cp]), "yafaray_createVolumeRegion": (vp, [vp, cp]), "yafaray_createImageHandler": (vp, [vp, cp, ci]),
+        "yafaray_setLoggingAndBadgeSettings": (ci, [vp]), "yafaray_setupRenderPasses": (ci, [vp]), "yafaray_setInteractive": (ci, [vp, ci]),
+        "yafaray_getRenderParameters": (ci, [vp, C.c_char_p, ci]),
+        "yafaray_setConsoleVerbosityLevel": (None, [vp, cp]), "yafaray_setLogVerbosityLevel": (None, [vp, cp]),
+        "yafaray_setParamsBadgePosition": (None, [vp, cp]), "yafaray_getDrawParams": (ci, [vp]),
+        "yafaray_printDebug": (None, [vp, cp]), "yafaray_printVerbose": (None, [vp, cp]), "yafaray_printInfo": (None, [vp, cp]),
+        "yafaray_printParams": (None, [vp, cp]), "yafaray_printWarning": (None, [vp, cp]), "yafaray_printError": (None, [vp, cp]),
+        "yafaray_setOutput2": (None, [vp, C.POINTER(Output)]),
         "yafaray_paramsSetPoint": (None, [vp, cp, cd, cd, cd]), "yafaray_paramsSetString": (None, [vp, cp, cp]),
         "yafaray_paramsSetBool": (None, [vp, cp, ci]), "yafaray_paramsSetInt": (None, [vp, cp, ci]),
         "yafaray_paramsSetFloat": (None, [vp, cp, cd]), "yafaray_paramsSetColor": (None, [vp, cp, cf, cf, cf, cf]),
@@ -187,6 +210,87 @@ class Interface:
 
     def addTriangle(self, a, b, c, mat):
         return self._ok(self._L.yafaray_addTriangle(self._h, a, b, c, mat), "addTriangle")
+
+    def startTriMeshPtr(self, vertices, triangles, has_orco, has_uv=False, type=0, obj_pass_index=0):
+        """-> the id the scene picked (the reference's SWIG typemap returns it the same way)"""
+        mid = C.c_uint(0)
+        ok = self._ok(self._L.yafaray_startTriMeshPtr(self._h, C.byref(mid), vertices, triangles, int(has_orco), int(has_uv), type, obj_pass_index), "startTriMeshPtr")
+        return mid.value if ok else 0
+
+    def addVertexWithOrco(self, x, y, z, ox, oy, oz):
+        return self._L.yafaray_addVertexWithOrco(self._h, x, y, z, ox, oy, oz)
+
+    def addUv(self, u, v):
+        return self._L.yafaray_addUv(self._h, u, v)
+
+    def addTriangleWithUv(self, a, b, c, uv_a, uv_b, uv_c, mat):
+        return self._ok(self._L.yafaray_addTriangleWithUv(self._h, a, b, c, uv_a, uv_b, uv_c, mat), "addTriangle")
+
+    def startCurveMesh(self, id, vertices, obj_pass_index=0):
+        return self._ok(self._L.yafaray_startCurveMesh(self._h, id, vertices, obj_pass_index), "startCurveMesh")
+
+    def endCurveMesh(self, mat, strand_start, strand_end, strand_shape):
+        return self._ok(self._L.yafaray_endCurveMesh(self._h, mat, strand_start, strand_end, strand_shape), "endCurveMesh")
+
+    def addInstance(self, base_object_id, obj_to_world):
+        m = (C.c_float * 16)(*[float(x) for x in np.asarray(obj_to_world, np.float32).reshape(16)])
+        return self._ok(self._L.yafaray_addInstance(self._h, base_object_id, m), "addInstance")
+
+    def createObject(self, name):
+        return self._obj(self._L.yafaray_createObject(self._h, _b(name)), "createObject")
+
+    def createVolumeRegion(self, name):
+        return self._obj(self._L.yafaray_createVolumeRegion(self._h, _b(name)), "createVolumeRegion")
+
+    def createImageHandler(self, name, add_to_table=True):
+        return self._obj(self._L.yafaray_createImageHandler(self._h, _b(name), int(add_to_table)), "createImageHandler")
+
+    def setLoggingAndBadgeSettings(self):
+        return self._ok(self._L.yafaray_setLoggingAndBadgeSettings(self._h), "setLoggingAndBadgeSettings")
+
+    def setupRenderPasses(self):
+        return self._ok(self._L.yafaray_setupRenderPasses(self._h), "setupRenderPasses")
+
+    def setInteractive(self, interactive):
+        return bool(self._L.yafaray_setInteractive(self._h, int(interactive)))
+
+    def getRenderParameters(self):
+        """the render ParamMap as a dict of strings"""
+        n = self._L.yafaray_getRenderParameters(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self._L.yafaray_getRenderParameters(self._h, buf, n + 1)
+        return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+
+    def setConsoleVerbosityLevel(self, level):
+        self._L.yafaray_setConsoleVerbosityLevel(self._h, _b(level))
+
+    def setLogVerbosityLevel(self, level):
+        self._L.yafaray_setLogVerbosityLevel(self._h, _b(level))
+
+    def setParamsBadgePosition(self, position="none"):
+        self._L.yafaray_setParamsBadgePosition(self._h, _b(position))
+
+    def getDrawParams(self):
+        return bool(self._L.yafaray_getDrawParams(self._h))
+
+    def printInfo(self, msg):
+        self._L.yafaray_printInfo(self._h, _b(msg))
+
+    def printWarning(self, msg):
+        self._L.yafaray_printWarning(self._h, _b(msg))
+
+    def printError(self, msg):
+        self._L.yafaray_printError(self._h, _b(msg))
+
+    def setInputColorSpace(self, color_space_string, gamma_val):
+        self._L.yafaray_setInputColorSpace(self._h, _b(color_space_string), gamma_val)
+
+    def paramsSetMatrix(self, name, m, transpose=False):
+        a = (C.c_float * 16)(*[float(x) for x in np.asarray(m, np.float32).reshape(16)])
+        self._L.yafaray_paramsSetMatrix(self._h, _b(name), a, int(transpose))
+
+    def paramsSetMemMatrix(self, name, m, transpose=False):
+        self.paramsSetMatrix(name, m, transpose)
 
     def addTriangles(self, verts, indices, mat):
         v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)

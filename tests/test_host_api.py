@@ -243,3 +243,91 @@ def test_smooth_mesh(angle):
     if angle == 25.0:     # 36 degrees between the cylinder's facets: nothing is smoothed across them, but each quad's two triangles are
         assert (np.abs(got).sum(axis=-1) == 0).any() and (np.abs(got).sum(axis=-1) != 0).any()
     assert yi.endGeometry()
+
+
+def test_every_interface_method_has_a_function_and_refusals_are_loud():
+    """The rest of yafaray4::Interface's surface (include/interface/interface.h:62-128): exporters call several of these
+    unconditionally.  Honoured where the path is concerned, accepted where only logging / decoration is, refused with a
+    getLastError() diagnostic where the request lies outside the scope — never silently dropped."""
+    yi = fresh()
+    assert yi.startScene(0)
+    # refusals: each leaves a diagnostic
+    for call, needle in [
+        (lambda: yi.createObject("sphere1"), "createObject"), (lambda: yi.createVolumeRegion("v"), "createVolumeRegion"),
+        (lambda: yi.createImageHandler("ih"), "createImageHandler"), (lambda: yi.startCurveMesh(5, 10), "startCurveMesh"),
+        (lambda: yi.endCurveMesh(None, 0.1, 0.1, 0.0), "endCurveMesh"), (lambda: yi.addInstance(1, np.eye(4)), "addInstance"),
+    ]:
+        assert not call()
+        assert needle in yi.getLastError(), yi.getLastError()
+    # render passes: the combined pass alone is fine, anything else is refused
+    yi.paramsClearAll(); yi.paramsSet({"pass_enable": False, "pass_Depth": "z-depth-norm"})
+    assert yi.setupRenderPasses()
+    yi.paramsClearAll(); yi.paramsSet({"pass_enable": True, "pass_Depth": "z-depth-norm", "pass_AO": "disabled"})
+    assert not yi.setupRenderPasses() and "pass_Depth" in yi.getLastError()
+    yi.paramsClearAll(); yi.paramsSet({"pass_enable": True, "pass_Depth": "disabled"})
+    assert yi.setupRenderPasses()
+    # accepted
+    yi.paramsClearAll(); yi.paramsSet({"logging_paramsBadgePosition": "top", "logging_title": "t"})
+    assert yi.setLoggingAndBadgeSettings()
+    assert yi.setInteractive(True)
+    yi.setConsoleVerbosityLevel("verbose"); yi.setLogVerbosityLevel("debug"); yi.setParamsBadgePosition("bottom")
+    assert yi.getDrawParams() is False
+    yi.printInfo("info line")
+    # getRenderParameters: the current ParamMap
+    yi.paramsClearAll(); yi.paramsSet({"width": 17, "filter_type": "gauss", "AA_pixelwidth": 1.5})
+    yi.paramsSetMatrix("transform", np.arange(16, dtype=np.float32).reshape(4, 4), transpose=True)
+    rp = yi.getRenderParameters()
+    assert rp["width"] == "17" and rp["filter_type"] == "gauss" and float(rp["AA_pixelwidth"]) == 1.5
+    assert [float(x) for x in rp["transform"].split()] == list(np.arange(16, dtype=np.float32).reshape(4, 4).T.reshape(-1))
+
+
+def test_uv_orco_geometry_and_mesh_ptr():
+    """startTriMeshPtr (the scene picks the id), addVertex with orco, addUv, the UV overload of addTriangle — the geometry
+    calls of a textured export (interface.h:63,67,70,71)."""
+    yi = fresh()
+    yi.startScene(0)
+    yi.paramsClearAll(); yi.paramsSet({"type": "shinydiffusemat"})
+    mat = yi.createMaterial("m")
+    yi.startGeometry()
+    mid = yi.startTriMeshPtr(3, 1, True, True)
+    assert mid >= 1
+    assert yi.addVertex(0, 0, 0) == 0                     # plain vertices stay legal on an orco mesh
+    assert yi.addVertexWithOrco(1, 0, 0, 0.5, 0, 0) == 1 and yi.addVertexWithOrco(0, 1, 0, 0, 0.5, 0) == 2
+    assert yi.addUv(0.0, 0.0) == 0 and yi.addUv(1.0, 0.0) == 1 and yi.addUv(0.0, 1.0) == 2
+    assert yi.addTriangleWithUv(0, 1, 2, 0, 1, 2, mat)
+    assert not yi.addTriangleWithUv(0, 1, 2, 0, 1, 9, mat) and "UV index" in yi.getLastError()
+    assert yi.endTriMesh()
+    assert yi.startTriMesh(yi.getNextFreeId(), 3, 1, False, False)
+    assert yi.addVertexWithOrco(0, 0, 0, 0, 0, 0) == -1 and "orco" in yi.getLastError()
+    assert not yi.addTriangleWithUv(0, 0, 0, 0, 0, 0, mat) and "UV" in yi.getLastError()
+    assert yi.endTriMesh() and yi.endGeometry()
+
+
+def test_input_color_space_converts_colours_on_entry():
+    """Interface::setInputColorSpace + paramsSetColor (interface.cc:247-252,292-301): colours are converted to linear RGB
+    when they are set — sRGB by the piecewise curve with the polynomial pow, XYZ by the D65 matrix, raw by the gamma."""
+    from oracle import pyoracle as po
+    import ctypes as C
+    L = po.lib()
+    yi = fresh()
+    yi.startScene(0)
+    def colour_of(name):
+        return [float(x) for x in yi.getRenderParameters()[name].split()]
+    yi.paramsClearAll()
+    yi.paramsSetColor("a", 0.5, 0.02, 1.0, 0.7)                          # default: raw, gamma 1 -> unchanged
+    assert colour_of("a") == [0.5, np.float32(0.02), 1.0, np.float32(0.7)]
+    yi.setInputColorSpace("sRGB", 1.0)
+    yi.paramsSetColor("b", 0.5, 0.02, 1.0, 0.7)
+    want = [float(L.yor_fpow(C.c_float((np.float32(0.5) + np.float32(0.055)) / np.float32(1.055)), C.c_float(2.4))), float(np.float32(0.02) / np.float32(12.92)),
+            float(L.yor_fpow(C.c_float((np.float32(1.0) + np.float32(0.055)) / np.float32(1.055)), C.c_float(2.4))), float(np.float32(0.7))]
+    np.testing.assert_allclose(colour_of("b"), want, rtol=1e-7)
+    yi.setInputColorSpace("XYZ", 1.0)
+    yi.paramsSetColor("c", 0.2, 0.3, 0.4)
+    m = np.array([[3.2406255, -1.537208, -0.4986286], [-0.9689307, 1.8757561, 0.0415175], [0.0557101, -0.2040211, 1.0569959]], np.float32)
+    np.testing.assert_allclose(colour_of("c")[:3], m @ np.array([0.2, 0.3, 0.4], np.float32), rtol=2e-6)
+    yi.setInputColorSpace("Raw_Manual_Gamma", 2.2)
+    yi.paramsSetColor("d", 0.25, 0.5, 0.75)
+    np.testing.assert_allclose(colour_of("d")[:3], [float(L.yor_fpow(C.c_float(v), C.c_float(2.2))) for v in (0.25, 0.5, 0.75)], rtol=1e-7)
+    yi.setInputColorSpace("LinearRGB", 2.2)
+    yi.paramsSetColor("e", 0.25, 0.5, 0.75)
+    assert colour_of("e")[:3] == [0.25, 0.5, 0.75]

@@ -1064,6 +1064,8 @@ struct yafgpu_scene
 	// serial-state replay tables (WfArgs::replay)
 	uint32_t *rp_flags = nullptr; float *rp_p = nullptr; uint8_t *rp_kill = nullptr, *rp_calls = nullptr; uint32_t *rp_base = nullptr; size_t rp_ents = 0; uint32_t rp_prob = 0;
 	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
+	std::vector<uint32_t> h_listed;                      // pixels of a masked (adaptive) pass, in tile order
+	std::vector<uint32_t> h_seg_begin, h_seg_seed;       // every chunk's segments of the pass, uploaded once (scene-owned: an async copy may read them late)
 	const volatile int32_t *abort_flag = nullptr;      // polled between chunks and passes (yafgpu_scene_set_abort_flag)
 	bool aborted() const { return abort_flag && *abort_flag != 0; }
 	bool profiling = false;
@@ -1463,10 +1465,13 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	pp.assign(1, 0u);
 	for(const int4 &r : s->h_tiles) pp.push_back(pp.back() + (uint32_t)(r.z * r.w));
 	// a resample mask (adaptive pass): the pixels of this shard's tiles that are flagged, in tile order
-	std::vector<uint32_t> listed, listed_prefix(1, 0u);
+	std::vector<uint32_t> &listed = s->h_listed;        // scene-owned: uploaded per chunk with async copies
+	std::vector<uint32_t> listed_prefix(1, 0u);
 	const bool masked = rp.resample_mask != nullptr;
 	if(masked)
 	{
+		HIP_OK(hipStreamSynchronize(stream));             // the previous pass's uploads of the list have been read
+		listed.clear();
 		for(const int4 &r : s->h_tiles)
 		{
 			for(int y = r.y; y < r.y + r.w; ++y)
@@ -1563,7 +1568,28 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			HIP_OK(hipMalloc((void **)&s->rp_base, (size_t)s->wf_cap * sizeof(uint32_t)));
 			s->rp_ents = ents; s->rp_prob = n_prob;
 		}
-		const size_t segs = s->h_tiles.size() + 1;
+		// every chunk's tiles as segments — first pixel of each (chunk-local) and the seed of its Random:
+		// rand() + offset * (resx * tile.y + tile.x) + 123 (integrator_tiled.cc:319), offset = pass offset + base sampling
+		// offset (:203,263).  One table for the whole pass, uploaded once: chunk k reads its slice [seg_off[k], ...).
+		HIP_OK(hipStreamSynchronize(stream));        // the previous pass's upload of the table has been read
+		s->h_seg_begin.clear(); s->h_seg_seed.clear();
+		{
+			const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size;
+			const uint32_t offset = rp.pass_offset + rp.base_sampling_offset;
+			for(const Chunk &ch : chunks)
+			{
+				for(uint32_t t = ch.tile_begin; t <= ch.tile_end; ++t) s->h_seg_begin.push_back(tile_px[t] - ch.pixel_begin);
+				for(uint32_t t = ch.tile_begin; t < ch.tile_end; ++t)
+				{
+					const int4 &r = s->h_tiles[t];
+					const int t_global = ((r.y - rp.ystart) / rp.tile_size) * ntx + (r.x - rp.xstart) / rp.tile_size;
+					const uint32_t rnd = rp.tile_rand ? (uint32_t)rp.tile_rand[t_global] : 0u;
+					s->h_seg_seed.push_back(rnd + offset * ((uint32_t)s->dev.cam.resx * (uint32_t)r.y + (uint32_t)r.x) + 123u);
+				}
+				s->h_seg_seed.push_back(0u);           // keeps the two tables aligned (n + 1 entries per chunk)
+			}
+		}
+		const size_t segs = s->h_seg_begin.size();
 		if(segs > s->rp_segs)
 		{
 			HIP_OK(hipStreamSynchronize(stream));
@@ -1574,6 +1600,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			HIP_OK(hipMalloc((void **)&s->rp_seg_total, segs * sizeof(uint32_t)));
 			s->rp_segs = segs;
 		}
+		HIP_OK(hipMemcpyAsync(s->rp_seg_begin, s->h_seg_begin.data(), segs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		HIP_OK(hipMemcpyAsync(s->rp_seg_seed, s->h_seg_seed.data(), segs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		if(!s->rp_counter) HIP_OK(hipMalloc((void **)&s->rp_counter, sizeof(uint32_t)));
 		// correlative_sample_number_ is zeroed once per render, before its first pass (integrator_tiled.cc:192-194)
 		if(!rp.accumulate) HIP_OK(hipMemsetAsync(s->rp_counter, 0, sizeof(uint32_t), stream));
@@ -1637,7 +1665,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		}
 		return 0;
 	};
-	std::vector<uint32_t> seg_begin, seg_seed;
+	size_t seg_off = 0;
 	for(const Chunk &ch : chunks)
 	{
 		if(s->aborted()) return fail(-30, "aborted");
@@ -1727,32 +1755,18 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * n_ps * sizeof(uint32_t), stream));
 			if((rc = run(iters_record, true))) return rc;
 			a.ra.counters = keep;
-			// the tiles of the chunk as segments, each with the seed of its Random:
-			// rand() + offset * (resx * tile.y + tile.x) + 123 (integrator_tiled.cc:319), offset = pass offset + base sampling offset (:203,263)
 			const uint32_t n_seg = ch.tile_end - ch.tile_begin;
-			seg_begin.assign(n_seg + 1, 0u); seg_seed.assign(n_seg + 1, 0u);
-			const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size;
-			const uint32_t offset = rp.pass_offset + rp.base_sampling_offset;
-			for(uint32_t k = 0; k <= n_seg; ++k) seg_begin[k] = tile_px[ch.tile_begin + k] - ch.pixel_begin;
-			for(uint32_t k = 0; k < n_seg; ++k)
-			{
-				const int4 &r = s->h_tiles[ch.tile_begin + k];
-				const int t_global = ((r.y - rp.ystart) / rp.tile_size) * ntx + (r.x - rp.xstart) / rp.tile_size;
-				const uint32_t rnd = rp.tile_rand ? (uint32_t)rp.tile_rand[t_global] : 0u;
-				seg_seed[k] = rnd + offset * ((uint32_t)s->dev.cam.resx * (uint32_t)r.y + (uint32_t)r.x) + 123u;
-			}
-			HIP_OK(hipMemcpyAsync(s->rp_seg_begin, seg_begin.data(), (n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-			HIP_OK(hipMemcpyAsync(s->rp_seg_seed, seg_seed.data(), (n_seg + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 			ReplayArgs r{};
-			r.seg_begin = s->rp_seg_begin; r.seg_seed = s->rp_seg_seed; r.n_seg = n_seg; r.spp = spp; r.n_paths = n_ps; r.n_prob = n_prob;
+			r.seg_begin = s->rp_seg_begin + seg_off; r.seg_seed = s->rp_seg_seed + seg_off; r.n_seg = n_seg; r.spp = spp; r.n_paths = n_ps; r.n_prob = n_prob;
 			r.bounces = (uint32_t)std::max(rp.bounces, 1);
 			r.ev_flags = s->rp_flags; r.ev_p = s->rp_p; r.ev_kill = s->rp_kill; r.ev_calls = s->rp_calls; r.lc_base = s->rp_base;
-			r.seg_total = s->rp_seg_total; r.lc_counter = s->rp_counter;
+			r.seg_total = s->rp_seg_total + seg_off; r.lc_counter = s->rp_counter;
 			if((rc = timed(3, [&] {
 				hipLaunchKernelGGL(wf_replay_tiles, dim3(n_seg), dim3(kWave), 0, stream, r);
 				hipLaunchKernelGGL(wf_replay_bases, dim3(1), dim3(1), 0, stream, r);
 				hipLaunchKernelGGL(wf_replay_samples, dim3(n_seg), dim3(kWave), 0, stream, r); }))) return rc;
 			a.replay = 2;
+			seg_off += n_seg + 1;
 		}
 		if((rc = run(iters, false))) return rc;
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);

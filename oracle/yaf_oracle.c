@@ -449,6 +449,13 @@ typedef struct
 	/* glass (material_glass.cc:32-49) and mirror (material_glass.h:74-79) */
 	float ior; rgb filter_color, spec_refl_color; int fake_shadow; unsigned tm_flags;
 	rgb ref_col;
+	/* shader nodes: the list in evaluation order and the node each slot reads (-1: none) */
+	int n_nodes; struct node_s *nodes;
+	int sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
+	float ior_base;                       /* ior_, for the IOR shader (material_shiny_diffuse.cc:258-262) */
+	/* values a resolved copy carries (mat_resolve): orenNayar with a texture sigma computes A and B in double (:230-235) */
+	int oren_tex; double oren_ad, oren_bd;
+	int has_diffuse_refl; float diffuse_refl;
 } mat_t;
 
 typedef struct
@@ -485,6 +492,9 @@ struct yor_scene
 	uint32_t *leaf_refs; uint32_t n_refs, cap_refs;
 	v3 tb_a, tb_g; /* tree bound */
 	double build_seconds;
+	/* image textures + per-triangle texture coordinates (row N2) */
+	int n_tex; struct tex_s *tex;
+	float *tri_uv, *tri_orco;
 };
 
 /* per-thread counters */
@@ -905,9 +915,9 @@ static int brute_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist)
 
 /* ------------------------------------------------------------------ surface point
  * the subset of SurfacePoint (surface.h:58-100) the path uses */
-typedef struct { v3 p, n, ng, nu, nv; int mat; } sp_t;
+typedef struct { v3 p, n, ng, nu, nv; int mat; int tri; float u, v; v3 orco_p, orco_ng; int has_uv, has_orco; } sp_t;
 
-/* Triangle::getSurface, triangle.cc:30-133 (no UV, no orco branch) */
+/* Triangle::getSurface, triangle.cc:30-133 (dPdU / dPdV are only used by bump mapping: not restated) */
 static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, sp_t *sp)
 {
 	const tri_t *tr = &s->tris[ti];
@@ -920,6 +930,24 @@ static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, 
 		sp->n = vnormalize(sp->n);
 	}
 	else sp->n = sp->ng;
+	sp->tri = ti;
+	if(s->tri_orco)
+	{	/* :46-57 */
+		const float *q = s->tri_orco + 9 * (size_t)ti;
+		v3 p_0 = V(q[0], q[1], q[2]), p_1 = V(q[3], q[4], q[5]), p_2 = V(q[6], q[7], q[8]);
+		sp->orco_p = vadd(vadd(vmul(p_0, u), vmul(p_1, v)), vmul(p_2, w));
+		sp->orco_ng = vnormalize(vcross(vsub(p_1, p_0), vsub(p_2, p_0)));
+		sp->has_orco = 1;
+	}
+	else { sp->orco_p = hit; sp->has_orco = 0; sp->orco_ng = sp->ng; }      /* :58-63 */
+	if(s->tri_uv)
+	{	/* :69-79 */
+		const float *q = s->tri_uv + 6 * (size_t)ti;
+		sp->u = u * q[0] + v * q[2] + w * q[4];
+		sp->v = u * q[1] + v * q[3] + w * q[5];
+		sp->has_uv = 1;
+	}
+	else { sp->u = 0.f; sp->v = 0.f; sp->has_uv = 0; }                      /* :103-111 */
 	sp->mat = tr->mat;
 	sp->p = hit;
 	create_cs(sp->n, &sp->nu, &sp->nv);
@@ -973,6 +1001,522 @@ static int scene_is_shadowed_ts(const yor_scene *s, v3 from, v3 dir, float tmin,
 	return r;
 }
 
+/* ------------------------------------------------------------------ image textures (row N2)
+ * ImageTexture, src/texture/texture_image.cc; adjustments include/texture/texture.h:202-275 */
+typedef struct tex_s
+{
+	int w, h; float *px;
+	int interp, clip, xrepeat, yrepeat, rot90, mirror_x, mirror_y, checker_even, checker_odd;
+	float checker_dist;
+	int cropx, cropy; float cropminx, cropmaxx, cropminy, cropmaxy;
+	int adj_set, adj_clamp; float adj_int, adj_con, adj_sat, adj_hue, adj_r, adj_g, adj_b;
+	int color_space; float gamma;
+} tex_t;
+typedef struct { float r, g, b, a; } rgba_t;
+static inline rgba_t RA(float r, float g, float b, float a) { rgba_t c = {r, g, b, a}; return c; }
+enum { TCL_EXTEND = 0, TCL_CLIP = 1, TCL_CLIPCUBE = 2, TCL_REPEAT = 3, TCL_CHECKER = 4 };
+
+static void tex_configure(tex_t *t, const yor_texture_desc *d)
+{
+	memset(t, 0, sizeof *t);
+	t->w = d->width; t->h = d->height;
+	size_t n = (size_t)(d->width > 0 ? d->width : 0) * (size_t)(d->height > 0 ? d->height : 0) * 4;
+	t->px = (float *)malloc((n ? n : 1) * sizeof(float));
+	if(n) memcpy(t->px, d->texels, n * sizeof(float));
+	t->interp = d->interpolate; t->clip = d->clip; t->xrepeat = d->xrepeat; t->yrepeat = d->yrepeat; t->rot90 = d->rot90;
+	t->mirror_x = d->mirror_x; t->mirror_y = d->mirror_y; t->checker_even = d->checker_even; t->checker_odd = d->checker_odd;
+	t->checker_dist = d->checker_dist;
+	/* setCrop :217-222 */
+	t->cropminx = d->cropmin_x; t->cropmaxx = d->cropmax_x; t->cropminy = d->cropmin_y; t->cropmaxy = d->cropmax_y;
+	t->cropx = ((t->cropminx != 0.0) || (t->cropmaxx != 1.0));
+	t->cropy = ((t->cropminy != 0.0) || (t->cropmaxy != 1.0));
+	/* setAdjustments texture.h:142-200 */
+	t->adj_int = d->adj_intensity; t->adj_con = d->adj_contrast; t->adj_sat = d->adj_saturation; t->adj_hue = d->adj_hue / 60.f;
+	t->adj_clamp = d->adj_clamp; t->adj_r = d->adj_red; t->adj_g = d->adj_green; t->adj_b = d->adj_blue;
+	t->adj_set = d->adj_intensity != 1.f || d->adj_contrast != 1.f || d->adj_saturation != 1.f || d->adj_hue != 0.f ||
+	             d->adj_red != 1.f || d->adj_green != 1.f || d->adj_blue != 1.f || d->adj_clamp;
+	t->color_space = d->color_space; t->gamma = d->gamma;
+}
+
+static inline rgba_t tex_pixel(const tex_t *t, int x, int y)
+{
+	const float *q = t->px + 4 * ((size_t)y * (size_t)t->w + (size_t)x);
+	return RA(q[0], q[1], q[2], q[3]);
+}
+
+/* ImageTexture::doMapping :119-215; returns `outside` */
+static int tex_do_mapping(const tex_t *t, v3 *texpt)
+{
+	int outside = 0;
+	texpt->x = 0.5f * texpt->x + 0.5f; texpt->y = 0.5f * texpt->y + 0.5f; texpt->z = 0.5f * texpt->z + 0.5f;
+	if(t->clip == TCL_REPEAT)
+	{
+		if(t->xrepeat > 1) texpt->x *= (float)t->xrepeat;
+		if(t->yrepeat > 1) texpt->y *= (float)t->yrepeat;
+		if(t->mirror_x && (int)ceilf(texpt->x) % 2 == 0) texpt->x = -texpt->x;
+		if(t->mirror_y && (int)ceilf(texpt->y) % 2 == 0) texpt->y = -texpt->y;
+		if(texpt->x > 1.f) texpt->x -= (int)texpt->x;
+		else if(texpt->x < 0.f) texpt->x += 1 - (int)texpt->x;
+		if(texpt->y > 1.f) texpt->y -= (int)texpt->y;
+		else if(texpt->y < 0.f) texpt->y += 1 - (int)texpt->y;
+	}
+	if(t->cropx) texpt->x = t->cropminx + texpt->x * (t->cropmaxx - t->cropminx);
+	if(t->cropy) texpt->y = t->cropminy + texpt->y * (t->cropmaxy - t->cropminy);
+	if(t->rot90) { float tmp = texpt->x; texpt->x = texpt->y; texpt->y = tmp; }
+	switch(t->clip)
+	{
+		case TCL_CLIPCUBE:
+			if((texpt->x < 0) || (texpt->x > 1) || (texpt->y < 0) || (texpt->y > 1) || (texpt->z < -1) || (texpt->z > 1)) outside = 1;
+			break;
+		case TCL_CHECKER:
+		{
+			int xs = (int)floor(texpt->x), ys = (int)floor(texpt->y);
+			texpt->x -= xs; texpt->y -= ys;
+			if(!t->checker_odd && !((xs + ys) & 1)) { outside = 1; break; }
+			if(!t->checker_even && ((xs + ys) & 1)) { outside = 1; break; }
+			if(t->checker_dist < 1.0)
+			{
+				texpt->x = (float)(((double)texpt->x - 0.5) / (1.0 - (double)t->checker_dist) + 0.5);
+				texpt->y = (float)(((double)texpt->y - 0.5) / (1.0 - (double)t->checker_dist) + 0.5);
+			}
+		}	/* falls through to clip */
+		/* fall through */
+		case TCL_CLIP:
+			if((texpt->x < 0) || (texpt->x > 1) || (texpt->y < 0) || (texpt->y > 1)) outside = 1;
+			break;
+		case TCL_EXTEND:
+			if(texpt->x > 0.99999f) texpt->x = 0.99999f; else if(texpt->x < 0) texpt->x = 0;
+			if(texpt->y > 0.99999f) texpt->y = 0.99999f; else if(texpt->y < 0) texpt->y = 0;
+			/* falls through */
+		default: outside = 0;
+	}
+	return outside;
+}
+
+/* findTextureInterpolationCoordinates :224-289 */
+static void tex_interp_coords(int *c0, int *c1, int *c2, int *c3, float *dec, float cf, int res, int repeat, int mirror)
+{
+	if(repeat)
+	{
+		*c1 = ((int)cf) % res;
+		if(mirror)
+		{
+			if(cf < 0.f) { *c0 = 1 % res; *c2 = *c1; *c3 = *c0; *dec = -cf; }
+			else if(cf >= res - 1.f) { *c0 = (res + res - 1) % res; *c2 = *c1; *c3 = *c0; *dec = cf - ((int)cf); }
+			else
+			{
+				*c0 = (res + *c1 - 1) % res;
+				*c2 = *c1 + 1; if(*c2 >= res) *c2 = (res + res - *c2) % res;
+				*c3 = *c1 + 2; if(*c3 >= res) *c3 = (res + res - *c3) % res;
+				*dec = cf - ((int)cf);
+			}
+		}
+		else
+		{
+			if(cf > 0.f) { *c0 = (res + *c1 - 1) % res; *c2 = (*c1 + 1) % res; *c3 = (*c1 + 2) % res; *dec = cf - ((int)cf); }
+			else { *c0 = 1 % res; *c2 = (res - 1) % res; *c3 = (res - 2) % res; *dec = -cf; }
+		}
+	}
+	else
+	{
+		int ci = (int)cf;
+		*c1 = ci < 0 ? 0 : (ci > res - 1 ? res - 1 : ci);
+		if(cf > 0.f) *c2 = (*c1 + 1 < res - 1) ? *c1 + 1 : res - 1; else *c2 = 0;
+		*c0 = (*c1 - 1 > 0) ? *c1 - 1 : 0;
+		*c3 = (*c2 + 1 < res - 1) ? *c2 + 1 : res - 1;
+		*dec = (float)((double)cf - floor((double)cf));
+	}
+}
+
+/* noInterpolation :291-305, bilinearInterpolation :307-330 */
+static rgba_t tex_interpolate(const tex_t *t, v3 p)
+{
+	int resx = t->w, resy = t->h;
+	int x0, x1, x2, x3, y0, y1, y2, y3; float dx, dy;
+	const int rep = t->clip == TCL_REPEAT;
+	if(t->interp == 0)
+	{
+		float xf = ((float)resx * (float)((double)p.x - floor((double)p.x)));
+		float yf = ((float)resy * (float)((double)p.y - floor((double)p.y)));
+		tex_interp_coords(&x0, &x1, &x2, &x3, &dx, xf, resx, rep, t->mirror_x);
+		tex_interp_coords(&y0, &y1, &y2, &y3, &dy, yf, resy, rep, t->mirror_y);
+		return tex_pixel(t, x1, y1);
+	}
+	float xf = ((float)resx * (float)((double)p.x - floor((double)p.x))) - 0.5f;
+	float yf = ((float)resy * (float)((double)p.y - floor((double)p.y))) - 0.5f;
+	tex_interp_coords(&x0, &x1, &x2, &x3, &dx, xf, resx, rep, t->mirror_x);
+	tex_interp_coords(&y0, &y1, &y2, &y3, &dy, yf, resy, rep, t->mirror_y);
+	rgba_t c11 = tex_pixel(t, x1, y1), c21 = tex_pixel(t, x2, y1), c12 = tex_pixel(t, x1, y2), c22 = tex_pixel(t, x2, y2);
+	float w11 = (1 - dx) * (1 - dy), w12 = (1 - dx) * dy, w21 = dx * (1 - dy), w22 = dx * dy;
+	/* (w_11 * c_11) + (w_12 * c_12) + (w_21 * c_21) + (w_22 * c_22), left to right */
+	rgba_t o;
+	o.r = ((w11 * c11.r + w12 * c12.r) + w21 * c21.r) + w22 * c22.r;
+	o.g = ((w11 * c11.g + w12 * c12.g) + w21 * c21.g) + w22 * c22.g;
+	o.b = ((w11 * c11.b + w12 * c12.b) + w21 * c21.b) + w22 * c22.b;
+	o.a = ((w11 * c11.a + w12 * c12.a) + w21 * c21.a) + w22 * c22.a;
+	return o;
+}
+
+/* Rgb::rgbToHsv / hsvToRgb, color.h (used by the saturation / hue adjustments) */
+static void rgb_to_hsv(rgba_t c, float *h, float *s, float *v)
+{
+	float r_1 = fmaxf_(c.r, 0.f), g_1 = fmaxf_(c.g, 0.f), b_1 = fmaxf_(c.b, 0.f);
+	float max_component = fmaxf_(fmaxf_(r_1, g_1), b_1), min_component = fminf_(fminf_(r_1, g_1), b_1);
+	float range = max_component - min_component;
+	*v = max_component;
+	if(fabsf(range) < 1.0e-6f) { *h = 0.f; *s = 0.f; }
+	else if(max_component == r_1) { *h = fmodf((g_1 - b_1) / range, 6.f); *s = range / fmaxf_(*v, 1.0e-6f); }
+	else if(max_component == g_1) { *h = ((b_1 - r_1) / range) + 2.f; *s = range / fmaxf_(*v, 1.0e-6f); }
+	else if(max_component == b_1) { *h = ((r_1 - g_1) / range) + 4.f; *s = range / fmaxf_(*v, 1.0e-6f); }
+	else { *h = 0.f; *s = 0.f; *v = 0.f; }
+	if(*h < 0.f) *h += 6.f;
+}
+static void hsv_to_rgb(rgba_t *o, float h, float s, float v)
+{
+	float c = v * s;
+	float x = c * (1.f - fabsf(fmodf(h, 2.f) - 1.f));
+	float m = v - c;
+	float r_1 = 0.f, g_1 = 0.f, b_1 = 0.f;
+	if(h >= 0.f && h < 1.f) { r_1 = c; g_1 = x; b_1 = 0.f; }
+	else if(h >= 1.f && h < 2.f) { r_1 = x; g_1 = c; b_1 = 0.f; }
+	else if(h >= 2.f && h < 3.f) { r_1 = 0.f; g_1 = c; b_1 = x; }
+	else if(h >= 3.f && h < 4.f) { r_1 = 0.f; g_1 = x; b_1 = c; }
+	else if(h >= 4.f && h < 5.f) { r_1 = x; g_1 = 0.f; b_1 = c; }
+	else if(h >= 5.f && h < 6.f) { r_1 = c; g_1 = 0.f; b_1 = x; }
+	o->r = r_1 + m; o->g = g_1 + m; o->b = b_1 + m;
+}
+
+static rgba_t tex_clamp_rgb0(rgba_t c) { if(c.r < 0.f) c.r = 0.f; if(c.g < 0.f) c.g = 0.f; if(c.b < 0.f) c.b = 0.f; return c; }
+/* Texture::applyAdjustments texture.h:202-255 */
+static rgba_t tex_apply_adjustments(const tex_t *t, rgba_t c)
+{
+	if(!t->adj_set) return c;
+	rgba_t ret = c;
+	if(t->adj_int != 1.f || t->adj_con != 1.f)
+	{
+		ret.r = (c.r - 0.5f) * t->adj_con + t->adj_int - 0.5f;
+		ret.g = (c.g - 0.5f) * t->adj_con + t->adj_int - 0.5f;
+		ret.b = (c.b - 0.5f) * t->adj_con + t->adj_int - 0.5f;
+	}
+	if(t->adj_clamp) ret = tex_clamp_rgb0(ret);
+	/* applyColorAdjustments */
+	if(t->adj_r != 1.f) ret.r *= t->adj_r;
+	if(t->adj_g != 1.f) ret.g *= t->adj_g;
+	if(t->adj_b != 1.f) ret.b *= t->adj_b;
+	if(t->adj_clamp) ret = tex_clamp_rgb0(ret);
+	if(t->adj_sat != 1.f || t->adj_hue != 0.f)
+	{
+		float h = 0.f, sa = 0.f, v = 0.f;
+		rgb_to_hsv(ret, &h, &sa, &v);
+		sa *= t->adj_sat;
+		h += t->adj_hue;
+		if(h < 0.f) h += 6.f; else if(h > 6.f) h -= 6.f;
+		hsv_to_rgb(&ret, h, sa, v);
+		if(t->adj_clamp) ret = tex_clamp_rgb0(ret);
+	}
+	return ret;
+}
+static float tex_apply_ic_float(const tex_t *t, float f)
+{	/* applyIntensityContrastAdjustments(float) :257-274 */
+	if(!t->adj_set) return f;
+	float ret = f;
+	if(t->adj_int != 1.f || t->adj_con != 1.f) ret = (f - 0.5f) * t->adj_con + t->adj_int - 0.5f;
+	if(t->adj_clamp) { if(ret < 0.f) ret = 0.f; else if(ret > 1.f) ret = 1.f; }
+	return ret;
+}
+
+/* ImageTexture::getColor :75-88 */
+static rgba_t tex_get_color(const tex_t *t, v3 p)
+{
+	v3 p_1 = V(p.x, -p.y, p.z);
+	if(tex_do_mapping(t, &p_1)) return RA(0.f, 0.f, 0.f, 0.f);
+	return tex_apply_adjustments(t, tex_interpolate(t, p_1));
+}
+/* sRgbFromLinearRgb color.h:359-364, colorSpaceFromLinearRgb :388-411 */
+static rgba_t color_space_from_linear(rgba_t c, int color_space, float gamma)
+{
+	if(color_space == 0)
+	{
+		c.r = (c.r <= 0.0031308f) ? (c.r * 12.92f) : ((1.055f * yor_fpow(c.r, 0.416667f)) - 0.055f);
+		c.g = (c.g <= 0.0031308f) ? (c.g * 12.92f) : ((1.055f * yor_fpow(c.g, 0.416667f)) - 0.055f);
+		c.b = (c.b <= 0.0031308f) ? (c.b * 12.92f) : ((1.055f * yor_fpow(c.b, 0.416667f)) - 0.055f);
+	}
+	else if(color_space == 1)
+	{
+		float r = c.r, g = c.g, b = c.b;
+		c.r = 0.412400f * r + 0.357600f * g + 0.180500f * b;
+		c.g = 0.212600f * r + 0.715200f * g + 0.072200f * b;
+		c.b = 0.019300f * r + 0.119200f * g + 0.950500f * b;
+	}
+	else if(color_space == 3 && gamma != 1.f)
+	{
+		if(gamma <= 0.f) gamma = 1.0e-2f;
+		float inv = 1.f / gamma;
+		c.r = yor_fpow(c.r, inv); c.g = yor_fpow(c.g, inv); c.b = yor_fpow(c.b, inv);
+	}
+	return c;
+}
+/* Texture::getFloat texture.h:51 = applyIntensityContrastAdjustments(getRawColor(p).col2Bri()); getRawColor :90-104 */
+static float tex_get_float(const tex_t *t, v3 p)
+{
+	rgba_t c = color_space_from_linear(tex_get_color(t, p), t->color_space, t->gamma);
+	return tex_apply_ic_float(t, (0.2126f * c.r + 0.7152f * c.g + 0.0722f * c.b));
+}
+
+/* ------------------------------------------------------------------ shader nodes (row N2)
+ * TextureMapperNode / ValueNode / MixNode (shader_node_basic.cc), LayerNode (shader_node_layer.cc),
+ * textureRgbBlend__ / textureValueBlend__ (shader_node.h:115-223) */
+typedef struct node_s
+{
+	int type;
+	int tex, texco, mapping, map_x, map_y, map_z; v3 scale, offset; float mtx[16]; int do_scalar;
+	rgba_t color; float value;
+	int mode; float cfactor; int input1, input2, factor; rgba_t col1, col2;
+	int input, upper; unsigned texflag; float colfac, valfac, def_val; rgba_t def_col, upper_col; float upper_val;
+	int do_color, do_scalar_l, color_input, use_alpha;
+} node_t;
+typedef struct { rgba_t col; float f; } node_result_t;
+enum { TXF_RGBTOINT = 1, TXF_STENCIL = 2, TXF_NEGATIVE = 4, TXF_ALPHAMIX = 8 };
+enum { MN_MIX = 0, MN_ADD, MN_MULT, MN_SUB, MN_SCREEN, MN_DIV, MN_DIFF, MN_DARK, MN_LIGHT, MN_OVERLAY };
+enum { TC_UV = 0, TC_GLOB, TC_ORCO, TC_TRAN, TC_NOR, TC_REFL, TC_WIN, TC_STICK, TC_STRESS, TC_TAN };
+
+static void node_configure(node_t *n, const yor_node_desc *d)
+{
+	memset(n, 0, sizeof *n);
+	n->type = d->type;
+	n->tex = d->texture; n->texco = d->texco; n->mapping = d->mapping;
+	int map[3];
+	for(int i = 0; i < 3; ++i) { map[i] = d->proj[i]; if(map[i] < 0) map[i] = 0; if(map[i] > 3) map[i] = 3; }   /* :406 */
+	n->map_x = map[0]; n->map_y = map[1]; n->map_z = map[2];
+	n->scale = V(d->scale[0], d->scale[1], d->scale[2]);
+	n->offset = V(2 * d->offset[0], 2 * d->offset[1], 2 * d->offset[2]);                                       /* :411 */
+	memcpy(n->mtx, d->mtx, sizeof n->mtx);
+	n->do_scalar = d->do_scalar;
+	n->color = RA(d->color[0], d->color[1], d->color[2], d->color[3]); n->value = d->scalar;
+	n->mode = d->mode; n->cfactor = d->cfactor; n->input1 = d->input1; n->input2 = d->input2; n->factor = d->factor;
+	n->col1 = RA(d->col1[0], d->col1[1], d->col1[2], d->col1[3]); n->col2 = RA(d->col2[0], d->col2[1], d->col2[2], d->col2[3]);
+	n->input = d->input; n->upper = d->upper_layer;
+	n->texflag = (d->no_rgb ? TXF_RGBTOINT : 0) | (d->stencil ? TXF_STENCIL : 0) | (d->negative ? TXF_NEGATIVE : 0) | (d->use_alpha ? TXF_ALPHAMIX : 0);
+	n->colfac = d->colfac; n->valfac = d->valfac; n->def_val = d->def_val;
+	n->def_col = RA(d->def_col[0], d->def_col[1], d->def_col[2], 1.f);
+	n->upper_col = RA(d->upper_col[0], d->upper_col[1], d->upper_col[2], d->upper_col[3]); n->upper_val = d->upper_val;
+	n->do_color = d->do_color; n->do_scalar_l = d->do_scalar_l; n->color_input = d->color_input; n->use_alpha = d->use_alpha;
+}
+
+/* fAcos__ util_math_optimizations.h:255-261 */
+static float f_acos(float x) { if(x <= -1.0) return (float)Y_M_PI; else if(x >= 1.0) return 0.0f; else return (float)acos((double)x); }
+#define Y_M_1_PI 0.31830988618379067154
+
+/* TextureMapperNode::doMapping :127-155 */
+static v3 mapper_do_mapping(const node_t *n, v3 p, v3 ng)
+{
+	v3 texpt = p;
+	if(n->texco == TC_UV) texpt = V(2.0f * texpt.x - 1.0f, 2.0f * texpt.y - 1.0f, texpt.z);
+	float texmap[4] = {0, texpt.x, texpt.y, texpt.z};
+	texpt.x = texmap[n->map_x]; texpt.y = texmap[n->map_y]; texpt.z = texmap[n->map_z];
+	switch(n->mapping)
+	{
+		case 2:
+		{	/* tubemap__ :62-74 */
+			v3 res; res.y = texpt.z;
+			float d = texpt.x * texpt.x + texpt.y * texpt.y;
+			if(d > 0) { res.z = (float)(1.0 / (double)yor_fsqrt(d)); res.x = (float)(-atan2((double)texpt.x, (double)texpt.y) * Y_M_1_PI); }
+			else res.x = res.z = 0;
+			texpt = res; break;
+		}
+		case 3:
+		{	/* spheremap__ :77-88 */
+			v3 res = V(0.f, 0.f, 0.f);
+			float d = texpt.x * texpt.x + texpt.y * texpt.y + texpt.z * texpt.z;
+			if(d > 0)
+			{
+				res.z = yor_fsqrt(d);
+				if((texpt.x != 0) && (texpt.y != 0)) res.x = (float)(-atan2((double)texpt.x, (double)texpt.y) * Y_M_1_PI);
+				res.y = (float)((double)1.0f - (double)2.0f * ((double)f_acos(texpt.z / res.z) * Y_M_1_PI));
+			}
+			texpt = res; break;
+		}
+		case 1:
+		{	/* cubemap__ :91-115 */
+			static const int ma[3][3] = {{1, 2, 0}, {0, 2, 1}, {0, 1, 2}};
+			int axis;
+			if(fabsf(ng.z) >= fabsf(ng.x) && fabsf(ng.z) >= fabsf(ng.y)) axis = 2;
+			else if(fabsf(ng.y) >= fabsf(ng.x) && fabsf(ng.y) >= fabsf(ng.z)) axis = 1;
+			else axis = 0;
+			float pc[3] = {texpt.x, texpt.y, texpt.z};
+			texpt = V(pc[ma[axis][0]], pc[ma[axis][1]], pc[ma[axis][2]]);
+			break;
+		}
+		default: break;
+	}
+	texpt = V(texpt.x * n->scale.x + n->offset.x, texpt.y * n->scale.y + n->offset.y, texpt.z * n->scale.z + n->offset.z);
+	return texpt;
+}
+
+static v3 mtx_point(const float *m, v3 p)      /* Matrix4 * Point3: with translation */
+{
+	return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+static v3 mtx_vec(const float *m, v3 v)        /* Matrix4 * Vec3: without */
+{
+	return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+/* one pass over a material's nodes in evaluation order (NodeMaterial::evalNodes, material_node.cc:83-86) */
+static void nodes_eval(const node_t *nodes, int n_nodes, const tex_t *tex, int n_tex, const camera_t *cam, const sp_t *sp, node_result_t *stack)
+{
+	for(int k = 0; k < n_nodes; ++k)
+	{
+		const node_t *n = &nodes[k];
+		node_result_t res; res.col = RA(0.f, 0.f, 0.f, 0.f); res.f = 0.f;
+		if(n->type == YOR_NODE_TEXTURE_MAPPER)
+		{	/* getCoords :163-190, eval :193-229 (no mipmaps) */
+			v3 texpt, ng;
+			switch(n->texco)
+			{
+				case TC_UV: texpt = V(sp->u, sp->v, 0.f); ng = sp->ng; break;
+				case TC_ORCO: texpt = sp->orco_p; ng = sp->orco_ng; break;
+				case TC_TRAN: texpt = mtx_point(n->mtx, sp->p); ng = mtx_vec(n->mtx, sp->ng); break;
+				case TC_WIN:
+				{	/* PerspectiveCamera::screenproject camera_perspective.cc:158-173 */
+					v3 dir = vsub(sp->p, cam->position);
+					float dx = vdot(dir, cam->cam_x), dy = vdot(dir, cam->cam_y), dz = vdot(dir, cam->cam_z);
+					texpt = V(2.0f * dx * cam->focal / dz, -2.0f * dy * cam->focal / (dz * cam->aspect_ratio), 0.f);
+					ng = sp->ng; break;
+				}
+				case TC_NOR: texpt = V(vdot(sp->n, cam->cam_x), -vdot(sp->n, cam->cam_y), 0.f); ng = sp->ng; break;
+				default: texpt = sp->p; ng = sp->ng; break;
+			}
+			texpt = mapper_do_mapping(n, texpt, ng);
+			if(n->tex >= 0 && n->tex < n_tex)
+			{
+				res.col = tex_get_color(&tex[n->tex], texpt);
+				res.f = n->do_scalar ? tex_get_float(&tex[n->tex], texpt) : 0.f;
+			}
+		}
+		else if(n->type == YOR_NODE_VALUE) { res.col = n->color; res.f = n->value; }
+		else if(n->type == YOR_NODE_MIX)
+		{	/* MixNode::getInputs shader_node_basic.h:98-124 (val_1_ / val_2_ are never set by the reference: 0 here) */
+			float f_2 = (n->factor >= 0) ? stack[n->factor].f : n->cfactor;
+			rgba_t c1, c2; float fin_1, fin_2;
+			if(n->input1 >= 0) { c1 = stack[n->input1].col; fin_1 = stack[n->input1].f; } else { c1 = n->col1; fin_1 = 0.f; }
+			if(n->input2 >= 0) { c2 = stack[n->input2].col; fin_2 = stack[n->input2].f; } else { c2 = n->col2; fin_2 = 0.f; }
+			float f_1 = 1.f - f_2;
+			float *a = &c1.r, *b = &c2.r;
+			switch(n->mode)
+			{
+				case MN_ADD: for(int i = 0; i < 4; ++i) a[i] += f_2 * b[i]; fin_1 += f_2 * fin_2; break;
+				case MN_MULT: for(int i = 0; i < 4; ++i) a[i] *= f_1 + f_2 * b[i]; break;      /* fin_1 is left as it is (:563-566) */
+				case MN_SUB: for(int i = 0; i < 4; ++i) a[i] -= f_2 * b[i]; fin_1 -= f_2 * fin_2; break;
+				case MN_SCREEN:
+					for(int i = 0; i < 4; ++i) a[i] = 1.f - (f_1 + f_2 * (1.f - b[i])) * (1.f - a[i]);
+					fin_1 = (float)(1.0 - (double)((f_1 + f_2 * (1.f - fin_2)) * (1.f - fin_1)));
+					break;
+				case MN_DIFF:
+					for(int i = 0; i < 4; ++i) a[i] = f_1 * a[i] + f_2 * fabsf(a[i] - b[i]);
+					fin_1 = f_1 * fin_1 + f_2 * fabsf(fin_1 - fin_2);
+					break;
+				case MN_DARK:
+					for(int i = 0; i < 4; ++i) { b[i] *= f_2; if(b[i] < a[i]) a[i] = b[i]; }
+					fin_2 *= f_2; if(fin_2 < fin_1) fin_1 = fin_2;
+					break;
+				case MN_LIGHT:
+					for(int i = 0; i < 4; ++i) { b[i] *= f_2; if(b[i] > a[i]) a[i] = b[i]; }
+					fin_2 *= f_2; if(fin_2 > fin_1) fin_1 = fin_2;
+					break;
+				case MN_OVERLAY:
+				{
+					rgba_t o; float *oo = &o.r;
+					for(int i = 0; i < 4; ++i)
+						oo[i] = (a[i] < 0.5f) ? a[i] * (f_1 + 2.0f * f_2 * b[i]) : (float)(1.0 - ((double)f_1 + (double)(2.0f * f_2) * (1.0 - (double)b[i])) * (1.0 - (double)a[i]));
+					fin_1 = (fin_1 < 0.5f) ? fin_1 * (f_1 + 2.0f * f_2 * fin_2) : (float)(1.0 - ((double)f_1 + (double)(2.0f * f_2) * (1.0 - (double)fin_2)) * (1.0 - (double)fin_1));
+					c1 = o;
+					break;
+				}
+				default:       /* MnMix, and MnDiv (no class of its own: MixNode::factory :697-703) */
+					for(int i = 0; i < 4; ++i) a[i] = f_1 * a[i] + f_2 * b[i];
+					fin_1 = f_1 * fin_1 + f_2 * fin_2;
+					break;
+			}
+			res.col = c1; res.f = fin_1;
+		}
+		else if(n->type == YOR_NODE_LAYER)
+		{	/* LayerNode::eval shader_node_layer.cc:29-117 */
+			rgba_t rcol, texcolor = RA(0.f, 0.f, 0.f, 0.f);
+			float rval, tin = 0.f, ta = 1.f, stencil_tin;
+			rcol = (n->upper >= 0) ? stack[n->upper].col : n->upper_col;
+			rval = (n->upper >= 0) ? stack[n->upper].f : n->upper_val;
+			stencil_tin = rcol.a;
+			int tex_rgb = n->color_input;
+			if(n->color_input) { texcolor = stack[n->input].col; ta = texcolor.a; }
+			else tin = stack[n->input].f;
+			if(n->texflag & TXF_RGBTOINT) { tin = (0.2126f * texcolor.r + 0.7152f * texcolor.g + 0.0722f * texcolor.b); tex_rgb = 0; }
+			if(n->texflag & TXF_NEGATIVE)
+			{
+				if(tex_rgb) texcolor = RA(1.f - texcolor.r, 1.f - texcolor.g, 1.f - texcolor.b, 1.f - texcolor.a);
+				tin = 1.f - tin;
+			}
+			float fact;
+			if(n->texflag & TXF_STENCIL)
+			{
+				if(tex_rgb) { fact = ta; ta *= stencil_tin; stencil_tin *= fact; }
+				else { fact = tin; tin *= stencil_tin; stencil_tin *= fact; }
+			}
+			if(n->do_color)
+			{
+				if(!tex_rgb) texcolor = n->def_col; else tin = ta;
+				float tt = tin > 1.f ? 1.f : (tin < 0.f ? 0.f : tin);
+				/* textureRgbBlend__(texcolor, rcol, tt, stencil_tin * colfac_, mode_) on Rgb */
+				float facg = stencil_tin * n->colfac, f = tt;
+				float tex[3] = {texcolor.r, texcolor.g, texcolor.b}, out[3] = {rcol.r, rcol.g, rcol.b}, r[3];
+				switch(n->mode)
+				{
+					case MN_MULT: f *= facg; for(int i = 0; i < 3; ++i) r[i] = ((1.f - facg) + f * tex[i]) * out[i]; break;
+					case MN_SCREEN: f *= facg; for(int i = 0; i < 3; ++i) r[i] = 1.0f - ((1.f - facg) + f * (1.0f - tex[i])) * (1.0f - out[i]); break;
+					case MN_SUB: f = -f; f *= facg; for(int i = 0; i < 3; ++i) r[i] = f * tex[i] + out[i]; break;
+					case MN_ADD: f *= facg; for(int i = 0; i < 3; ++i) r[i] = f * tex[i] + out[i]; break;
+					case MN_DIV:
+						f *= facg;
+						for(int i = 0; i < 3; ++i) { float it = (tex[i] != 0.f) ? 1.f / tex[i] : tex[i]; r[i] = (1.f - f) * out[i] + (f * out[i]) * it; }
+						break;
+					case MN_DIFF: f *= facg; for(int i = 0; i < 3; ++i) r[i] = (1.f - f) * out[i] + f * fabsf(tex[i] - out[i]); break;
+					case MN_DARK: f *= facg; for(int i = 0; i < 3; ++i) { float c = f * tex[i]; r[i] = (out[i] < c) ? out[i] : c; } break;
+					case MN_LIGHT: f *= facg; for(int i = 0; i < 3; ++i) { float c = f * tex[i]; r[i] = (out[i] > c) ? out[i] : c; } break;
+					default: f *= facg; for(int i = 0; i < 3; ++i) r[i] = f * tex[i] + (1.f - f) * out[i]; break;
+				}
+				rcol = RA(r[0], r[1], r[2], 1.f);
+				rcol = tex_clamp_rgb0(rcol);
+			}
+			if(n->do_scalar_l)
+			{
+				if(tex_rgb)
+				{
+					if(n->use_alpha) { tin = ta; if(n->texflag & TXF_NEGATIVE) tin = 1.f - tin; }
+					else tin = (0.2126f * texcolor.r + 0.7152f * texcolor.g + 0.0722f * texcolor.b);
+				}
+				/* textureValueBlend__(default_val_, rval, tin, stencil_tin * valfac_, mode_) */
+				float facg = stencil_tin * n->valfac, f = tin * facg, facm = 1.f - f, tex = n->def_val, out = rval;
+				switch(n->mode)
+				{
+					case MN_MULT: facm = 1.f - facg; rval = (facm + f * tex) * out; break;
+					case MN_SCREEN: facm = 1.f - facg; rval = 1.f - (facm + f * (1.f - tex)) * (1.f - out); break;
+					case MN_SUB: f = -f; rval = f * tex + out; break;
+					case MN_ADD: rval = f * tex + out; break;
+					case MN_DIV: rval = (tex == 0.f) ? 0.f : facm * out + f * out / tex; break;
+					case MN_DIFF: rval = facm * out + f * fabsf(tex - out); break;
+					case MN_DARK: { float c = f * tex; rval = (c < out) ? c : out; break; }
+					case MN_LIGHT: { float c = f * tex; rval = (c > out) ? c : out; break; }
+					default: rval = f * tex + facm * out; break;
+				}
+				if(rval < 0.f) rval = 0.f;
+			}
+			rcol.a = stencil_tin;
+			res.col = rcol; res.f = rval;
+		}
+		stack[k] = res;
+	}
+}
+
 /* ------------------------------------------------------------------ materials */
 typedef struct { float component[4]; float m_diffuse, m_glossy, p_diffuse; } bsdf_dat; /* SdDat / MDatT */
 typedef struct { float s_1, s_2, pdf; unsigned flags, sampled_flags; } sample_t;         /* material.h:68-78 */
@@ -1022,27 +1566,39 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 			m->oren_b = (float)(0.45 * sigma_squared / (sigma_squared + 0.09));
 			m->use_oren = 1;
 		}
+		/* shader slots (factory :692-752); a slot with a node makes its component present whatever the strength (config :52-85) */
+		m->sh_diffuse = m->sh_mirror_color = m->sh_mirror = m->sh_transparency = m->sh_translucency = m->sh_sigma_oren = m->sh_diffuse_refl = m->sh_ior = -1;
+		m->ior_base = d->ior;
+		if(d->n_nodes > 0 && d->nodes)
+		{
+			m->n_nodes = d->n_nodes;
+			m->nodes = (node_t *)calloc((size_t)d->n_nodes, sizeof(node_t));
+			for(int k = 0; k < d->n_nodes; ++k) node_configure(&m->nodes[k], &d->nodes[k]);
+			m->sh_diffuse = d->sh_diffuse; m->sh_mirror_color = d->sh_mirror_color; m->sh_mirror = d->sh_mirror; m->sh_transparency = d->sh_transparency;
+			m->sh_translucency = d->sh_translucency; m->sh_sigma_oren = d->sh_sigma_oren; m->sh_diffuse_refl = d->sh_diffuse_refl; m->sh_ior = d->sh_ior;
+		}
 		/* config() :46-92 */
 		float acc = 1.f;
 		m->n_bsdf = 0;
-		if(m->mirror_strength > 0.00001f)
+		if(m->mirror_strength > 0.00001f || m->sh_mirror >= 0)
 		{
 			m->is_mirror = 1;
-			if(!m->has_fresnel) acc = 1.f - m->mirror_strength;
+			if(m->sh_mirror >= 0) { /* the node's value is not known here: acc stays (:55) */ }
+			else if(!m->has_fresnel) acc = 1.f - m->mirror_strength;
 			m->flags |= BSDF_SPECULAR | BSDF_REFLECT;
 			m->c_flags[m->n_bsdf] = BSDF_SPECULAR | BSDF_REFLECT; m->c_index[m->n_bsdf] = 0; ++m->n_bsdf;
 		}
-		if(m->transparency_strength * acc > 0.00001f)
+		if(m->transparency_strength * acc > 0.00001f || m->sh_transparency >= 0)
 		{
 			m->is_transparent = 1;
-			acc *= 1.f - m->transparency_strength;
+			if(m->sh_transparency < 0) acc *= 1.f - m->transparency_strength;
 			m->flags |= BSDF_TRANSMIT | BSDF_FILTER;
 			m->c_flags[m->n_bsdf] = BSDF_TRANSMIT | BSDF_FILTER; m->c_index[m->n_bsdf] = 1; ++m->n_bsdf;
 		}
-		if(m->translucency_strength * acc > 0.00001f)
+		if(m->translucency_strength * acc > 0.00001f || m->sh_translucency >= 0)
 		{
 			m->is_translucent = 1;
-			acc *= 1.f - m->transparency_strength; /* sic: the reference multiplies by transparency here (:72) */
+			if(m->sh_translucency < 0) acc *= 1.f - m->transparency_strength; /* sic: the reference multiplies by transparency here (:76) */
 			m->flags |= BSDF_DIFFUSE | BSDF_TRANSMIT;
 			m->c_flags[m->n_bsdf] = BSDF_DIFFUSE | BSDF_TRANSMIT; m->c_index[m->n_bsdf] = 2; ++m->n_bsdf;
 		}
@@ -1182,6 +1738,36 @@ static float oren_nayar(float oren_a, float oren_b, v3 wi, v3 wo, v3 n)
 	return fminf_(1.f, fmaxf_(0.f, (float)(oren_a + oren_b * maxcos_f * sin_alpha * tan_beta)));
 }
 
+/* the same with A and B computed from a texture's sigma, in double (material_shiny_diffuse.cc:230-235) */
+static float oren_nayar_d(double oren_a, double oren_b, v3 wi, v3 wo, v3 n)
+{
+	float cos_ti = fmaxf_(-1.f, fminf_(1.f, vdot(n, wi)));
+	float cos_to = fmaxf_(-1.f, fminf_(1.f, vdot(n, wo)));
+	float maxcos_f = 0.f;
+	if(cos_ti < 0.9999f && cos_to < 0.9999f)
+	{
+		v3 v_1 = vnormalize(vsub(wi, vmul(n, cos_ti)));
+		v3 v_2 = vnormalize(vsub(wo, vmul(n, cos_to)));
+		maxcos_f = fmaxf_(0.f, vdot(v_1, v_2));
+	}
+	float sin_alpha, tan_beta;
+	if(cos_to >= cos_ti)
+	{
+		sin_alpha = yor_fsqrt(1.f - cos_ti * cos_ti);
+		tan_beta = yor_fsqrt(1.f - cos_to * cos_to) / ((cos_to == 0.f) ? 1e-8f : cos_to);
+	}
+	else
+	{
+		sin_alpha = yor_fsqrt(1.f - cos_to * cos_to);
+		tan_beta = yor_fsqrt(1.f - cos_ti * cos_ti) / ((cos_ti == 0.f) ? 1e-8f : cos_ti);
+	}
+	return fminf_(1.f, fmaxf_(0.f, (float)(oren_a + oren_b * (double)maxcos_f * (double)sin_alpha * (double)tan_beta)));
+}
+static float sd_oren(const mat_t *m, v3 wi, v3 wo, v3 n)
+{
+	return m->oren_tex ? oren_nayar_d(m->oren_ad, m->oren_bd, wi, wo, n) : oren_nayar(m->oren_a, m->oren_b, wi, wo, n);
+}
+
 /* refract__, vector.cc:86-108 */
 static int refract_dir(v3 n, v3 wi, v3 *wo, float ior)
 {
@@ -1224,6 +1810,37 @@ static v3 glass_normal(const sp_t *sp, v3 wo)
 	if(outside ? (cos_wo_n >= 0) : (cos_wo_n <= 0)) return sp->n;
 	float f = (float)(1.00001 * (double)cos_wo_n);
 	return vnormalize(vsub(sp->n, vmul(wo, f)));
+}
+
+/* A textured material at one surface point: the node list is evaluated once (ShinyDiffuseMaterial::initBsdf :163-183 —
+ * every supported node is view independent) and what the material's functions read through a shader slot is written
+ * into a copy of the material record: `slot ? slot->getColor / getScalar(stack) : member` becomes the member of the copy.
+ * Untextured materials are returned as they are. */
+#define YOR_MAX_NODES 32
+static const mat_t *mat_resolve(const yor_scene *s, const sp_t *sp, mat_t *out)
+{
+	const mat_t *m = &s->mats[sp->mat];
+	if(m->n_nodes <= 0 || m->type != YOR_MAT_SHINYDIFFUSE) return m;
+	node_result_t stack[YOR_MAX_NODES];
+	nodes_eval(m->nodes, m->n_nodes < YOR_MAX_NODES ? m->n_nodes : YOR_MAX_NODES, s->tex, s->n_tex, &s->cam, sp, stack);
+	*out = *m;
+	if(m->sh_diffuse >= 0)
+	{
+		out->diffuse_color = C(stack[m->sh_diffuse].col.r, stack[m->sh_diffuse].col.g, stack[m->sh_diffuse].col.b);
+		out->emit_color = cscale(out->diffuse_color, m->emit_strength);             /* emit :300 */
+	}
+	if(m->sh_mirror_color >= 0) out->mirror_color = C(stack[m->sh_mirror_color].col.r, stack[m->sh_mirror_color].col.g, stack[m->sh_mirror_color].col.b);
+	if(m->sh_mirror >= 0) out->mirror_strength = stack[m->sh_mirror].f;             /* getComponents :98-117 */
+	if(m->sh_transparency >= 0) out->transparency_strength = stack[m->sh_transparency].f;
+	if(m->sh_translucency >= 0) out->translucency_strength = stack[m->sh_translucency].f;
+	if(m->sh_sigma_oren >= 0)
+	{	/* orenNayar :230-235 */
+		double sigma = (double)stack[m->sh_sigma_oren].f, s2 = sigma * sigma;
+		out->oren_tex = 1; out->oren_ad = 1.0 - 0.5 * (s2 / (s2 + 0.33)); out->oren_bd = 0.45 * s2 / (s2 + 0.09);
+	}
+	if(m->sh_diffuse_refl >= 0) { out->has_diffuse_refl = 1; out->diffuse_refl = stack[m->sh_diffuse_refl].f; }
+	if(m->sh_ior >= 0) { float cur = m->ior_base + stack[m->sh_ior].f; out->ior_squared = cur * cur; }     /* :258-262 */
+	return out;
 }
 
 static void mat_init_bsdf(const mat_t *m, bsdf_dat *dat, unsigned *bsdf_types)
@@ -1294,7 +1911,8 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		}
 		if(vdot(n, wl) < 0.0 && !m->flat) return C(0, 0, 0);
 		float m_d = m_t * (1.f - dat->component[2]) * dat->component[3];
-		if(m->use_oren) m_d *= oren_nayar(m->oren_a, m->oren_b, wo, wl, n);
+		if(m->use_oren) m_d *= sd_oren(m, wo, wl, n);
+		if(m->has_diffuse_refl) m_d *= m->diffuse_refl;                      /* :285 */
 		return cscale(m->diffuse_color, m_d);
 	}
 	else if(m->type == YOR_MAT_GLOSSY)
@@ -1494,7 +2112,8 @@ static rgb mat_transparency_at(const yor_scene *s, int ti, v3 hit, float bu, flo
 {
 	sp_t sp;
 	get_surface(s, ti, hit, bu, bv, &sp);
-	return mat_transparency(&s->mats[sp.mat], &sp, dir);
+	mat_t mloc;
+	return mat_transparency(mat_resolve(s, &sp, &mloc), &sp, dir);
 }
 
 /* GlassMaterial::getTransparency / getAlpha, material_glass.cc:217-240 */
@@ -1698,7 +2317,7 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 				*wi = sample_cos_hemisphere(n, sp->nu, sp->nv, s_1, s->s_2);
 				cos_ng_wi = vdot(sp->ng, *wi);
 				if(cos_ng_wo * cos_ng_wi > 0) scolor = cscale(m->diffuse_color, accum_c[3]);
-				if(m->use_oren) scolor = cscale(scolor, oren_nayar(m->oren_a, m->oren_b, wo, *wi, n));
+				if(m->use_oren) scolor = cscale(scolor, sd_oren(m, wo, *wi, n));
 				s->pdf = fabsf(vdot(*wi, n)) * width[pick]; break;
 		}
 		s->sampled_flags = choice[pick];
@@ -2202,7 +2821,50 @@ yor_scene *yor_scene_create(int32_t n_tris, const float *verts, const int32_t *t
 void yor_scene_destroy(yor_scene *s)
 {
 	if(!s) return;
+	for(int i = 0; i < s->n_mats; ++i) free(s->mats[i].nodes);
+	for(int i = 0; i < s->n_tex; ++i) free(s->tex[i].px);
+	free(s->tex); free(s->tri_uv); free(s->tri_orco);
 	free(s->tris); free(s->mats); free(s->lights); free(s->nodes); free(s->leaf_refs); free(s);
+}
+
+void yor_scene_set_textures(yor_scene *s, int32_t n_textures, const yor_texture_desc *textures)
+{
+	for(int i = 0; i < s->n_tex; ++i) free(s->tex[i].px);
+	free(s->tex);
+	s->n_tex = n_textures > 0 ? n_textures : 0;
+	s->tex = (tex_t *)calloc((size_t)(s->n_tex > 0 ? s->n_tex : 1), sizeof(tex_t));
+	for(int i = 0; i < s->n_tex; ++i) tex_configure(&s->tex[i], &textures[i]);
+}
+void yor_scene_set_texcoords(yor_scene *s, const float *uv, const float *orco)
+{
+	free(s->tri_uv); free(s->tri_orco); s->tri_uv = NULL; s->tri_orco = NULL;
+	if(uv && s->n_tris > 0) { s->tri_uv = (float *)malloc((size_t)s->n_tris * 6 * sizeof(float)); memcpy(s->tri_uv, uv, (size_t)s->n_tris * 6 * sizeof(float)); }
+	if(orco && s->n_tris > 0) { s->tri_orco = (float *)malloc((size_t)s->n_tris * 9 * sizeof(float)); memcpy(s->tri_orco, orco, (size_t)s->n_tris * 9 * sizeof(float)); }
+}
+void yor_texture_probe(const yor_texture_desc *d, const float p[3], float out5[5])
+{
+	tex_t t; tex_configure(&t, d);
+	rgba_t c = tex_get_color(&t, V(p[0], p[1], p[2]));
+	out5[0] = c.r; out5[1] = c.g; out5[2] = c.b; out5[3] = c.a; out5[4] = tex_get_float(&t, V(p[0], p[1], p[2]));
+	free(t.px);
+}
+void yor_nodes_probe(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
+                     const float sp18[18], float *out)
+{
+	node_t nd[YOR_MAX_NODES]; node_result_t stack[YOR_MAX_NODES];
+	if(n_nodes > YOR_MAX_NODES) n_nodes = YOR_MAX_NODES;
+	for(int k = 0; k < n_nodes; ++k) node_configure(&nd[k], &nodes[k]);
+	tex_t *tx = (tex_t *)calloc((size_t)(n_textures > 0 ? n_textures : 1), sizeof(tex_t));
+	for(int i = 0; i < n_textures; ++i) tex_configure(&tx[i], &textures[i]);
+	camera_t c; memset(&c, 0, sizeof c);
+	if(cam) camera_configure(&c, cam);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.p = V(sp18[0], sp18[1], sp18[2]); sp.n = V(sp18[3], sp18[4], sp18[5]); sp.ng = V(sp18[6], sp18[7], sp18[8]);
+	sp.orco_p = V(sp18[9], sp18[10], sp18[11]); sp.orco_ng = V(sp18[12], sp18[13], sp18[14]); sp.u = sp18[15]; sp.v = sp18[16];
+	nodes_eval(nd, n_nodes, tx, n_textures, &c, &sp, stack);
+	for(int k = 0; k < n_nodes; ++k) { out[5 * k] = stack[k].col.r; out[5 * k + 1] = stack[k].col.g; out[5 * k + 2] = stack[k].col.b; out[5 * k + 3] = stack[k].col.a; out[5 * k + 4] = stack[k].f; }
+	for(int i = 0; i < n_textures; ++i) free(tx[i].px);
+	free(tx);
 }
 
 void yor_scene_set_tree(yor_scene *s, uint32_t n_nodes, const uint32_t *nodes, uint32_t n_refs, const uint32_t *refs, const float bound6[6])
@@ -2388,7 +3050,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		if(raylevel == 0) st->include_lights = 1; /* :129-135 */
 		unsigned bsdfs;
 		bsdf_dat dat0;
-		const mat_t *material = &s->mats[sp.mat];
+		mat_t mat_here; const mat_t *material = mat_resolve(s, &sp, &mat_here);
 		mat_init_bsdf(material, &dat0, &bsdfs);
 		v3 wo = vneg(dir);
 		if(bsdfs & BSDF_EMIT) col = cadd(col, mat_emit(material, &sp, wo, st->include_lights));
@@ -2418,7 +3080,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 				p_tmin = st->ray_min_dist;
 				p_tmax = -1.0f;
 				if(!scene_intersect(s, sp.p, p_dir, p_tmin, &p_tmax, hit, &st->cn)) continue;
-				const mat_t *p_mat = &s->mats[hit->mat];
+				mat_t mat_hit; const mat_t *p_mat = mat_resolve(s, hit, &mat_hit);
 				unsigned mat_bsdfs;
 				mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
 				if(sm.sampled_flags != BSDF_NONE) pwo = vneg(p_dir);
@@ -2440,7 +3102,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 					p_tmax = -1.0f;
 					if(!scene_intersect(s, hit->p, p_dir, p_tmin, &p_tmax, hit_2, &st->cn)) break;
 					{ sp_t *tmp = hit; hit = hit_2; hit_2 = tmp; }
-					p_mat = &s->mats[hit->mat];
+					p_mat = mat_resolve(s, hit, &mat_hit);
 					mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
 					pwo = vneg(p_dir);
 					if(mat_bsdfs & BSDF_DIFFUSE) lcol = estimate_one_direct_light(st, hit, p_mat, &dat_n, pwo);

@@ -73,7 +73,62 @@ typedef struct yor_material_desc
 	float absorption[3];
 	int32_t has_absorption;
 	double absorption_dist;
+	/* shader nodes: the material's node list in EVALUATION order (NodeMaterial::solveNodesOrder,
+	 * material_node.cc:88-108: dependencies before dependants) and the node each shader slot reads (-1: none).
+	 * shinydiffusemat slots, material_shiny_diffuse.cc:697-724. */
+	int32_t n_nodes;
+	int32_t sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
+	int32_t pad2;
+	const struct yor_node_desc *nodes;
 } yor_material_desc;
+
+/* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has
+ * already linearised the file's colours and pushed them through the buffer's storage format. */
+typedef struct yor_texture_desc
+{
+	int32_t width, height;
+	const float *texels;       /* height * width * 4 (rgba), row y = the image handler's row y */
+	int32_t interpolate;       /* 0 none, 1 bilinear */
+	int32_t clip;              /* TexClipMode: 0 extend, 1 clip, 2 clipcube, 3 repeat, 4 checker */
+	int32_t xrepeat, yrepeat, rot90, mirror_x, mirror_y, checker_even, checker_odd;
+	float checker_dist;
+	float cropmin_x, cropmin_y, cropmax_x, cropmax_y;
+	float adj_intensity, adj_contrast, adj_saturation, adj_hue, adj_red, adj_green, adj_blue;
+	int32_t adj_clamp;
+	int32_t color_space;       /* for getRawColor (texture_image.cc:90-104): 0 sRGB, 1 XYZ, 2 LinearRGB, 3 RawManualGamma */
+	float gamma;
+} yor_texture_desc;
+
+enum { YOR_NODE_TEXTURE_MAPPER = 0, YOR_NODE_VALUE = 1, YOR_NODE_MIX = 2, YOR_NODE_LAYER = 3 };
+/* one shader node, parameter level (the factory() arguments of shader_node_basic.cc / shader_node_layer.cc); node
+ * references are indices into the material's node list, -1 = not connected */
+typedef struct yor_node_desc
+{
+	int32_t type;
+	/* texture_mapper (shader_node_basic.cc:344-413) */
+	int32_t texture;           /* index into the scene's textures */
+	int32_t texco;             /* Coords: 0 uv, 1 glob, 2 orco, 3 tran, 4 nor, 5 refl, 6 win, 7 stick, 8 stress, 9 tan */
+	int32_t mapping;           /* Projection: 0 plain, 1 cube, 2 tube, 3 sphere */
+	int32_t proj[3];
+	float scale[3], offset[3]; /* as given (the factory doubles the offset) */
+	float mtx[16];
+	int32_t do_scalar;
+	/* value (:429-438) */
+	float color[4];            /* rgb + alpha */
+	float scalar;
+	/* mix (:480-530, :682-703) */
+	int32_t mode;              /* MixModes, also the layer's blend mode */
+	float cfactor;
+	int32_t input1, input2, factor;
+	float col1[4], col2[4];
+	/* layer (shader_node_layer.cc:205-244, :148-187) */
+	int32_t input, upper_layer;
+	int32_t no_rgb, stencil, negative, use_alpha, do_color, do_scalar_l, color_input;
+	float colfac, valfac, def_val;
+	float def_col[3];
+	float upper_col[4];
+	float upper_val;
+} yor_node_desc;
 
 typedef struct yor_light_desc
 {
@@ -174,6 +229,15 @@ yor_scene *yor_scene_create(int32_t n_tris, const float *verts, const int32_t *t
                             int32_t n_lights, const yor_light_desc *lights,
                             const yor_camera_desc *cam);
 void yor_scene_destroy(yor_scene *s);
+/* textures of the scene (referred to by texture_mapper nodes) and per-triangle texture coordinates: uv = n_tris * 6 floats
+ * (u, v of the three corners) or NULL, orco = n_tris * 9 floats or NULL.  The material descriptions handed to
+ * yor_scene_create may refer to textures set later, but before the first render. */
+void yor_scene_set_textures(yor_scene *s, int32_t n_textures, const yor_texture_desc *textures);
+void yor_scene_set_texcoords(yor_scene *s, const float *uv, const float *orco);
+/* probes for the pins: one image-texture lookup (getColor rgba + getFloat), one material's node stack at a surface point */
+void yor_texture_probe(const yor_texture_desc *t, const float p[3], float out5[5]);
+void yor_nodes_probe(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
+                     const float sp18[18], float *out /* n_nodes * 5 */);
 
 /* film = height*width*5 floats {r,g,b,a,weight} (the reference's Pixel, util_image_buffers.h:36-48),
  * zeroed by the callee.  Returns 0 on success, negative on unsupported configuration. */

@@ -377,6 +377,10 @@ def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, 
     rd = scenes.render_settings(72, 56, 6, bounces=case["bounces"], path_samples=case["path_samples"], tile_size=16,
                                 russian_roulette_min_bounces=case["rr"], **case.get("aa", {}))
     film, st, ofilm, ost = _render_with_rand_state(sc, rd)
+    wdiff = int((film[..., 4] != ofilm[..., 4]).sum())
+    exact = float((film == ofilm).all(axis=-1).mean())
+    print(f"serial replay {case}: rays {st.rays_closest}+{st.rays_shadow} vs oracle {ost.rays_closest}+{ost.rays_shadow}, samples {st.camera_samples} vs {ost.camera_samples}, "
+          f"pixels with another weight {wdiff}, bit-exact pixels {exact:.4f}")
     assert st.camera_samples == ost.camera_samples
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow, "ray counts differ from the oracle's single-thread render"
     compare_films(film, ofilm, f"serial replay {case}")

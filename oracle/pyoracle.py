@@ -33,7 +33,136 @@ class MaterialDesc(C.Structure):
         ("as_diffuse", C.c_int32),
         ("light_color", f3), ("light_power", C.c_float), ("double_sided", C.c_int32), ("pad1", C.c_int32),
         ("absorption", f3), ("has_absorption", C.c_int32), ("absorption_dist", C.c_double),
+        ("n_nodes", C.c_int32),
+        ("sh_diffuse", C.c_int32), ("sh_mirror_color", C.c_int32), ("sh_mirror", C.c_int32), ("sh_transparency", C.c_int32),
+        ("sh_translucency", C.c_int32), ("sh_sigma_oren", C.c_int32), ("sh_diffuse_refl", C.c_int32), ("sh_ior", C.c_int32),
+        ("pad2", C.c_int32), ("nodes", C.c_void_p),
     ]
+
+
+f4 = C.c_float * 4
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("texels", C.POINTER(C.c_float)),
+        ("interpolate", C.c_int32), ("clip", C.c_int32),
+        ("xrepeat", C.c_int32), ("yrepeat", C.c_int32), ("rot90", C.c_int32), ("mirror_x", C.c_int32), ("mirror_y", C.c_int32),
+        ("checker_even", C.c_int32), ("checker_odd", C.c_int32), ("checker_dist", C.c_float),
+        ("cropmin_x", C.c_float), ("cropmin_y", C.c_float), ("cropmax_x", C.c_float), ("cropmax_y", C.c_float),
+        ("adj_intensity", C.c_float), ("adj_contrast", C.c_float), ("adj_saturation", C.c_float), ("adj_hue", C.c_float),
+        ("adj_red", C.c_float), ("adj_green", C.c_float), ("adj_blue", C.c_float), ("adj_clamp", C.c_int32),
+        ("color_space", C.c_int32), ("gamma", C.c_float),
+    ]
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("texture", C.c_int32), ("texco", C.c_int32), ("mapping", C.c_int32), ("proj", C.c_int32 * 3),
+        ("scale", f3), ("offset", f3), ("mtx", C.c_float * 16), ("do_scalar", C.c_int32),
+        ("color", f4), ("scalar", C.c_float),
+        ("mode", C.c_int32), ("cfactor", C.c_float), ("input1", C.c_int32), ("input2", C.c_int32), ("factor", C.c_int32),
+        ("col1", f4), ("col2", f4),
+        ("input", C.c_int32), ("upper_layer", C.c_int32),
+        ("no_rgb", C.c_int32), ("stencil", C.c_int32), ("negative", C.c_int32), ("use_alpha", C.c_int32), ("do_color", C.c_int32),
+        ("do_scalar_l", C.c_int32), ("color_input", C.c_int32),
+        ("colfac", C.c_float), ("valfac", C.c_float), ("def_val", C.c_float), ("def_col", f3), ("upper_col", f4), ("upper_val", C.c_float),
+    ]
+
+
+TEXCO = {"uv": 0, "global": 1, "orco": 2, "transformed": 3, "normal": 4, "reflect": 5, "window": 6, "stick": 7, "stress": 8, "tangent": 9}
+MAPPING = {"plain": 0, "cube": 1, "tube": 2, "sphere": 3}
+CLIPPING = {"extend": 0, "clip": 1, "clipcube": 2, "repeat": 3, "checker": 4}
+COLOR_SPACE = {"sRGB": 0, "XYZ": 1, "LinearRGB": 2, "Raw_Manual_Gamma": 3}
+SHADER_SLOTS = {"diffuse_shader": "sh_diffuse", "mirror_color_shader": "sh_mirror_color", "mirror_shader": "sh_mirror",
+                "transparency_shader": "sh_transparency", "translucency_shader": "sh_translucency",
+                "sigma_oren_shader": "sh_sigma_oren", "diffuse_refl_shader": "sh_diffuse_refl", "IOR_shader": "sh_ior"}
+
+
+def texture_desc(t):
+    """t: the reference's ImageTexture::factory parameters (texture_image.cc:545-700) + "texels" (h, w, 4) float32 as the
+    image buffer returns them"""
+    d = TextureDesc()
+    px = np.ascontiguousarray(t["texels"], dtype=np.float32)
+    d._keep = px
+    d.height, d.width = px.shape[0], px.shape[1]
+    d.texels = px.ctypes.data_as(C.POINTER(C.c_float))
+    d.interpolate = {"none": 0, "bilinear": 1}[t.get("interpolate", "bilinear")]
+    d.clip = CLIPPING.get(t.get("clipping", "repeat"), 3)                # string2Cliptype__: unknown -> repeat
+    d.xrepeat, d.yrepeat = t.get("xrepeat", 1), t.get("yrepeat", 1)
+    d.rot90, d.mirror_x, d.mirror_y = int(t.get("rot90", False)), int(t.get("mirror_x", False)), int(t.get("mirror_y", False))
+    d.checker_even, d.checker_odd, d.checker_dist = int(t.get("even_tiles", False)), int(t.get("odd_tiles", True)), t.get("checker_dist", 0.0)
+    d.cropmin_x, d.cropmin_y, d.cropmax_x, d.cropmax_y = t.get("cropmin_x", 0.0), t.get("cropmin_y", 0.0), t.get("cropmax_x", 1.0), t.get("cropmax_y", 1.0)
+    d.adj_intensity, d.adj_contrast = t.get("adj_intensity", 1.0), t.get("adj_contrast", 1.0)
+    d.adj_saturation, d.adj_hue = t.get("adj_saturation", 1.0), t.get("adj_hue", 0.0)
+    d.adj_red, d.adj_green, d.adj_blue = t.get("adj_mult_factor_red", 1.0), t.get("adj_mult_factor_green", 1.0), t.get("adj_mult_factor_blue", 1.0)
+    d.adj_clamp = int(t.get("adj_clamp", False))
+    d.color_space = COLOR_SPACE.get(t.get("color_space", "sRGB"), 0)
+    d.gamma = t.get("gamma", 1.0)
+    return d
+
+
+def sort_nodes(nodes):
+    """evaluation order (NodeMaterial::solveNodesOrder): every node after the nodes it reads; -> (sorted list, name -> index)"""
+    by_name = {n["name"]: n for n in nodes}
+    order, seen = [], set()
+
+    def visit(n):
+        if n["name"] in seen:
+            return
+        seen.add(n["name"])
+        for k in ("input", "upper_layer", "input1", "input2", "factor"):
+            if k in n and n[k] in by_name:
+                visit(by_name[n[k]])
+        order.append(n)
+    for n in nodes:
+        visit(n)
+    return order, {n["name"]: i for i, n in enumerate(order)}
+
+
+def node_descs(nodes, texture_index):
+    """nodes: the material's list_element dicts (reference parameter names) -> (NodeDesc array in evaluation order, name -> index)"""
+    order, index = sort_nodes(nodes)
+    arr = (NodeDesc * max(1, len(order)))()
+    for i, n in enumerate(order):
+        d = arr[i]
+        ref = lambda key: index.get(n.get(key), -1) if key in n else -1
+        t = n["type"]
+        d.texture = d.input1 = d.input2 = d.factor = d.input = d.upper_layer = -1
+        if t == "texture_mapper":
+            d.type = 0
+            d.texture = texture_index[n["texture"]]
+            d.texco = TEXCO.get(n.get("texco", "global"), 1)
+            d.mapping = MAPPING.get(n.get("mapping", "plain"), 0)
+            d.proj = (C.c_int32 * 3)(n.get("proj_x", 1), n.get("proj_y", 2), n.get("proj_z", 3))
+            d.scale = f3(*n.get("scale", (1, 1, 1))); d.offset = f3(*n.get("offset", (0, 0, 0)))
+            d.mtx = (C.c_float * 16)(*np.asarray(n.get("transform", np.eye(4)), np.float32).reshape(16))
+            d.do_scalar = int(n.get("do_scalar", True))
+        elif t == "value":
+            d.type = 1
+            col = n.get("color", (1, 1, 1))
+            d.color = f4(col[0], col[1], col[2], n.get("alpha", 1.0)); d.scalar = n.get("scalar", 1.0)
+        elif t == "mix":
+            d.type = 2
+            d.mode = n.get("mode", 0); d.cfactor = n.get("value", n.get("cfactor", 0.5))
+            d.input1, d.input2, d.factor = ref("input1"), ref("input2"), ref("factor")
+            c1, c2 = n.get("color1", (0, 0, 0, 1)), n.get("color2", (0, 0, 0, 1))
+            d.col1 = f4(*(tuple(c1) + (1.0,))[:4]); d.col2 = f4(*(tuple(c2) + (1.0,))[:4])
+        elif t == "layer":
+            d.type = 3
+            d.mode = n.get("mode", 0)
+            d.input, d.upper_layer = ref("input"), ref("upper_layer")
+            d.no_rgb, d.stencil, d.negative = int(n.get("noRGB", False)), int(n.get("stencil", False)), int(n.get("negative", False))
+            d.use_alpha, d.do_color, d.do_scalar_l = int(n.get("use_alpha", False)), int(n.get("do_color", True)), int(n.get("do_scalar", False))
+            d.color_input = int(n.get("color_input", True))
+            d.colfac, d.valfac, d.def_val = n.get("colfac", 1.0), n.get("valfac", 1.0), n.get("def_val", 1.0)
+            d.def_col = f3(*n.get("def_col", (1, 1, 1))[:3])
+            uc = n.get("upper_color", (0, 0, 0))
+            # configInputs: upper_color is read into an Rgba (alpha from the parameter, 1 by default); absent -> Rgb(0) (alpha 1)
+            d.upper_col = f4(*(tuple(uc) + (1.0,))[:4]); d.upper_val = n.get("upper_value", 0.0)
+        else:
+            raise ValueError(f"shader node type {t}")
+    return arr, index
 
 
 class LightDesc(C.Structure):
@@ -105,6 +234,10 @@ def lib():
     L.yor_scene_create.argtypes = [C.c_int32, fp, C.POINTER(C.c_int32), fp, C.c_int32, C.POINTER(MaterialDesc),
                                    C.c_int32, C.POINTER(LightDesc), C.POINTER(CameraDesc)]
     L.yor_scene_destroy.argtypes = [C.c_void_p]
+    L.yor_scene_set_textures.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TextureDesc)]
+    L.yor_scene_set_texcoords.argtypes = [C.c_void_p, fp, fp]
+    L.yor_texture_probe.argtypes = [C.POINTER(TextureDesc), fp, fp]
+    L.yor_nodes_probe.argtypes = [C.c_int32, C.POINTER(NodeDesc), C.c_int32, C.POINTER(TextureDesc), C.POINTER(CameraDesc), fp, fp]
     L.yor_render.restype = C.c_int
     L.yor_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), fp, C.POINTER(Stats)]
     L.yor_scene_set_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), fp]
@@ -232,6 +365,7 @@ def material_desc(m):
         d.double_sided = int(m.get("double_sided", False))
     else:
         raise ValueError(t)
+    d.sh_diffuse = d.sh_mirror_color = d.sh_mirror = d.sh_transparency = d.sh_translucency = d.sh_sigma_oren = d.sh_diffuse_refl = d.sh_ior = -1
     return d
 
 
@@ -340,12 +474,33 @@ class OracleScene:
         n = self.verts.shape[0]
         vn = scene.get("vnormals")
         self.vn = None if vn is None else np.ascontiguousarray(vn, dtype=np.float32).reshape(-1, 9)
-        mats = (MaterialDesc * len(scene["materials"]))(*[material_desc(m) for m in scene["materials"]])
+        textures = scene.get("textures") or []
+        tex_index = {t.get("name", f"tex{i}"): i for i, t in enumerate(textures)}
+        mdescs, self._node_arrays = [], []
+        for m in scene["materials"]:
+            d = material_desc(m)
+            if m.get("nodes"):
+                arr, index = node_descs(m["nodes"], tex_index)
+                self._node_arrays.append(arr)
+                d.n_nodes = len(m["nodes"]); d.nodes = C.cast(arr, C.c_void_p)
+                for pname, field in SHADER_SLOTS.items():
+                    if pname in m and m[pname] in index:
+                        setattr(d, field, index[m[pname]])
+            mdescs.append(d)
+        mats = (MaterialDesc * len(scene["materials"]))(*mdescs)
         lights = (LightDesc * max(1, len(scene["lights"])))(*[light_desc(l) for l in scene["lights"]])
         cam = camera_desc(scene["camera"])
         self.h = L.yor_scene_create(n, fptr(self.verts), self.tri_mat.ctypes.data_as(C.POINTER(C.c_int32)),
                                     None if self.vn is None else fptr(self.vn),
                                     len(scene["materials"]), mats, len(scene["lights"]), lights, C.byref(cam))
+        if textures:
+            self._tdescs = [texture_desc(t) for t in textures]
+            L.yor_scene_set_textures(self.h, len(textures), (TextureDesc * len(textures))(*self._tdescs))
+        uv, orco = scene.get("uv"), scene.get("orco")
+        if uv is not None or orco is not None:
+            self._uv = None if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 6)
+            self._orco = None if orco is None else np.ascontiguousarray(orco, dtype=np.float32).reshape(-1, 9)
+            L.yor_scene_set_texcoords(self.h, None if self._uv is None else fptr(self._uv), None if self._orco is None else fptr(self._orco))
 
     def render(self, render):
         L = lib()

@@ -17,8 +17,28 @@
 //
 // Output: one JSON document on stdout, floats as IEEE-754 bit patterns.  tests/golden/make_golden.py stores it as
 // tests/golden/ref_textures_{ieee,fast}.json.gz.
+// the standard library first: its headers must not see the two macros below
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
 #define private public
 #define protected public
+#include "common/param.h"
 #include "texture/texture_image.h"
 #include "imagehandler/imagehandler.h"
 #include "imagehandler/imagehandler_tga.h"
@@ -268,7 +288,7 @@ static void sec_nodes(Json &j)
 			const bool no_rgb = fl == 2, negative = fl == 3 || fl == 5, stencil = fl == 4 || fl == 5, use_alpha = fl == 5 || fl == 1;
 			const bool do_color = fl != 1, do_scalar = fl == 1 || fl == 2 || fl == 5, color_input = fl != 5;
 			ParamMap lp;
-			lp["mode"] = mode; lp["def_col"] = Rgb(0.9f, 0.4f, 0.2f); lp["colfac"] = 0.8; lp["def_val"] = 0.7; lp["valfac"] = 0.9;
+			lp["mode"] = mode; lp["def_col"] = Rgb(0.9f, 0.4f, 0.2f); lp["colfac"] = Parameter(0.8); lp["def_val"] = Parameter(0.7); lp["valfac"] = Parameter(0.9);
 			lp["do_color"] = do_color; lp["do_scalar"] = do_scalar; lp["color_input"] = color_input; lp["use_alpha"] = use_alpha;
 			lp["noRGB"] = no_rgb; lp["stencil"] = stencil; lp["negative"] = negative;
 			LayerNode *ln = (LayerNode *)LayerNode::factory(lp, fake_env());

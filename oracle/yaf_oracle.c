@@ -1136,14 +1136,15 @@ static rgba_t tex_interpolate(const tex_t *t, v3 p)
 	const int rep = t->clip == TCL_REPEAT;
 	if(t->interp == 0)
 	{
-		float xf = ((float)resx * (float)((double)p.x - floor((double)p.x)));
-		float yf = ((float)resy * (float)((double)p.y - floor((double)p.y)));
+		float xf = (float)((double)(float)resx * ((double)p.x - floor((double)p.x)));
+		float yf = (float)((double)(float)resy * ((double)p.y - floor((double)p.y)));
 		tex_interp_coords(&x0, &x1, &x2, &x3, &dx, xf, resx, rep, t->mirror_x);
 		tex_interp_coords(&y0, &y1, &y2, &y3, &dy, yf, resy, rep, t->mirror_y);
 		return tex_pixel(t, x1, y1);
 	}
-	float xf = ((float)resx * (float)((double)p.x - floor((double)p.x))) - 0.5f;
-	float yf = ((float)resy * (float)((double)p.y - floor((double)p.y))) - 0.5f;
+	/* floor() here is C's double floor: the expression is evaluated in double and narrowed once (pinned by the golden vectors) */
+	float xf = (float)((double)(float)resx * ((double)p.x - floor((double)p.x)) - (double)0.5f);
+	float yf = (float)((double)(float)resy * ((double)p.y - floor((double)p.y)) - (double)0.5f);
 	tex_interp_coords(&x0, &x1, &x2, &x3, &dx, xf, resx, rep, t->mirror_x);
 	tex_interp_coords(&y0, &y1, &y2, &y3, &dy, yf, resy, rep, t->mirror_y);
 	rgba_t c11 = tex_pixel(t, x1, y1), c21 = tex_pixel(t, x2, y1), c12 = tex_pixel(t, x1, y2), c22 = tex_pixel(t, x2, y2);
@@ -1816,7 +1817,7 @@ static v3 glass_normal(const sp_t *sp, v3 wo)
  * every supported node is view independent) and what the material's functions read through a shader slot is written
  * into a copy of the material record: `slot ? slot->getColor / getScalar(stack) : member` becomes the member of the copy.
  * Untextured materials are returned as they are. */
-#define YOR_MAX_NODES 32
+#define YOR_MAX_NODES 128
 static const mat_t *mat_resolve(const yor_scene *s, const sp_t *sp, mat_t *out)
 {
 	const mat_t *m = &s->mats[sp->mat];

@@ -24,13 +24,16 @@ def main():
     if not os.path.isdir("/root/reference"):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, timeout=900)
-    for variant in ("fast", "ieee"):
-        exe = os.path.join(ROOT, "oracle", "_ref", f"ref_components_{variant}")
-        out = subprocess.run([exe], check=True, capture_output=True, timeout=60).stdout
-        path = os.path.join(HERE, f"ref_components_{variant}.json.gz")
-        with gzip.GzipFile(path, "wb", mtime=0) as f:
-            f.write(out)
-        print(path, len(out), "bytes raw")
+    which = sys.argv[1:] or ["components", "textures"]
+    for name in which:          # textures: image textures + shader nodes, oracle/ref_harness/ref_textures.cc
+        for variant in ("fast", "ieee"):
+            exe = os.path.join(ROOT, "oracle", "_ref", f"ref_{name}_{variant}")
+            out = subprocess.run([exe], check=True, capture_output=True, timeout=120).stdout
+            out = out[out.index(b"{\n"):]          # the reference's handlers log to stdout before the document starts
+            path = os.path.join(HERE, f"ref_{name}_{variant}.json.gz")
+            with gzip.GzipFile(path, "wb", mtime=0) as f:
+                f.write(out)
+            print(path, len(out), "bytes raw")
 
 
 if __name__ == "__main__":

@@ -1589,6 +1589,14 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				s->h_seg_seed.push_back(0u);           // keeps the two tables aligned (n + 1 entries per chunk)
 			}
 		}
+		if(std::getenv("YAFGPU_VERBOSE"))
+		{
+			std::fprintf(stderr, "[yafgpu] replay pass_offset %u accumulate %d spp %u: seeds", rp.pass_offset, rp.accumulate, spp);
+			for(size_t k = 0; k < std::min<size_t>(s->h_seg_seed.size(), 6); ++k) std::fprintf(stderr, " %u", s->h_seg_seed[k]);
+			std::fprintf(stderr, " ... entries/tile");
+			for(size_t k = 0; k + 1 < std::min<size_t>(s->h_seg_begin.size(), 7); ++k) std::fprintf(stderr, " %u", s->h_seg_begin[k + 1] - s->h_seg_begin[k]);
+			std::fprintf(stderr, "\n");
+		}
 		const size_t segs = s->h_seg_begin.size();
 		if(segs > s->rp_segs)
 		{
@@ -1765,6 +1773,13 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				hipLaunchKernelGGL(wf_replay_tiles, dim3(n_seg), dim3(kWave), 0, stream, r);
 				hipLaunchKernelGGL(wf_replay_bases, dim3(1), dim3(1), 0, stream, r);
 				hipLaunchKernelGGL(wf_replay_samples, dim3(n_seg), dim3(kWave), 0, stream, r); }))) return rc;
+			if(std::getenv("YAFGPU_VERBOSE"))
+			{
+				uint32_t cnt_now = 0;
+				HIP_OK(hipMemcpyAsync(&cnt_now, s->rp_counter, sizeof cnt_now, hipMemcpyDeviceToHost, stream));
+				HIP_OK(hipStreamSynchronize(stream));
+				std::fprintf(stderr, "[yafgpu] replay chunk of %u tiles: light counter now %u\n", n_seg, cnt_now);
+			}
 			a.replay = 2;
 			seg_off += n_seg + 1;
 		}

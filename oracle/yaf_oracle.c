@@ -3339,6 +3339,7 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 	int tile_rand = (int)rd->tile_seed_rand;
 	if(wk->tile_rand) tile_rand = wk->tile_rand[__atomic_fetch_add(wk->tile_rand_next, 1, __ATOMIC_RELAXED)];
 	mwc_init(&prng, (uint32_t)(tile_rand + offset * (x * ay + ax) + 123));
+	if(getenv("YOR_VERBOSE") && ty == 0) fprintf(stderr, "[oracle] pass offset %d tile (%d,%d): seed %u, light counter %u\n", offset, tx, ty, (uint32_t)(tile_rand + offset * (x * ay + ax) + 123), st->correlative_sample_number);
 	st->prng = &prng;
 	int pass_offs = offset;
 	for(int i = ay; i < end_y; ++i)

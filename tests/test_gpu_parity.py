@@ -344,9 +344,13 @@ def test_full_size_c4_one_light_against_oracle_windows(pipeline):
 
 
 # ---- serial-state replay: the reference's per-tile roulette stream and its light counter -------------
-def _render_with_rand_state(sc, rd, replay=True):
+def _render_with_rand_state(sc, rd, replay=True, same_tree=False):
     """device render + the oracle's SINGLE-THREADED render of the same scene with the libc state the device side derived
-    for it (srand seed of the last constructor, values its colour loop consumed): the reference's serial semantics"""
+    for it (srand seed of the last constructor, values its colour loop consumed): the reference's serial semantics.
+    same_tree: the oracle walks the product's kd-tree — multi-pass renders put sample 1 of every pixel on the pixel's
+    diagonal (riVdC(1, r) = riS(1, r)), where a camera ray can run exactly into the edge two walls of the box share: a
+    tie in t that TriKdTree::intersect resolves by visiting order, i.e. by tree topology (see test_multi_pass_anti_aliasing).
+    With serial state one such sample shifts the light counter of every sample after it."""
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.setSerialReplay(replay)
@@ -354,7 +358,10 @@ def _render_with_rand_state(sc, rd, replay=True):
     assert seed > 0 and skip >= 3
     yi.render()
     film, st = yi.getFilm(rd["width"], rd["height"]), yi.getRenderStats()
-    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=1, rand_srand=seed, rand_skip=skip))
+    osc = po.OracleScene(sc)
+    if same_tree:
+        osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4, device=DEVICE_TREE)[:3])
+    ofilm, ost = osc.render(dict(rd, oracle_threads=1, rand_srand=seed, rand_skip=skip))
     return film, st, ofilm, ost
 
 
@@ -367,6 +374,7 @@ def _render_with_rand_state(sc, rd, replay=True):
     dict(n_lights=1, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02)),   # ... the stream alone
     dict(n_lights=2, bounces=4, rr=4, path_samples=1, aa=dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02)),   # ... the counter alone
     dict(n_lights=2, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=2, AA_inc_samples=2, AA_threshold=0.0)),    # every pixel again
+    dict(n_lights=2, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=2, AA_inc_samples=2, AA_threshold=10.0)),   # no pixel again: pass 0 in the multi-pass mode
 ])
 def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, monkeypatch):
     """Russian roulette ON (the reference's default, integrator_path_tracer.cc:355) and / or more than one light: the
@@ -379,7 +387,8 @@ def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, 
     sc = scenes.cornell_soup(1500, seed=41 + case["bounces"], res=(72, 56), n_lights=case["n_lights"], glossy_fraction=case.get("glossy", 0.0))
     rd = scenes.render_settings(72, 56, 6, bounces=case["bounces"], path_samples=case["path_samples"], tile_size=16,
                                 russian_roulette_min_bounces=case["rr"], **case.get("aa", {}))
-    film, st, ofilm, ost = _render_with_rand_state(sc, rd)
+    multi = "aa" in case
+    film, st, ofilm, ost = _render_with_rand_state(sc, rd, same_tree=multi)
     wdiff = int((film[..., 4] != ofilm[..., 4]).sum())
     exact = float((film == ofilm).all(axis=-1).mean())
     print(f"serial replay {case}: rays {st.rays_closest}+{st.rays_shadow} vs oracle {ost.rays_closest}+{ost.rays_shadow}, samples {st.camera_samples} vs {ost.camera_samples}, "
@@ -390,12 +399,12 @@ def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, 
     # chunk borders (whole tiles per chunk) do not change anything.  (Every scene set-up moves the libc state on — the
     # material counter is process-wide, as in the reference — so each render is compared with its own oracle run.)
     monkeypatch.setenv("YAFGPU_WF_CHUNK", "4096")
-    film2, st2, ofilm2, ost2 = _render_with_rand_state(sc, rd)
+    film2, st2, ofilm2, ost2 = _render_with_rand_state(sc, rd, same_tree=multi)
     assert st2.rays_closest == ost2.rays_closest and st2.rays_shadow == ost2.rays_shadow, "chunked replay: ray counts differ from the oracle"
     compare_films(film2, ofilm2, f"serial replay, chunked {case}")
     monkeypatch.delenv("YAFGPU_WF_CHUNK")
     # and the per-sample streams (replay off) render something else: the state does matter in this scene
-    film3, st3, _, _ = _render_with_rand_state(sc, rd, replay=False)
+    film3, st3, _, _ = _render_with_rand_state(sc, rd, replay=False, same_tree=multi)
     assert not np.array_equal(film3, film)
 
 

@@ -29,6 +29,7 @@ typedef struct yafaray_interface yafaray_interface_t;
 /* borrowed handles, owned by the interface until clearAll (environment.h:85-95) */
 typedef struct yafaray_material yafaray_material_t;
 typedef struct yafaray_light yafaray_light_t;
+typedef struct yafaray_texture yafaray_texture_t;
 typedef struct yafaray_camera yafaray_camera_t;
 typedef struct yafaray_background yafaray_background_t;
 typedef struct yafaray_integrator yafaray_integrator_t;
@@ -111,11 +112,18 @@ void yafaray_paramsEndList(yafaray_interface_t *yi);                            
  * Material::factory (src/material/material.cc:36-52), Light::factory (src/light/light.cc:36-51),
  * Camera::factory (src/camera/camera.cc:34-44), Integrator::factory (src/integrator/integrator.cc:36-57) */
 yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name);            /* :92 */
+yafaray_texture_t *yafaray_createTexture(yafaray_interface_t *yi, const char *name);        /* :93: type "image" (TGA, HDR and PNG files; none /
+                                                                                               bilinear interpolation); procedural types are refused */
 yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *name);      /* :94 */
 yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name);          /* :95 */
 yafaray_background_t *yafaray_createBackground(yafaray_interface_t *yi, const char *name);  /* :96 */
 yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const char *name);  /* :97 */
 void yafaray_clearAll(yafaray_interface_t *yi);                                             /* :101 */
+/* not in the reference's Interface: an image texture over RGBA float texels the caller holds (row major, as the reference's
+ * ImageHandler::getPixel(x, y) would return them), configured by the current ParamMap like createTexture; and the decoded image
+ * behind a texture (the file decoders' test hook) */
+yafaray_texture_t *yafaray_createTextureFromMemory(yafaray_interface_t *yi, const char *name, int width, int height, const float *rgba);
+yafaray_bool_t yafaray_getTextureImage(yafaray_interface_t *yi, const char *name, int *width, int *height, float *rgba, int n_floats);
 /* refused with a diagnostic (NULL / 0 and yafaray_getLastError): */
 unsigned int yafaray_createObject(yafaray_interface_t *yi, const char *name);               /* :100 */
 void *yafaray_createVolumeRegion(yafaray_interface_t *yi, const char *name);                /* :98 */

@@ -64,7 +64,58 @@ typedef struct yafgpu_material
 	uint32_t tm_flags;             /* the transmission lobe: Filter|Transmit with fake shadows, else Specular|Transmit */
 	int32_t has_vol_i;             /* glass "absorption": vol_i_ = BeerVolumeHandler (material_glass.cc:371-398), bsdf_flags has Volumetric */
 	float beer_sigma[3];           /* its sigma_a_ = -log(absorption) / absorption_dist (volumehandler_beer.cc:28-35) */
+	/* shader nodes: the material's nodes are nodes[node_first .. node_first + n_nodes) of the scene's node array,
+	   in evaluation order (NodeMaterial::solveNodesOrder, material_node.cc:88-108); each shader slot names the node it reads
+	   (index into that range) or -1.  shinydiffusemat slots, material_shiny_diffuse.cc:697-724. */
+	int32_t node_first, n_nodes;
+	int32_t sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
+	float ior_base;                /* ior_ (the IOR shader adds to it, :258-262) */
+	float emit_strength;           /* emit_strength_ (emit() with a diffuse shader: colour * emit_strength_, :300) */
+	int32_t has_diffuse_refl;      /* the fields below are only set in a resolved per-hit copy of the record (mat_resolve) */
+	float diffuse_refl;
+	int32_t oren_tex;              /* orenNayar with a texture's sigma: A and B in double (:230-235) */
+	double oren_ad, oren_bd;
 } yafgpu_material;
+
+/* ImageTexture (src/texture/texture_image.cc) over float texels that hold what ImageHandler::getPixel returns (the host decoded
+   the file, linearised its colours and pushed them through the image buffer's storage format) */
+typedef struct yafgpu_texture
+{
+	int32_t width, height;
+	uint32_t texel_first;          /* first texel in the scene's texel array (float4 units), row-major, row y = the handler's row y */
+	int32_t interpolate;           /* 0 none, 1 bilinear */
+	int32_t clip;                  /* TexClipMode: 0 extend, 1 clip, 2 clipcube, 3 repeat, 4 checker */
+	int32_t xrepeat, yrepeat, rot90, mirror_x, mirror_y, checker_even, checker_odd;
+	float checker_dist;
+	int32_t cropx, cropy;
+	float cropminx, cropmaxx, cropminy, cropmaxy;
+	int32_t adj_set, adj_clamp;
+	float adj_int, adj_con, adj_sat, adj_hue, adj_r, adj_g, adj_b;    /* adj_hue already divided by 60 (Texture::setAdjustments) */
+	int32_t color_space;           /* for getRawColor / getFloat: 0 sRGB, 1 XYZ, 2 LinearRGB, 3 RawManualGamma */
+	float gamma;
+} yafgpu_texture;
+
+enum { YAFGPU_NODE_TEXTURE_MAPPER = 0, YAFGPU_NODE_VALUE = 1, YAFGPU_NODE_MIX = 2, YAFGPU_NODE_LAYER = 3 };
+/* one shader node after its factory() / configInputs() ran on the host (shader_node_basic.cc, shader_node_layer.cc); node
+   references are indices into the material's node range, -1 = not connected */
+typedef struct yafgpu_node
+{
+	int32_t type;
+	/* texture_mapper */
+	int32_t texture, texco, mapping, map_x, map_y, map_z, do_scalar;
+	float scale[3], offset[3];     /* offset already doubled (TextureMapperNode::factory :411) */
+	float mtx[16];
+	/* value */
+	float color[4]; float value;
+	/* mix */
+	int32_t mode; float cfactor; int32_t input1, input2, factor;
+	float col1[4], col2[4];
+	/* layer */
+	int32_t input, upper; uint32_t texflag;
+	float colfac, valfac, def_val, upper_val;
+	float def_col[4], upper_col[4];
+	int32_t do_color, do_scalar_l, color_input, use_alpha;
+} yafgpu_node;
 
 /* A light after its constructor ran on the host (light_area.cc:34-52, light_point.cc:28-36) */
 typedef struct yafgpu_light
@@ -90,6 +141,9 @@ typedef struct yafgpu_camera
 	float bokeh_rotation;          /* degrees */
 	float dof_rt[3], dof_up[3];    /* aperture * cam_x, aperture * cam_y */
 	float ls[16];                  /* polygon corner table; filled by yafgpu_scene_create from bokeh_type / bokeh_rotation */
+	/* for the `window` / `normal` texture coordinates (PerspectiveCamera::screenproject, Camera::getAxis) */
+	float cam_x[3], cam_y[3], cam_z[3];
+	float focal_distance, aspect_ratio;
 } yafgpu_camera;
 
 typedef struct yafgpu_scene_desc
@@ -98,6 +152,12 @@ typedef struct yafgpu_scene_desc
 	const float *verts;          /* n_tris*9: a,b,c */
 	const int32_t *tri_mat;      /* n_tris */
 	const float *vnormals;       /* NULL or n_tris*9; an all-zero triple means "use the geometric normal" */
+	/* texture coordinates per triangle corner (Triangle::getSurface, triangle.cc:46-79): uv = n_tris*6 floats or NULL,
+	   orco = n_tris*9 floats or NULL; only read when some material has shader nodes */
+	const float *tri_uv, *tri_orco;
+	int32_t n_textures; const yafgpu_texture *textures;
+	uint64_t n_texels; const float *texels;      /* n_texels * 4 floats */
+	int32_t n_nodes; const yafgpu_node *nodes;
 	int32_t n_materials;
 	const yafgpu_material *materials;
 	int32_t n_lights;

@@ -7,12 +7,15 @@
 // and Scene::update (scene.cc:784-894).  Everything per-sample happens on the device (yafgpu.h).
 #include "../../include/yafaray_c_api.h"
 #include "../../include/yafgpu.h"
+#include "yafaray_image.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <limits>
 #include <list>
 #include <map>
 #include <memory>
@@ -71,7 +74,8 @@ struct BackgroundCfg { float color[3]; };
 
 } // namespace
 
-struct yafaray_material { yafgpu_material m; int index; };
+struct yafaray_material { yafgpu_material m; int index; std::vector<yafgpu_node> nodes; };   // nodes: evaluation order, `texture` = index into texture_order
+struct yafaray_texture { yafgpu_texture t; int index; std::vector<float> texels; };            // texels: height * width * 4, as ImageHandler::getPixel returns them
 struct yafaray_light { yafgpu_light l; };
 struct yafaray_camera { CameraCfg c; };
 struct yafaray_background { BackgroundCfg b; };
@@ -86,6 +90,9 @@ struct yafaray_interface
 	// registries, name -> object (environment.h:85-95)
 	std::map<std::string, std::unique_ptr<yafaray_material>> materials;
 	std::vector<yafaray_material *> material_order;
+	std::map<std::string, std::unique_ptr<yafaray_texture>> textures;
+	std::vector<yafaray_texture *> texture_order;
+	std::string base_dir;                // where relative texture file names are looked up after the working directory (the XML file's directory)
 	std::map<std::string, std::unique_ptr<yafaray_light>> lights;
 	std::vector<yafaray_light *> light_order;
 	std::map<std::string, std::unique_ptr<yafaray_camera>> cameras;
@@ -185,8 +192,170 @@ int visibility_from(const std::string &s)
 	return 0;
 }
 
+
+// ---- shader nodes -----------------------------------------------------------------------------------
+inline void clear_shader_slots(yafgpu_material &m)
+{
+	m.node_first = 0; m.n_nodes = 0;
+	m.sh_diffuse = m.sh_mirror_color = m.sh_mirror = m.sh_transparency = m.sh_translucency = m.sh_sigma_oren = m.sh_diffuse_refl = m.sh_ior = -1;
+}
+
+constexpr int kMaxMaterialNodes = 16;    // yafgpu_texture.h kMaxNodes: the per-lane node stack of the shading kernels
+
+struct LoadedNodes
+{
+	std::vector<yafgpu_node> nodes;                 // as listed (loadNodes order), references = indices into this list
+	std::map<std::string, int> by_name;
+};
+
+// the four factories + configInputs (shader_node.cc:28-37; shader_node_basic.cc:345-409, :425-434, :482-531, :683-703;
+// shader_node_layer.cc:162-201, :211-245).  -1 = the reference's own failure (it then builds the material without shaders,
+// material_shiny_diffuse.cc:709-713), 0 = refused by the GPU path (err set), 1 = loaded
+int load_nodes(yafaray_interface *yi, const std::list<ParamMap> &list, LoadedNodes &out)
+{
+	std::vector<const ParamMap *> maps;
+	for(const ParamMap &pm : list)
+	{	// NodeMaterial::loadNodes, material_node.cc:150-205
+		std::string element, name, type;
+		if(pm.get("element", element) && element != "shader_node") continue;
+		if(!pm.get("name", name)) return -1;
+		if(out.by_name.count(name)) return -1;
+		if(!pm.get("type", type)) return -1;
+		yafgpu_node n; std::memset(&n, 0, sizeof n);
+		n.texture = n.input1 = n.input2 = n.factor = n.input = n.upper = -1;
+		if(type == "texture_mapper")
+		{
+			n.type = YAFGPU_NODE_TEXTURE_MAPPER;
+			std::string texname, option;
+			if(!pm.get("texture", texname)) return -1;
+			auto tex = yi->textures.find(texname);
+			if(tex == yi->textures.end()) return -1;
+			n.texture = tex->second->index;
+			n.texco = 1;         // Coords { Uv, Glob, Orco, Tran, Nor, Refl, Win, Stick, Stress, Tan }, shader_node_basic.h
+			if(pm.get("texco", option))
+			{
+				static const char *names[] = {"uv", "global", "orco", "transformed", "normal", "reflect", "window", "stick", "stress", "tangent"};
+				for(int k = 0; k < 10; ++k) if(option == names[k]) n.texco = k;
+			}
+			n.mapping = 0;       // Projection { Plain, Cube, Tube, Sphere }; image textures are discrete()
+			if(pm.get("mapping", option))
+			{
+				static const char *names[] = {"plain", "cube", "tube", "sphere"};
+				for(int k = 0; k < 4; ++k) if(option == names[k]) n.mapping = k;
+			}
+			float scale[3] = {1, 1, 1}, offset[3] = {0, 0, 0}; bool scalar = true; int map[3] = {1, 2, 3};
+			for(int k = 0; k < 16; ++k) n.mtx[k] = (k % 5 == 0) ? 1.f : 0.f;
+			{ auto it = pm.dicc.find("transform"); if(it != pm.dicc.end() && it->second.type == Param::Matrix) std::memcpy(n.mtx, it->second.m, sizeof n.mtx); }
+			pm.getPoint("scale", scale); pm.getPoint("offset", offset); pm.get("do_scalar", scalar);
+			pm.get("proj_x", map[0]); pm.get("proj_y", map[1]); pm.get("proj_z", map[2]);
+			for(int k = 0; k < 3; ++k) map[k] = std::min(3, std::max(0, map[k]));
+			n.map_x = map[0]; n.map_y = map[1]; n.map_z = map[2];
+			for(int k = 0; k < 3; ++k) { n.scale[k] = scale[k]; n.offset[k] = 2 * offset[k]; }
+			n.do_scalar = scalar ? 1 : 0;
+		}
+		else if(type == "value")
+		{
+			n.type = YAFGPU_NODE_VALUE;
+			float col[3] = {1, 1, 1}, alpha = 1.f, val = 1.f;
+			pm.getColor("color", col); pm.get("alpha", alpha); pm.get("scalar", val);
+			n.color[0] = col[0]; n.color[1] = col[1]; n.color[2] = col[2]; n.color[3] = alpha; n.value = val;
+		}
+		else if(type == "mix")
+		{
+			n.type = YAFGPU_NODE_MIX;
+			float val = 0.5f; int mode = 0;
+			pm.get("cfactor", val); pm.get("mode", mode);
+			// MixNode::factory's switch has no case for MnDiv (5) and none above MnOverlay (9): those build a plain MixNode
+			n.mode = (mode >= 0 && mode <= 9 && mode != 5) ? mode : 0;
+			n.cfactor = (n.mode == 0) ? val : 0.f;       // MixNode(val) / the derived nodes' MixNode(): cfactor_ 0
+			n.col1[3] = n.col2[3] = 1.f;
+		}
+		else if(type == "layer")
+		{
+			n.type = YAFGPU_NODE_LAYER;
+			float def_col[3] = {1, 1, 1};
+			bool do_color = true, do_scalar = false, color_input = true, use_alpha = false, stencil = false, no_rgb = false, negative = false;
+			double def_val = 1.0, colfac = 1.0, valfac = 1.0; int mode = 0;
+			pm.get("mode", mode); pm.getColor("def_col", def_col); pm.get("colfac", colfac); pm.get("def_val", def_val); pm.get("valfac", valfac);
+			pm.get("do_color", do_color); pm.get("do_scalar", do_scalar); pm.get("color_input", color_input); pm.get("use_alpha", use_alpha);
+			pm.get("noRGB", no_rgb); pm.get("stencil", stencil); pm.get("negative", negative);
+			n.texflag = (no_rgb ? 1u : 0u) | (stencil ? 2u : 0u) | (negative ? 4u : 0u) | (use_alpha ? 8u : 0u);
+			n.mode = mode; n.colfac = (float)colfac; n.valfac = (float)valfac; n.def_val = (float)def_val;
+			n.def_col[0] = def_col[0]; n.def_col[1] = def_col[1]; n.def_col[2] = def_col[2]; n.def_col[3] = 1.f;
+			n.do_color = do_color; n.do_scalar_l = do_scalar; n.color_input = color_input; n.use_alpha = use_alpha;
+		}
+		else return -1;      // ShaderNode::factory knows no other type: "No shader node was constructed by plugin"
+		out.by_name[name] = (int)out.nodes.size();
+		out.nodes.push_back(n);
+		maps.push_back(&pm);
+	}
+	for(size_t k = 0; k < out.nodes.size(); ++k)
+	{	// configInputs, material_node.cc:207-220
+		yafgpu_node &n = out.nodes[k]; const ParamMap &pm = *maps[k];
+		auto find = [&](const std::string &nm) { auto it = out.by_name.find(nm); return it == out.by_name.end() ? -1 : it->second; };
+		auto rgba = [&](const char *key, float o[4]) { auto it = pm.dicc.find(key); if(it == pm.dicc.end() || it->second.type != Param::Color) return false; for(int c = 0; c < 4; ++c) o[c] = it->second.v[c]; return true; };
+		std::string name;
+		if(n.type == YAFGPU_NODE_MIX)
+		{
+			if(pm.get("input1", name)) { if((n.input1 = find(name)) < 0) return -1; }
+			else if(!rgba("color1", n.col1)) return -1;
+			if(pm.get("input2", name)) { if((n.input2 = find(name)) < 0) return -1; }
+			else if(!rgba("color2", n.col2)) return -1;
+			if(pm.get("factor", name)) { if((n.factor = find(name)) < 0) return -1; }
+			else if(!pm.get("value", n.cfactor)) return -1;
+		}
+		else if(n.type == YAFGPU_NODE_LAYER)
+		{
+			if(!pm.get("input", name)) return -1;
+			if((n.input = find(name)) < 0) return -1;
+			if(pm.get("upper_layer", name)) { if((n.upper = find(name)) < 0) return -1; }
+			else
+			{
+				n.upper_col[3] = 1.f;
+				if(!rgba("upper_color", n.upper_col)) { n.upper_col[0] = n.upper_col[1] = n.upper_col[2] = 0.f; n.upper_col[3] = 1.f; }
+				if(!pm.get("upper_value", n.upper_val)) n.upper_val = 0.f;
+			}
+		}
+	}
+	return 1;
+}
+
+// NodeMaterial::solveNodesOrder + getNodeList (material_node.cc:88-121): the nodes the material's shader slots reach, every node
+// after the ones it reads.  slots: in = index into ld.nodes or -1, out = index into `sorted`.  false: a cycle, or more nodes
+// than the shading kernels' stack holds (err set).
+bool sort_nodes(yafaray_interface *yi, const LoadedNodes &ld, int *slots, int n_slots, std::vector<yafgpu_node> &sorted)
+{
+	const int n = (int)ld.nodes.size();
+	std::vector<int> new_index((size_t)n, -1), mark((size_t)n, 0);
+	std::vector<int> order;
+	bool cycle = false;
+	std::function<void(int)> visit = [&](int k)
+	{
+		if(k < 0 || mark[(size_t)k] == 2) return;
+		if(mark[(size_t)k] == 1) { cycle = true; return; }
+		mark[(size_t)k] = 1;
+		const yafgpu_node &nd = ld.nodes[(size_t)k];
+		visit(nd.input1); visit(nd.input2); visit(nd.factor); visit(nd.input); visit(nd.upper);
+		mark[(size_t)k] = 2;
+		new_index[(size_t)k] = (int)order.size(); order.push_back(k);
+	};
+	for(int s = 0; s < n_slots; ++s) visit(slots[s]);
+	if(cycle) return fail(yi, "shader nodes: the node graph has a cycle");
+	if((int)order.size() > kMaxMaterialNodes) return fail(yi, "shader nodes: more than 16 nodes reachable from one material's shader slots is not supported by the GPU path");
+	auto remap = [&](int k) { return k < 0 ? -1 : new_index[(size_t)k]; };
+	sorted.clear();
+	for(int k : order)
+	{
+		yafgpu_node nd = ld.nodes[(size_t)k];
+		nd.input1 = remap(nd.input1); nd.input2 = remap(nd.input2); nd.factor = remap(nd.factor); nd.input = remap(nd.input); nd.upper = remap(nd.upper);
+		sorted.push_back(nd);
+	}
+	for(int s = 0; s < n_slots; ++s) slots[s] = remap(slots[s]);
+	return true;
+}
+
 // ShinyDiffuseMaterial::factory + ctor + config, material_shiny_diffuse.cc:599-690, :26-36, :46-92
-bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
 {
 	float color[3] = {1, 1, 1}, mirror_color[3] = {1, 1, 1};
 	float diffuse = 1.f, transp = 0.f, transl = 0.f, mirror = 0.f, emit = 0.f, ior = 1.33f, wire = 0.f;
@@ -206,8 +375,33 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 		if(add_depth != 0) return fail(yi, "shinydiffusemat: additionaldepth is not supported by the GPU path");
 		if(tb_factor != 0.f || tb_mult) return fail(yi, "shinydiffusemat: transparentbias_factor / transparentbias_multiply_raydepth are not supported by the GPU path");
 	}
-	if(!yi->eparams.empty()) return fail(yi, "shinydiffusemat: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
+	// shader nodes, material_shiny_diffuse.cc:692-747: slots in the order of yafgpu_material's sh_* fields
+	enum { kDiffuse, kMirrorColor, kMirror, kTransparency, kTranslucency, kSigmaOren, kDiffuseRefl, kIor, kBump, kWireframe, kSlots };
+	int slots[kSlots]; for(int &v : slots) v = -1;
+	nodes.clear();
+	if(!yi->eparams.empty())
+	{
+		LoadedNodes ld;
+		const int rc = load_nodes(yi, yi->eparams, ld);
+		if(rc == 0) return false;
+		if(rc > 0)
+		{	// parseNodes, material_node.cc:227-247: a slot naming a node that does not exist stays empty
+			static const char *names[kSlots] = {"diffuse_shader", "mirror_color_shader", "mirror_shader", "transparency_shader", "translucency_shader",
+			                                    "sigma_oren_shader", "diffuse_refl_shader", "IOR_shader", "bump_shader", "wireframe_shader"};
+			std::string node;
+			for(int k = 0; k < kSlots; ++k) if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
+			if(slots[kBump] >= 0) return fail(yi, "shinydiffusemat: bump_shader (bump / normal mapping) is not supported by the GPU path");
+			if(slots[kWireframe] >= 0) return fail(yi, "shinydiffusemat: wireframe_shader is not supported by the GPU path");
+			if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
+		}
+		else std::fprintf(stderr, "WARNING: ShinyDiffuse: Loading shader nodes failed! (the material is built without them, as the reference does)\n");
+	}
 	std::memset(&m, 0, sizeof m);
+	clear_shader_slots(m);
+	m.n_nodes = (int32_t)nodes.size();
+	m.sh_diffuse = slots[kDiffuse]; m.sh_mirror_color = slots[kMirrorColor]; m.sh_mirror = slots[kMirror]; m.sh_transparency = slots[kTransparency];
+	m.sh_translucency = slots[kTranslucency]; m.sh_sigma_oren = slots[kSigmaOren]; m.sh_diffuse_refl = slots[kDiffuseRefl]; m.sh_ior = slots[kIor];
+	m.ior_base = ior; m.emit_strength = emit;
 	m.type = YAFGPU_MAT_SHINYDIFFUSE; m.visibility = visibility_from(vis); m.receive_shadows = recv; m.flat = flat;
 	for(int k = 0; k < 3; ++k) { m.diffuse_color[k] = color[k]; m.mirror_color[k] = mirror_color[k]; m.emit_color[k] = emit * color[k]; }
 	m.diffuse_strength = diffuse; m.transparency_strength = transp; m.translucency_strength = transl; m.mirror_strength = mirror;
@@ -226,24 +420,25 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	}
 	float acc = 1.f;
 	m.n_bsdf = 0;
-	if(m.mirror_strength > 0.00001f)
+	if(m.mirror_strength > 0.00001f || m.sh_mirror >= 0)
 	{
 		m.is_mirror = 1;
-		if(!m.has_fresnel) acc = 1.f - m.mirror_strength;
+		if(m.sh_mirror >= 0) {}
+		else if(!m.has_fresnel) acc = 1.f - m.mirror_strength;
 		m.bsdf_flags |= 0x1u | 0x10u;
 		m.c_flags[m.n_bsdf] = 0x1u | 0x10u; m.c_index[m.n_bsdf] = 0; ++m.n_bsdf;
 	}
-	if(m.transparency_strength * acc > 0.00001f)
+	if(m.transparency_strength * acc > 0.00001f || m.sh_transparency >= 0)
 	{
 		m.is_transparent = 1;
-		acc *= 1.f - m.transparency_strength;
+		if(m.sh_transparency < 0) acc *= 1.f - m.transparency_strength;
 		m.bsdf_flags |= 0x20u | 0x40u;
 		m.c_flags[m.n_bsdf] = 0x20u | 0x40u; m.c_index[m.n_bsdf] = 1; ++m.n_bsdf;
 	}
-	if(m.translucency_strength * acc > 0.00001f)
+	if(m.translucency_strength * acc > 0.00001f || m.sh_translucency >= 0)
 	{
 		m.is_translucent = 1;
-		acc *= 1.f - m.transparency_strength; // sic, material_shiny_diffuse.cc:72
+		if(m.sh_translucency < 0) acc *= 1.f - m.transparency_strength; // sic, material_shiny_diffuse.cc:72
 		m.bsdf_flags |= 0x4u | 0x20u;
 		m.c_flags[m.n_bsdf] = 0x4u | 0x20u; m.c_index[m.n_bsdf] = 2; ++m.n_bsdf;
 	}
@@ -447,7 +642,9 @@ bool make_camera(yafaray_interface *yi, const ParamMap &p, yafgpu_camera &c)
 		c.vup[k] = vup / (float)resy;
 		c.vright[k] = vright / (float)resx;
 		c.dof_rt[k] = apt * cx[k]; c.dof_up[k] = apt * cy[k];         // setAxis, :66-67
+		c.cam_x[k] = cx[k]; c.cam_y[k] = cy[k]; c.cam_z[k] = cz[k];
 	}
+	c.focal_distance = dfocal; c.aspect_ratio = aspect_ratio;
 	c.aperture = apt; c.dof_distance = dofd; c.bokeh_rotation = bkhrot;
 	c.bokeh_type = bkhtype == "disk2" ? 1 : bkhtype == "triangle" ? 3 : bkhtype == "square" ? 4 : bkhtype == "pentagon" ? 5
 	             : bkhtype == "hexagon" ? 6 : bkhtype == "ring" ? 7 : 0;
@@ -494,7 +691,20 @@ yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, in
 	yi->cur = &m; yi->last = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
 	return 1;
 }
-yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi) { if(yi->state != 2) return fail(yi, "endTriMesh: wrong state"); yi->state = 1; yi->cur = nullptr; return 1; }
+yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi)
+{	// Scene::endTriMesh, scene.cc:311-337: "UV-offsets mismatch!" when the triangle and UV-offset counts disagree; the reference never
+	// range-checks the offsets themselves (exporters may list <uv> after the faces), so that check waits until here
+	if(yi->state != 2) return fail(yi, "endTriMesh: wrong state");
+	Mesh &m = *yi->cur;
+	if(m.has_uv)
+	{
+		if(m.tri_uv.size() != m.tri.size()) return fail(yi, "endTriMesh: UV-offsets mismatch!");
+		const int nuv = (int)(m.uv.size() / 2);
+		for(int o : m.tri_uv) if(o < 0 || o >= nuv) return fail(yi, "endTriMesh: UV index out of range");
+	}
+	yi->state = 1; yi->cur = nullptr;
+	return 1;
+}
 int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z)
 {
 	if(yi->state != 2) { fail(yi, "addVertex: wrong state"); return -1; }
@@ -503,7 +713,7 @@ int yafaray_addVertex(yafaray_interface_t *yi, double x, double y, double z)
 	return (int)(m.points.size() / 3) - 1;
 }
 void yafaray_addNormal(yafaray_interface_t *yi, double nx, double ny, double nz)
-{	// Scene::addNormal, scene.cc:380-400: attaches to the last vertex
+{	// Scene::addNormal, scene.cc:592-607: attaches to the last vertex
 	if(yi->state != 2) { fail(yi, "addNormal: wrong state"); return; }
 	Mesh &m = *yi->cur;
 	const size_t nv = m.points.size() / 3;
@@ -523,7 +733,7 @@ yafaray_bool_t yafaray_addTriangle(yafaray_interface_t *yi, int a, int b, int c,
 	return 1;
 }
 int yafaray_addVertexWithOrco(yafaray_interface_t *yi, double x, double y, double z, double ox, double oy, double oz)
-{	// Interface::addVertex(x, y, z, ox, oy, oz) -> Scene::addVertex(p, orco), scene.cc:352-366
+{	// Interface::addVertex(x, y, z, ox, oy, oz) -> Scene::addVertex(p, orco), scene.cc:567-590
 	if(yi->state != 2) { fail(yi, "addVertex: wrong state"); return -1; }
 	Mesh &m = *yi->cur;
 	if(!m.has_orco) { fail(yi, "addVertex: the mesh was started without orco coordinates"); return -1; }
@@ -534,23 +744,19 @@ int yafaray_addVertexWithOrco(yafaray_interface_t *yi, double x, double y, doubl
 	return (int)(m.points.size() / 3) - 1;
 }
 int yafaray_addUv(yafaray_interface_t *yi, float u, float v)
-{	// Scene::addUv, scene.cc:545-560
+{	// Scene::addUv, scene.cc:672-686
 	if(yi->state != 2 || !yi->cur) { fail(yi, "addUv: wrong state"); return -1; }
 	Mesh &m = *yi->cur;
 	m.uv.push_back(u); m.uv.push_back(v);
 	return (int)(m.uv.size() / 2) - 1;
 }
 yafaray_bool_t yafaray_addTriangleWithUv(yafaray_interface_t *yi, int a, int b, int c, int uv_a, int uv_b, int uv_c, const yafaray_material_t *mat)
-{	// Interface::addTriangle(a, b, c, uv_a, uv_b, uv_c, mat) -> Scene::addTriangle, scene.cc:491-543
+{	// Interface::addTriangle(a, b, c, uv_a, uv_b, uv_c, mat) -> Scene::addTriangle, scene.cc:652-670
 	if(yi->state != 2) return fail(yi, "addTriangle: wrong state");
 	Mesh &m = *yi->cur;
 	if(!m.has_uv) return fail(yi, "addTriangle: the mesh was started without UV coordinates");
-	const int nuv = (int)(m.uv.size() / 2);
-	if(uv_a < 0 || uv_b < 0 || uv_c < 0 || uv_a >= nuv || uv_b >= nuv || uv_c >= nuv) return fail(yi, "addTriangle: UV index out of range");
 	if(!yafaray_addTriangle(yi, a, b, c, mat)) return 0;
-	m.tri_uv.resize(m.tri.size(), 0);
-	const size_t k = m.tri.size() - 3;
-	m.tri_uv[k] = uv_a; m.tri_uv[k + 1] = uv_b; m.tri_uv[k + 2] = uv_c;
+	m.tri_uv.push_back(uv_a); m.tri_uv.push_back(uv_b); m.tri_uv.push_back(uv_c);     // uv_offsets_.push_back x3
 	return 1;
 }
 yafaray_bool_t yafaray_startTriMeshPtr(yafaray_interface_t *yi, unsigned int *id, int vertices, int triangles, yafaray_bool_t has_orco, yafaray_bool_t has_uv, int type, int obj_pass_index)
@@ -786,7 +992,7 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	if(!yi->params.get("type", type)) { fail(yi, "createMaterial: type of material not specified"); return nullptr; }
 	auto m = std::make_unique<yafaray_material>();
 	bool ok;
-	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m);
+	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m, m->nodes);
 	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
 	else if(type == "glass") ok = make_glass(yi, yi->params, m->m);
@@ -794,6 +1000,7 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
 	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }
 	if(!ok) return nullptr;
+	if(type != "shinydiffusemat") clear_shader_slots(m->m);
 	note_srand(yi, ++g_material_index_auto);        // Material::Material, material.cc:53-57
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();
@@ -801,6 +1008,117 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	yi->materials[name] = std::move(m);
 	yi->prepared = false;
 	return raw;
+}
+// ImageTexture::factory's parameters other than the image itself (texture_image.cc:559-563, :657-716)
+static bool texture_params(yafaray_interface *yi, const ParamMap &p, yafgpu_texture &t)
+{
+	std::string intp, clip;
+	p.get("interpolate", intp);
+	if(intp == "bicubic" || intp == "mipmap_trilinear" || intp == "mipmap_ewa")
+		return fail(yi, "createTexture: interpolate \"" + intp + "\" is not supported by the GPU path (none and bilinear are)");
+	bool normalmap = false; p.get("normalmap", normalmap);
+	if(normalmap) return fail(yi, "createTexture: normal maps are not supported by the GPU path");
+	t.interpolate = intp == "none" ? 0 : 1;          // bilinear is the default (:575)
+	bool rot90 = false, even = false, odd = true, mirror_x = false, mirror_y = false, clamp = false;
+	int xrep = 1, yrep = 1; double minx = 0.0, miny = 0.0, maxx = 1.0, maxy = 1.0, cdist = 0.0;
+	float intensity = 1.f, contrast = 1.f, saturation = 1.f, hue = 0.f, fr = 1.f, fg = 1.f, fb = 1.f;
+	p.get("xrepeat", xrep); p.get("yrepeat", yrep);
+	p.get("cropmin_x", minx); p.get("cropmin_y", miny); p.get("cropmax_x", maxx); p.get("cropmax_y", maxy);
+	p.get("rot90", rot90); p.get("clipping", clip); p.get("even_tiles", even); p.get("odd_tiles", odd); p.get("checker_dist", cdist);
+	p.get("mirror_x", mirror_x); p.get("mirror_y", mirror_y);
+	p.get("adj_mult_factor_red", fr); p.get("adj_mult_factor_green", fg); p.get("adj_mult_factor_blue", fb);
+	p.get("adj_intensity", intensity); p.get("adj_contrast", contrast); p.get("adj_saturation", saturation); p.get("adj_hue", hue); p.get("adj_clamp", clamp);
+	t.xrepeat = xrep; t.yrepeat = yrep; t.rot90 = rot90; t.mirror_x = mirror_x; t.mirror_y = mirror_y;
+	t.checker_even = even; t.checker_odd = odd; t.checker_dist = (float)cdist;
+	// setCrop (:218-223): float members compared with double literals
+	t.cropminx = (float)minx; t.cropmaxx = (float)maxx; t.cropminy = (float)miny; t.cropmaxy = (float)maxy;
+	t.cropx = ((double)t.cropminx != 0.0) || ((double)t.cropmaxx != 1.0);
+	t.cropy = ((double)t.cropminy != 0.0) || ((double)t.cropmaxy != 1.0);
+	// string2Cliptype__ (:533-543): TexClipMode { Extend, Clip, ClipCube, Repeat, Checker }, anything unknown repeats
+	t.clip = clip == "extend" ? 0 : clip == "clip" ? 1 : clip == "clipcube" ? 2 : clip == "checker" ? 4 : 3;
+	// Texture::setAdjustments, texture.h:142-190
+	t.adj_int = intensity; t.adj_con = contrast; t.adj_sat = saturation; t.adj_hue = hue / 60.f; t.adj_clamp = clamp;
+	t.adj_r = fr; t.adj_g = fg; t.adj_b = fb;
+	t.adj_set = (intensity != 1.f || contrast != 1.f || saturation != 1.f || hue != 0.f || clamp || fr != 1.f || fg != 1.f || fb != 1.f) ? 1 : 0;
+	return true;
+}
+static int color_space_from(const std::string &cs)
+{	// texture_image.cc:609-613
+	if(cs == "sRGB") return yafimg::kSrgb;
+	if(cs == "XYZ") return yafimg::kXyz;
+	if(cs == "LinearRGB") return yafimg::kLinearRgb;
+	if(cs == "Raw_Manual_Gamma") return yafimg::kRawManualGamma;
+	return yafimg::kSrgb;
+}
+static yafaray_texture_t *register_texture(yafaray_interface *yi, const char *name, std::unique_ptr<yafaray_texture> t)
+{
+	t->index = (int)yi->texture_order.size();
+	yafaray_texture *raw = t.get();
+	yi->texture_order.push_back(raw);
+	yi->textures[name] = std::move(t);
+	yi->prepared = false;
+	return raw;
+}
+
+// Interface::createTexture (interface.h:84) -> RenderEnvironment::createTexture (environment.cc:203-224) -> ImageTexture::factory
+// (texture_image.cc:545-720).  Only type "image" is on the GPU path; the procedural textures are refused.
+yafaray_texture_t *yafaray_createTexture(yafaray_interface_t *yi, const char *name)
+{
+	const ParamMap &p = yi->params;
+	std::string type, file, cs = "Raw_Manual_Gamma", opt = "optimized";
+	if(!name) { fail(yi, "createTexture: null name"); return nullptr; }
+	if(yi->textures.count(name)) { fail(yi, std::string("createTexture: \"") + name + "\" already defined"); return nullptr; }
+	if(!p.get("type", type)) { fail(yi, "createTexture: type of texture not specified"); return nullptr; }
+	if(type != "image") { fail(yi, "createTexture: texture type \"" + type + "\" is outside the GPU path's scope (image textures only)"); return nullptr; }
+	auto t = std::make_unique<yafaray_texture>();
+	std::memset(&t->t, 0, sizeof t->t);
+	if(!texture_params(yi, p, t->t)) return nullptr;
+	double gamma = 1.0; bool gray = false;
+	p.get("color_space", cs); p.get("gamma", gamma); p.get("filename", file); p.get("texture_optimization", opt); p.get("img_grayscale", gray);
+	if(file.empty()) { fail(yi, "createTexture: required argument filename not found for image texture"); return nullptr; }
+	yafimg::Image img;
+	img.color_space = color_space_from(cs); img.gamma = (float)gamma; img.grayscale = gray;
+	img.optimization = opt == "optimized" ? yafimg::kOptOptimized : (opt == "compressed" ? yafimg::kOptCompressed : yafimg::kOptNone);   // :615-618
+	std::string err, path = file;
+	{	// the reference opens the name as given (relative to the working directory); the XML loader adds the scene file's directory
+		FILE *f = std::fopen(path.c_str(), "rb");
+		if(f) std::fclose(f);
+		else if(!yi->base_dir.empty() && !file.empty() && file[0] != '/') path = yi->base_dir + "/" + file;
+	}
+	if(!yafimg::load(path, img, err)) { fail(yi, "createTexture: " + err); return nullptr; }
+	t->t.width = img.width; t->t.height = img.height;
+	t->t.color_space = img.color_space; t->t.gamma = (float)gamma;      // ImageTexture(ih, interpolation, gamma, color_space) with HDR's forced LinearRgb (:600-606, :631)
+	t->texels = std::move(img.texels);
+	return register_texture(yi, name, std::move(t));
+}
+
+// Not in the reference's Interface: an image texture over texels the caller already holds (what its ImageHandler::getPixel would
+// return, row major, RGBA float), with the current ParamMap's ImageTexture parameters.  For embedders with in-memory images and
+// for the parity tests, which feed the reference harness's own buffers.
+yafaray_texture_t *yafaray_createTextureFromMemory(yafaray_interface_t *yi, const char *name, int width, int height, const float *rgba)
+{
+	const ParamMap &p = yi->params;
+	if(!name || !rgba || width <= 0 || height <= 0) { fail(yi, "createTextureFromMemory: bad arguments"); return nullptr; }
+	if(yi->textures.count(name)) { fail(yi, std::string("createTexture: \"") + name + "\" already defined"); return nullptr; }
+	auto t = std::make_unique<yafaray_texture>();
+	std::memset(&t->t, 0, sizeof t->t);
+	if(!texture_params(yi, p, t->t)) return nullptr;
+	std::string cs = "Raw_Manual_Gamma"; double gamma = 1.0;
+	p.get("color_space", cs); p.get("gamma", gamma);
+	t->t.width = width; t->t.height = height; t->t.color_space = color_space_from(cs); t->t.gamma = (float)gamma;
+	t->texels.assign(rgba, rgba + (size_t)width * (size_t)height * 4);
+	return register_texture(yi, name, std::move(t));
+}
+
+// the decoded image behind a texture (test hook for the file decoders): width / height, and up to n_floats of its RGBA texels
+yafaray_bool_t yafaray_getTextureImage(yafaray_interface_t *yi, const char *name, int *width, int *height, float *rgba, int n_floats)
+{
+	auto it = name ? yi->textures.find(name) : yi->textures.end();
+	if(it == yi->textures.end()) return fail(yi, "getTextureImage: no such texture");
+	if(width) *width = it->second->t.width;
+	if(height) *height = it->second->t.height;
+	if(rgba && n_floats > 0) std::memcpy(rgba, it->second->texels.data(), sizeof(float) * std::min((size_t)n_floats, it->second->texels.size()));
+	return 1;
 }
 yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name)
 {
@@ -893,7 +1211,7 @@ yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const ch
 void yafaray_clearAll(yafaray_interface_t *yi)
 {
 	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
-	yi->materials.clear(); yi->material_order.clear(); yi->lights.clear(); yi->light_order.clear();
+	yi->materials.clear(); yi->material_order.clear(); yi->textures.clear(); yi->texture_order.clear(); yi->lights.clear(); yi->light_order.clear();
 	yi->cameras.clear(); yi->backgrounds.clear(); yi->integrators.clear(); yi->meshes.clear();
 	yi->params.dicc.clear(); yi->eparams.clear(); yi->cparams = &yi->params;
 	yi->state = -1; yi->prepared = false; yi->geometry_changed = true; yi->film.clear();
@@ -1001,6 +1319,11 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
 	std::vector<float> verts; std::vector<int32_t> tri_mat; std::vector<float> vnormals; bool any_normals = false;
 	for(auto &kv : yi->meshes) if(kv.second.normals_exported || (kv.second.smooth && !kv.second.smooth_normals.empty())) any_normals = true;
+	// texture coordinates, only when some material evaluates shader nodes: per triangle corner UVs and orcos (yafgpu_scene_desc)
+	bool any_nodes = false;
+	for(auto *m : yi->material_order) if(!m->nodes.empty()) any_nodes = true;
+	std::vector<float> tri_uv, tri_orco;
+	const float kNoOrco = std::numeric_limits<float>::quiet_NaN();
 	for(auto &kv : yi->meshes)
 	{
 		const Mesh &m = kv.second;
@@ -1022,16 +1345,52 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 				}
 			}
 			tri_mat.push_back(m.tri_mat[t]);
+			if(any_nodes)
+			{
+				for(int c = 0; c < 3; ++c)
+				{
+					const size_t vi = (size_t)m.tri[3 * t + (size_t)c];
+					if(m.has_uv && m.tri_uv.size() >= 3 * (t + 1))
+					{ const size_t ui = (size_t)m.tri_uv[3 * t + (size_t)c]; tri_uv.push_back(m.uv[2 * ui]); tri_uv.push_back(m.uv[2 * ui + 1]); }
+					else { tri_uv.push_back(0.f); tri_uv.push_back(0.f); }            // sp.u_ = sp.v_ = 0, triangle.cc:103-111
+					if(m.has_orco && m.orco.size() >= 3 * (vi + 1))
+					{ tri_orco.push_back(m.orco[3 * vi]); tri_orco.push_back(m.orco[3 * vi + 1]); tri_orco.push_back(m.orco[3 * vi + 2]); }
+					else { tri_orco.push_back(c == 0 ? kNoOrco : 0.f); tri_orco.push_back(0.f); tri_orco.push_back(0.f); }   // has_orco_ false: orco = the hit point
+				}
+			}
 		}
 	}
 	if(yi->material_order.empty()) return fail(yi, "render: no materials defined");
-	std::vector<yafgpu_material> mats; for(auto *m : yi->material_order) mats.push_back(m->m);
+	std::vector<yafgpu_material> mats; std::vector<yafgpu_node> nodes;
+	for(auto *m : yi->material_order)
+	{
+		yafgpu_material rec = m->m;
+		rec.node_first = (int32_t)nodes.size(); rec.n_nodes = (int32_t)m->nodes.size();
+		nodes.insert(nodes.end(), m->nodes.begin(), m->nodes.end());
+		mats.push_back(rec);
+	}
+	std::vector<yafgpu_texture> textures; std::vector<float> texels;
+	if(any_nodes)
+		for(auto *t : yi->texture_order)
+		{
+			yafgpu_texture rec = t->t;
+			rec.texel_first = (uint32_t)(texels.size() / 4);
+			texels.insert(texels.end(), t->texels.begin(), t->texels.end());
+			textures.push_back(rec);
+		}
 	std::vector<yafgpu_light> lights; for(auto *l : yi->light_order) lights.push_back(l->l);
 	yafgpu_scene_desc d{};
 	d.n_tris = (int32_t)tri_mat.size(); d.verts = verts.data(); d.tri_mat = tri_mat.data();
 	d.vnormals = any_normals ? vnormals.data() : nullptr;
 	d.n_materials = (int32_t)mats.size(); d.materials = mats.data();
 	d.n_lights = (int32_t)lights.size(); d.lights = lights.data();
+	if(any_nodes)
+	{
+		d.tri_uv = tri_uv.data(); d.tri_orco = tri_orco.data();
+		d.n_textures = (int32_t)textures.size(); d.textures = textures.data();
+		d.n_texels = texels.size() / 4; d.texels = texels.data();
+		d.n_nodes = (int32_t)nodes.size(); d.nodes = nodes.data();
+	}
 	d.camera = cam->second->c.cam;
 	d.build_threads = 0;
 	int threads = -1; p.get("threads", threads); if(threads > 0) d.build_threads = threads;
@@ -1235,6 +1594,7 @@ yafaray_bool_t yafaray_render(yafaray_interface_t *yi, const yafaray_output_t *o
 
 void yafaray_abort(yafaray_interface_t *yi) { yi->abort_flag = 1; }
 void yafaray_internal_set_error(yafaray_interface_t *yi, const char *msg) { if(yi) yi->err = msg ? msg : ""; }
+void yafaray_internal_set_base_dir(yafaray_interface_t *yi, const char *dir) { if(yi) yi->base_dir = dir ? dir : ""; }
 
 yafaray_bool_t yafaray_getRenderedImage(yafaray_interface_t *yi, int num_view, const yafaray_output_t *output)
 {

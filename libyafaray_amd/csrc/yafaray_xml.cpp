@@ -5,6 +5,7 @@
 // startElMesh__ (:550-638), startElParammap__/endElParammap__ (:676-737) and parseParam__ (:273-318).
 #include "../../include/yafaray_c_api.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include <vector>
 
 extern "C" void yafaray_internal_set_error(yafaray_interface_t *yi, const char *msg); // yafaray_c_api.cpp
+extern "C" void yafaray_internal_set_base_dir(yafaray_interface_t *yi, const char *dir);
 
 namespace {
 
@@ -98,8 +100,15 @@ void set_param(yafaray_interface_t *yi, const std::string &name, const Attrs &a)
 		if(k == "sval") { yafaray_paramsSetString(yi, name.c_str(), v.c_str()); return; }
 	}
 	double p[3] = {0, 0, 0}; float c[4] = {0, 0, 0, 0}; int type = 0;
+	float m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // the reference leaves unset elements uninitialised; exporters write all 16
 	for(const auto &kv : a)
 	{
+		const std::string &k = kv.first;
+		if(k.size() == 3 && k[0] == 'm' && k[1] >= '0' && k[1] <= '3' && k[2] >= '0' && k[2] <= '3')
+		{	// "mij", import_xml.cc:302-308
+			m[4 * (k[1] - '0') + (k[2] - '0')] = (float)atof(kv.second.c_str()); type = 3;
+			continue;
+		}
 		if(kv.first.size() != 1) continue;
 		switch(kv.first[0])
 		{
@@ -114,6 +123,7 @@ void set_param(yafaray_interface_t *yi, const std::string &name, const Attrs &a)
 		}
 	}
 	if(type == 1) yafaray_paramsSetPoint(yi, name.c_str(), p[0], p[1], p[2]);
+	else if(type == 3) yafaray_paramsSetMatrix(yi, name.c_str(), m, 0);
 	else if(type == 2) yafaray_paramsSetColor(yi, name.c_str(), c[0], c[1], c[2], c[3]);
 }
 
@@ -135,6 +145,10 @@ extern "C" yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *p
 		char buf[1 << 16]; size_t n;
 		while((n = std::fread(buf, 1, sizeof buf, f)) > 0) src.append(buf, n);
 		std::fclose(f);
+	}
+	{	// texture file names in the scene are relative to where yafaray-xml is started, by convention the scene file's directory
+		const std::string ps(path); const size_t slash = ps.rfind('/');
+		yafaray_internal_set_base_dir(yi, slash == std::string::npos ? "." : ps.substr(0, slash).c_str());
 	}
 	Lexer lx(src);
 	std::map<std::string, yafaray_material_t *> materials;
@@ -188,6 +202,7 @@ extern "C" yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *p
 			else if(el == "light") created = yafaray_createLight(yi, name->c_str()) != nullptr;
 			else if(el == "camera") created = yafaray_createCamera(yi, name->c_str()) != nullptr;
 			else if(el == "background") created = yafaray_createBackground(yi, name->c_str()) != nullptr;
+			else if(el == "texture") created = yafaray_createTexture(yi, name->c_str()) != nullptr;
 			else if(el == "render_passes" || el == "logging_badge") created = true;   // only the combined pass exists here
 			else { errors.push_back("<" + el + "> elements are outside the GPU path's scope"); created = false; }
 			if(!created) { errors.push_back(std::string("<") + el + " name=\"" + *name + "\">: " + yafaray_getLastError(yi)); ok = false; }
@@ -215,10 +230,16 @@ extern "C" yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *p
 				if(p.kind == Tok::End) { ok = false; break; }
 				if(p.kind == Tok::Close) { if(p.name == "mesh") break; continue; }
 				if(p.name == "p")
-				{
-					double x = 0, y = 0, z = 0;
-					for(const auto &kv : p.attrs) if(kv.first.size() == 1) { if(kv.first[0] == 'x') x = atof(kv.second.c_str()); else if(kv.first[0] == 'y') y = atof(kv.second.c_str()); else if(kv.first[0] == 'z') z = atof(kv.second.c_str()); }
-					yafaray_addVertex(yi, x, y, z);
+				{	// parsePoint__, import_xml.cc:214-249: x y z and, for has_orco meshes, ox oy oz
+					double x = 0, y = 0, z = 0, ox = 0, oy = 0, oz = 0;
+					for(const auto &kv : p.attrs)
+					{
+						const std::string &k = kv.first;
+						if(k.size() == 1) { if(k[0] == 'x') x = atof(kv.second.c_str()); else if(k[0] == 'y') y = atof(kv.second.c_str()); else if(k[0] == 'z') z = atof(kv.second.c_str()); }
+						else if(k.size() == 2 && k[0] == 'o') { if(k[1] == 'x') ox = atof(kv.second.c_str()); else if(k[1] == 'y') oy = atof(kv.second.c_str()); else if(k[1] == 'z') oz = atof(kv.second.c_str()); }
+					}
+					if(has_orco) yafaray_addVertexWithOrco(yi, x, y, z, ox, oy, oz);
+					else yafaray_addVertex(yi, x, y, z);
 				}
 				else if(p.name == "n")
 				{
@@ -228,16 +249,30 @@ extern "C" yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *p
 				}
 				else if(p.name == "f")
 				{
-					int a = 0, b = 0, c = 0;
-					for(const auto &kv : p.attrs) if(kv.first.size() == 1) { if(kv.first[0] == 'a') a = atoi(kv.second.c_str()); else if(kv.first[0] == 'b') b = atoi(kv.second.c_str()); else if(kv.first[0] == 'c') c = atoi(kv.second.c_str()); }
-					if(!mat || !yafaray_addTriangle(yi, a, b, c, mat)) { if(ok) errors.push_back(mat ? yafaray_getLastError(yi) : "face before set_material / unknown material"); ok = false; }
+					int a = 0, b = 0, c = 0, uv_a = 0, uv_b = 0, uv_c = 0;
+					for(const auto &kv : p.attrs)
+					{
+						if(kv.first.size() == 1) { if(kv.first[0] == 'a') a = atoi(kv.second.c_str()); else if(kv.first[0] == 'b') b = atoi(kv.second.c_str()); else if(kv.first[0] == 'c') c = atoi(kv.second.c_str()); }
+						else if(kv.first == "uv_a") uv_a = atoi(kv.second.c_str());
+						else if(kv.first == "uv_b") uv_b = atoi(kv.second.c_str());
+						else if(kv.first == "uv_c") uv_c = atoi(kv.second.c_str());
+					}
+					const bool added = mat && (has_uv ? yafaray_addTriangleWithUv(yi, a, b, c, uv_a, uv_b, uv_c, mat) : yafaray_addTriangle(yi, a, b, c, mat));
+					if(!added) { if(ok) errors.push_back(mat ? yafaray_getLastError(yi) : "face before set_material / unknown material"); ok = false; }
+				}
+				else if(p.name == "uv")
+				{	// :593-619
+					float u = 0, v = 0;
+					for(const auto &kv : p.attrs) if(!kv.first.empty()) { if(kv.first[0] == 'u') u = (float)atof(kv.second.c_str()); else if(kv.first[0] == 'v') v = (float)atof(kv.second.c_str()); }
+					if(!std::isfinite(u)) u = 0.f;
+					if(!std::isfinite(v)) v = 0.f;
+					yafaray_addUv(yi, u, v);
 				}
 				else if(p.name == "set_material")
 				{
 					mat = nullptr;
 					if(!p.attrs.empty()) { auto it = materials.find(p.attrs[0].second); if(it != materials.end()) mat = it->second; }
 				}
-				// <uv> is accepted and ignored (no textures on this path)
 			}
 			if(!yafaray_endTriMesh(yi)) { errors.push_back(yafaray_getLastError(yi)); ok = false; }
 			if(!yafaray_endGeometry(yi)) { errors.push_back(yafaray_getLastError(yi)); ok = false; }

@@ -33,6 +33,7 @@
 #include "kdtree_build.h"
 #include "yafgpu_math.h"
 #include "yafgpu_shading.h"
+#include "yafgpu_texture.h"
 
 namespace yafgpu {
 
@@ -69,6 +70,7 @@ struct DevScene
 	uint32_t n_nodes;
 	float blo[3], bhi[3];
 	yafgpu_camera cam;
+	TexScene tex;                // textures, texels, shader nodes, per-triangle texture coordinates (nodes == nullptr: none)
 };
 
 struct RenderArgs
@@ -369,7 +371,13 @@ YG_DEV bool kd_trace_ts(const DevScene &sc, LaneStack &stk, uint32_t *seen /* [k
 			if(n_seen <= kTsMaxDepth) seen[(n_seen++) * kWave] = ti;
 			SurfPt sp;
 			get_surface(sc, (int)ti, from + dir * t, u, v, sp);
-			filt = filt * mat_transparency(m, sp, dir);
+			if(m.n_nodes > 0 && sc.tex.nodes != nullptr)
+			{	// getTransparency reads the diffuse shader and the component nodes (material_shiny_diffuse.cc:541-563)
+				TexPoint tp; tex_point(sc.tex, (int)ti, u, v, sp.p, sp.n, sp.ng, tp);
+				yafgpu_material tmp; mat_resolve(sc.tex, sc.cam, m, tp, tmp);
+				filt = filt * mat_transparency(tmp, sp, dir);
+			}
+			else filt = filt * mat_transparency(m, sp, dir);
 			++depth;
 		}
 		if(stk.empty())
@@ -1008,6 +1016,29 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			o[14] = tr.r; o[15] = tr.g; o[16] = tr.b;
 			break;
 		}
+		case 13:
+		{	// image texture lookup: in (p.xyz, texture index) -> getColor rgba, getFloat
+			const int ti = (int)__float_as_uint(x[3]);
+			if(sc.tex.nodes == nullptr && sc.tex.textures == nullptr) break;
+			if(ti < 0 || ti >= sc.tex.n_textures) break;
+			const Rgba4 c = tex_get_color(sc.tex, sc.tex.textures[ti], mk(x[0], x[1], x[2]));
+			o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = tex_get_float(sc.tex, sc.tex.textures[ti], mk(x[0], x[1], x[2]));
+			break;
+		}
+		case 14:
+		{	// node stack of material x[18] at a surface point (p, n, ng, orco_p, orco_ng, u, v): n_nodes x (rgba, scalar); one node
+			// range at a time (x[19] = first node of the range, x[20] = count <= kMaxNodes) so that graphs larger than a material's
+			// limit can be pinned piecewise by tests that arrange the ranges to be closed under dependencies
+			if(sc.tex.nodes == nullptr) break;
+			TexPoint tp;
+			tp.p = mk(x[0], x[1], x[2]); tp.n = mk(x[3], x[4], x[5]); tp.ng = mk(x[6], x[7], x[8]);
+			tp.orco_p = mk(x[9], x[10], x[11]); tp.orco_ng = mk(x[12], x[13], x[14]); tp.u = x[15]; tp.v = x[16];
+			const int first = (int)__float_as_uint(x[18]), cnt = min((int)__float_as_uint(x[19]), kMaxNodes);
+			NodeResult stack[kMaxNodes];
+			nodes_eval(sc.tex, sc.tex.nodes + first, cnt, sc.cam, tp, stack);
+			for(int k = 0; k < cnt && 5 * k + 4 < n_out; ++k) { o[5 * k] = stack[k].col.r; o[5 * k + 1] = stack[k].col.g; o[5 * k + 2] = stack[k].col.b; o[5 * k + 3] = stack[k].col.a; o[5 * k + 4] = stack[k].f; }
+			break;
+		}
 		default: break;
 	}
 }
@@ -1059,6 +1090,7 @@ struct yafgpu_scene
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
+	bool has_textures = false;           // some material in use has shader nodes: the general shading kernel, texture coordinates parked per path
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
 	// serial-state replay tables (WfArgs::replay)
@@ -1258,6 +1290,34 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	if(any_smooth && (rc = upload(s, vn.data(), vn.size(), &dv.tri_vn))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, d->materials, (size_t)d->n_materials, &dv.mats))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, d->lights, (size_t)d->n_lights, &dv.lights))) { yafgpu_scene_destroy(s); return rc; }
+	std::memset(&dv.tex, 0, sizeof dv.tex);
+	if(d->n_nodes > 0 && d->nodes)
+	{	// shader nodes, image textures and the per-triangle texture coordinates they read
+		for(int i = 0; i < d->n_materials; ++i)
+		{
+			const yafgpu_material &m = d->materials[i];
+			if(m.n_nodes < 0 || m.n_nodes > kMaxNodes || m.node_first < 0 || m.node_first + m.n_nodes > d->n_nodes)
+			{ yafgpu_scene_destroy(s); return fail(-24, "a material's shader nodes: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
+			if(m.n_nodes > 0) s->has_textures = true;
+		}
+		for(int i = 0; i < d->n_nodes; ++i)
+		{
+			const yafgpu_node &n = d->nodes[i];
+			if(n.type == YAFGPU_NODE_TEXTURE_MAPPER && (n.texture < 0 || n.texture >= d->n_textures)) { yafgpu_scene_destroy(s); return fail(-24, "a texture_mapper node refers to a texture that does not exist"); }
+		}
+		for(int i = 0; i < d->n_textures; ++i)
+		{
+			const yafgpu_texture &t = d->textures[i];
+			if(t.width <= 0 || t.height <= 0 || (uint64_t)t.texel_first + (uint64_t)t.width * (uint64_t)t.height > d->n_texels) { yafgpu_scene_destroy(s); return fail(-24, "a texture's texel range lies outside the texel array"); }
+		}
+		const float4 *texels = nullptr;
+		if((rc = upload(s, d->nodes, (size_t)d->n_nodes, &dv.tex.nodes))) { yafgpu_scene_destroy(s); return rc; }
+		if((rc = upload(s, d->textures, (size_t)std::max(d->n_textures, 0), &dv.tex.textures))) { yafgpu_scene_destroy(s); return rc; }
+		if((rc = upload(s, (const float4 *)d->texels, (size_t)d->n_texels, &texels))) { yafgpu_scene_destroy(s); return rc; }
+		dv.tex.texels = texels; dv.tex.n_textures = d->n_textures;
+		if(d->tri_uv && (rc = upload(s, d->tri_uv, nt * 6, &dv.tex.tri_uv))) { yafgpu_scene_destroy(s); return rc; }
+		if(d->tri_orco && (rc = upload(s, d->tri_orco, nt * 9, &dv.tex.tri_orco))) { yafgpu_scene_destroy(s); return rc; }
+	}
 	if((rc = upload(s, faure.data(), faure.size(), &dv.faure))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, foff.data(), foff.size(), &dv.faure_off))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, invp.data(), invp.size(), &dv.inv_prims))) { yafgpu_scene_destroy(s); return rc; }
@@ -1430,6 +1490,7 @@ extern "C" {
 	int yafgpu_shade_##name##_launch(const void *, size_t, int, hipStream_t);
 YG_DECLARE_SHADE_VARIANT(diffuse)
 YG_DECLARE_SHADE_VARIANT(glossy)
+YG_DECLARE_SHADE_VARIANT(full)
 #undef YG_DECLARE_SHADE_VARIANT
 }
 struct ShadeVariant
@@ -1442,11 +1503,13 @@ struct ShadeVariant
 static const ShadeVariant kShadeVariants[] = {
 	{"diffuse", yafgpu_shade_diffuse_describe, yafgpu_shade_diffuse_kernel, yafgpu_shade_diffuse_launch},
 	{"glossy", yafgpu_shade_glossy_describe, yafgpu_shade_glossy_kernel, yafgpu_shade_glossy_launch},
+	{"full", yafgpu_shade_full_describe, yafgpu_shade_full_kernel, yafgpu_shade_full_launch},      // everything but shader nodes
 };
 static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
 {
 	if(const char *e = std::getenv("YAFGPU_SHADE_VARIANT")) if(std::strcmp(e, "general") == 0) return nullptr;
 	const bool needs_recurse = frames > 0 || s->has_volumetric;
+	if(s->has_textures) return nullptr;        // the variants are built without shader nodes
 	for(const ShadeVariant &v : kShadeVariants)
 	{
 		uint32_t mask = 0u; int recurse = 0;
@@ -1878,6 +1941,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		// transpShad changes which hits occlude even without a transparent material (intersectTs skips hits before tmin_)
 		if(rp->transp_shad) return fail(-15, "the one-kernel pipeline has no transparent shadows (transpShad); use the wavefront pipeline");
 		if(s->has_specular && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent materials");
+		if(s->has_textures) return fail(-15, "the one-kernel pipeline has no shader nodes / textures; use the wavefront pipeline");
 		if(rp->serial_replay && rp->integrator == YAFGPU_INTEGRATOR_PATH && (rp->bounces - 1 > rp->rr_min_bounces || s->n_lights > 1))
 			return fail(-15, "the one-kernel pipeline cannot replay the reference's serial state (Russian roulette stream, light counter); use the wavefront pipeline or switch the replay off");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)

@@ -89,6 +89,40 @@ YG_DEV float oren_nayar(float oa, float ob, V3 wi, V3 wo, V3 n)
 	return smin(1.f, smax(0.f, (oa + ob * maxcos_f * sin_alpha * tan_beta)));
 }
 
+// orenNayar with a texture's sigma (material_shiny_diffuse.cc:230-235): A and B, and the sum, in double
+YG_DEV float oren_nayar_d(double oa, double ob, V3 wi, V3 wo, V3 n)
+{
+	const float cos_ti = smax(-1.f, smin(1.f, dot(n, wi)));
+	const float cos_to = smax(-1.f, smin(1.f, dot(n, wo)));
+	float maxcos_f = 0.f;
+	if(cos_ti < 0.9999f && cos_to < 0.9999f)
+	{
+		const V3 v_1 = normalize(wi - n * cos_ti);
+		const V3 v_2 = normalize(wo - n * cos_to);
+		maxcos_f = smax(0.f, dot(v_1, v_2));
+	}
+	float sin_alpha, tan_beta;
+	if(cos_to >= cos_ti)
+	{
+		sin_alpha = f_sqrt(1.f - cos_ti * cos_ti);
+		tan_beta = f_sqrt(1.f - cos_to * cos_to) / ((cos_to == 0.f) ? 1e-8f : cos_to);
+	}
+	else
+	{
+		sin_alpha = f_sqrt(1.f - cos_to * cos_to);
+		tan_beta = f_sqrt(1.f - cos_ti * cos_ti) / ((cos_ti == 0.f) ? 1e-8f : cos_ti);
+	}
+	return smin(1.f, smax(0.f, (float)(oa + ob * (double)maxcos_f * (double)sin_alpha * (double)tan_beta)));
+}
+#ifndef YAFGPU_FEAT_TEXTURE
+#define YAFGPU_FEAT_TEXTURE 1      // shader nodes / image textures (a kernel built with 0 serves scenes without them)
+#endif
+YG_DEV float sd_oren(const yafgpu_material &m, V3 wi, V3 wo, V3 n)
+{
+	if(YAFGPU_FEAT_TEXTURE && m.oren_tex) return oren_nayar_d(m.oren_ad, m.oren_bd, wi, wo, n);
+	return oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+}
+
 // initBsdf: material_shiny_diffuse.cc:163-183 (+getComponents :98-117), material_glossy.cc:51-64
 YG_DEV uint32_t mat_init_bsdf(const yafgpu_material &m, BsdfDat &d)
 {
@@ -204,7 +238,8 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		}
 		if(dot(n, wl) < 0.f && !m.flat) return mkc(0.f, 0.f, 0.f);
 		float m_d = m_t * (1.f - d.c2) * d.c3;
-		if(m.use_oren) m_d *= oren_nayar(m.oren_a, m.oren_b, wo, wl, n);
+		if(m.use_oren) m_d *= sd_oren(m, wo, wl, n);
+		if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) m_d *= m.diffuse_refl;            // diffuse_refl_shader_, :285
 		return col3(m.diffuse_color) * m_d;
 	}
 	if(YG_IS(m, YAFGPU_MAT_GLOSSY))
@@ -675,7 +710,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		{
 			wi = sample_cos_hemisphere(n, sp.nu, sp.nv, s_1, s.s_2);
 			if(cos_ng_wo * dot(sp.ng, wi) > 0.f) scolor = col3(m.diffuse_color) * acc[3];
-			if(m.use_oren) scolor = scolor * oren_nayar(m.oren_a, m.oren_b, wo, wi, n);
+			if(m.use_oren) scolor = scolor * sd_oren(m, wo, wi, n);
 			s.pdf = fabsf(dot(wi, n)) * width[pick];
 		}
 		s.sampled = ch;

@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 22;   // float4 records of parked state per path (352 B)
+constexpr int kWfRecs = 24;   // float4 records of parked state per path (384 B; 22 and 23 are only touched in textured scenes)
 
 struct WfArgs
 {
@@ -160,6 +160,8 @@ YG_DEV bool dl_candidate(const RenderArgs &ra, const yafgpu_light &light, int ph
 //   r14 pending A | li,l_end,mask,is r15 ccol   r16 ccol_2   r17 col_dirac   r18 total   (light estimate in flight)
 //   r19 offs, sampled_flags, one_light_calls, alpha
 //   r20 second shadow ray: direction | tmin      r21 pending B | tmax of the second ray
+//   r22 camera hit: triangle, barycentrics       r23 current vertex: triangle, barycentrics   (textured scenes: the nodes read
+//       texture coordinates, Triangle::getSurface triangle.cc:46-79, which are interpolated again when a step needs them)
 // Each step loads only what it uses and stores what it produced, so that no step keeps the whole path
 // in registers: the live set of wf_shade is that of its widest step, not of the whole integrator.
 // Addressing: the record base state + k*cap is wave-uniform (scalar registers) and the path's byte offset slot*16
@@ -170,6 +172,34 @@ YG_DEV float4 &wf_rec(const WfArgs &a, int k, uint32_t slot)
 	return *(float4 *)((char *)(a.state + (size_t)k * a.cap) + (slot << 4));
 }
 #define REC(k) wf_rec(a, (k), slot)
+
+// The material at a path vertex: the record itself or, for a material with shader nodes, its resolved copy in `tmp`
+// (yafgpu_texture.h mat_resolve).  wf_mat_hit: triangle and barycentrics at hand; wf_mat_parked: from record 22 / 23.
+YG_DEV const yafgpu_material &wf_mat_hit(const DevScene &sc, const SurfPt &sp, int tri, float bu, float bv, yafgpu_material &tmp)
+{
+	const yafgpu_material &m = sc.mats[sp.mat];
+#if YAFGPU_FEAT_TEXTURE
+	if(m.n_nodes > 0 && sc.tex.nodes != nullptr)
+	{
+		TexPoint tp; tex_point(sc.tex, tri, bu, bv, sp.p, sp.n, sp.ng, tp);
+		mat_resolve(sc.tex, sc.cam, m, tp, tmp);
+		return tmp;
+	}
+#endif
+	return m;
+}
+YG_DEV const yafgpu_material &wf_mat_parked(const WfArgs &a, uint32_t slot, int vertex, const SurfPt &sp, yafgpu_material &tmp)
+{
+	const yafgpu_material &m = a.ra.sc.mats[sp.mat];
+#if YAFGPU_FEAT_TEXTURE
+	if(m.n_nodes > 0 && a.ra.sc.tex.nodes != nullptr)
+	{
+		const float4 r = REC(22 + vertex);
+		return wf_mat_hit(a.ra.sc, sp, (int)ubits(r.x), r.y, r.z, tmp);
+	}
+#endif
+	return m;
+}
 
 struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl; };   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_
 YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.incl << 16) | ((uint32_t)c.path_i << 17); }
@@ -270,7 +300,9 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		const V3 dir = v3(r1);
 		SurfPt sp0;
 		get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, sp0);
-		const yafgpu_material &m = sc.mats[sp0.mat];
+		yafgpu_material m_tmp;
+		const yafgpu_material &m = wf_mat_hit(sc, sp0, tri, ans.z, ans.w, m_tmp);
+		if(YAFGPU_FEAT_TEXTURE && sc.tex.nodes != nullptr) REC(22) = make_float4(fbits((uint32_t)tri), ans.z, ans.w, 0.f);
 		BsdfDat dat0;
 		const uint32_t bsdfs0 = mat_init_bsdf(m, dat0);
 		const V3 wo0 = -dir;
@@ -303,7 +335,9 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	const V3 dir = v3(r1);
 	SurfPt hit;
 	get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, hit);
-	const yafgpu_material &pm = sc.mats[hit.mat];
+	yafgpu_material pm_tmp;
+	const yafgpu_material &pm = wf_mat_hit(sc, hit, tri, ans.z, ans.w, pm_tmp);
+	if(YAFGPU_FEAT_TEXTURE && sc.tex.nodes != nullptr) REC(23) = make_float4(fbits((uint32_t)tri), ans.z, ans.w, 0.f);
 	BsdfDat dat_n;
 	const uint32_t mb = mat_init_bsdf(pm, dat_n);
 	float4 misc = REC(19);
@@ -420,7 +454,8 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 	SurfPt sp; V3 wo;
 	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
 	else { const float4 p = REC(7); make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), sp); wo = v3(REC(10)); }
-	const yafgpu_material &mat = sc.mats[sp.mat];
+	yafgpu_material mat_tmp;
+	const yafgpu_material &mat = wf_mat_parked(a, slot, c.dl_on_sp0 ? 0 : 1, sp, mat_tmp);
 	BsdfDat dat; mat_init_bsdf(mat, dat);
 	const yafgpu_light &light = sc.lights[li];
 	const bool dirac = light.type == YAFGPU_LIGHT_POINT;
@@ -468,9 +503,20 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 		c.path_i = 0;
 		return W_START_PATH;
 	}
-	const yafgpu_material &pm = sc.mats[(int)ubits(REC(7).w)];
+	const yafgpu_material &pm_rec = sc.mats[(int)ubits(REC(7).w)];
 	BsdfDat dat_n;
-	const uint32_t mb = mat_init_bsdf(pm, dat_n);
+	const uint32_t mb = mat_init_bsdf(pm_rec, dat_n);      // the flags do not depend on the nodes
+	yafgpu_material pm_tmp; (void)pm_tmp;
+	const yafgpu_material *pm_p = &pm_rec;
+#if YAFGPU_FEAT_TEXTURE
+	if(c.stage == kStFirst && (mb & kEmit) && pm_rec.n_nodes > 0 && sc.tex.nodes != nullptr)
+	{	// its own emission reads the diffuse shader (emit(), material_shiny_diffuse.cc:295-306)
+		const float4 p7 = REC(7);
+		SurfPt hp; hp.p = v3(p7); hp.n = v3(REC(8)); hp.ng = v3(REC(9)); hp.mat = (int)ubits(p7.w);
+		pm_p = &wf_mat_parked(a, slot, 1, hp, pm_tmp);
+	}
+#endif
+	const yafgpu_material &pm = *pm_p;
 	Col lcol = mkc(0.f, 0.f, 0.f);
 	if(l_end > 0) lcol = total * (float)sc.n_lights;
 	float4 r11 = HGET(11), r12 = HGET(12);
@@ -533,7 +579,8 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
 	const float4 r10 = REC(10);
 	const V3 pwo = v3(r10);
-	const yafgpu_material &pm = sc.mats[hit.mat];
+	yafgpu_material pm_tmp;
+	const yafgpu_material &pm = wf_mat_parked(a, slot, 1, hit, pm_tmp);
 	BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
 	const uint32_t offs = ubits(REC(19).x);
 	const int d_4 = 4 * c.depth;
@@ -566,7 +613,8 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
 	const V3 wo0 = v3(REC(6));
-	const yafgpu_material &m = sc.mats[sp0.mat];
+	yafgpu_material m_tmp;
+	const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
 	BsdfDat dat0; mat_init_bsdf(m, dat0);
 	const uint32_t offs = (uint32_t)rp.path_samples * pixel_sample + sampling_offs + (uint32_t)c.path_i;
 	BsdfSample bs;
@@ -602,14 +650,15 @@ YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
 }
 YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 {
-	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp; (void)sc;
 	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
 	const float4 r5 = REC(5);
 	if(!(ubits(r5.w) & (kSpecular | kFilter))) return W_RETURN;
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(r5), (int)ubits(p.w), sp0);
 	const V3 wo0 = v3(REC(6));
-	const yafgpu_material &m = sc.mats[sp0.mat];
+	yafgpu_material m_tmp;
+	const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
 	BsdfDat dat0; mat_init_bsdf(m, dat0);
 	c.incl = 1;                                                                       // :973
 	bool refl, refr; V3 d_refl, d_refr; Col c_refl, c_refr;

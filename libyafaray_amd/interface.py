@@ -60,6 +60,7 @@ C_API_SYMBOLS = [
     "yafaray_paramsSetPoint", "yafaray_paramsSetString", "yafaray_paramsSetBool", "yafaray_paramsSetInt",
     "yafaray_paramsSetFloat", "yafaray_paramsSetColor", "yafaray_paramsClearAll", "yafaray_paramsStartList",
     "yafaray_paramsPushList", "yafaray_paramsEndList",
+    "yafaray_createTexture", "yafaray_createTextureFromMemory", "yafaray_getTextureImage",
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
     "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_prepareRender",
@@ -116,6 +117,8 @@ def load():
         "yafaray_paramsClearAll": (None, [vp]), "yafaray_paramsStartList": (None, [vp]),
         "yafaray_paramsPushList": (None, [vp]), "yafaray_paramsEndList": (None, [vp]),
         "yafaray_createLight": (vp, [vp, cp]), "yafaray_createMaterial": (vp, [vp, cp]),
+        "yafaray_createTexture": (vp, [vp, cp]), "yafaray_createTextureFromMemory": (vp, [vp, cp, ci, ci, C.POINTER(C.c_float)]),
+        "yafaray_getTextureImage": (ci, [vp, cp, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_float), ci]),
         "yafaray_createCamera": (vp, [vp, cp]), "yafaray_createBackground": (vp, [vp, cp]),
         "yafaray_createIntegrator": (vp, [vp, cp]), "yafaray_clearAll": (None, [vp]),
         "yafaray_render": (ci, [vp, C.POINTER(Output), vp]), "yafaray_abort": (None, [vp]),
@@ -362,6 +365,23 @@ class Interface:
 
     def createMaterial(self, name):
         return self._obj(self._L.yafaray_createMaterial(self._h, _b(name)), "createMaterial")
+
+    def createTexture(self, name):
+        return self._obj(self._L.yafaray_createTexture(self._h, _b(name)), "createTexture")
+
+    def createTextureFromMemory(self, name, texels):
+        """texels: (height, width, 4) float32, as the reference's ImageHandler::getPixel would return them"""
+        import numpy as np
+        px = np.ascontiguousarray(texels, dtype=np.float32)
+        return self._obj(self._L.yafaray_createTextureFromMemory(self._h, _b(name), px.shape[1], px.shape[0], px.ctypes.data_as(C.POINTER(C.c_float))), "createTextureFromMemory")
+
+    def getTextureImage(self, name):
+        import numpy as np
+        w, h = C.c_int(0), C.c_int(0)
+        self._ok(self._L.yafaray_getTextureImage(self._h, _b(name), C.byref(w), C.byref(h), None, 0), "getTextureImage")
+        px = np.zeros((h.value, w.value, 4), np.float32)
+        self._ok(self._L.yafaray_getTextureImage(self._h, _b(name), C.byref(w), C.byref(h), px.ctypes.data_as(C.POINTER(C.c_float)), px.size), "getTextureImage")
+        return px
 
     def createCamera(self, name):
         return self._obj(self._L.yafaray_createCamera(self._h, _b(name)), "createCamera")

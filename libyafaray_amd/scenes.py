@@ -82,6 +82,7 @@ def _color(v):
 
 
 _COLOR_KEYS = {"color", "mirror_color", "diffuse_color", "filter_color", "absorption"}
+_NODE_COLOR_KEYS = {"color", "color1", "color2", "def_col", "upper_color"}
 
 
 def load_scene(yi, scene, render):
@@ -89,9 +90,32 @@ def load_scene(yi, scene, render):
     materials, lights, camera, background, integrators, geometry, then the render ParamMap."""
     yi.startScene(0)
     handles = []
+    for i, t in enumerate(scene.get("textures") or []):
+        # image textures: ImageTexture::factory's parameters, and either a file name or texels already in memory
+        yi.paramsClearAll()
+        params = {k: v for k, v in t.items() if k not in ("name", "texels")}
+        params.setdefault("type", "image")
+        yi.paramsSet(params)
+        name = t.get("name", f"tex{i}")
+        if "texels" in t:
+            yi.createTextureFromMemory(name, t["texels"])
+        else:
+            yi.createTexture(name)
     for i, m in enumerate(scene["materials"]):
         yi.paramsClearAll()
-        yi.paramsSet({k: (_color(v) if k in _COLOR_KEYS else v) for k, v in m.items()})
+        yi.paramsSet({k: (_color(v) if k in _COLOR_KEYS else v) for k, v in m.items() if k != "nodes"})
+        for node in m.get("nodes") or []:
+            # shader nodes: one <list_element> ParamMap each (import_xml.cc:683-690)
+            yi.paramsPushList()
+            yi.paramsSetString("element", "shader_node")
+            for k, v in node.items():
+                if k == "transform":
+                    yi.paramsSetMatrix(k, np.asarray(v, dtype=np.float32).reshape(16))
+                elif k in _NODE_COLOR_KEYS:
+                    yi.paramsSetColor(k, *[float(c) for c in v])
+                else:
+                    yi.paramsSet({k: v})
+            yi.paramsEndList()
         handles.append(yi.createMaterial(f"mat{i}"))
     for i, l in enumerate(scene["lights"]):
         yi.paramsClearAll()
@@ -125,7 +149,29 @@ def load_scene(yi, scene, render):
     tri_mat = np.asarray(scene["tri_mat"], dtype=np.int32)
     vn = scene.get("vnormals")
     n = verts.shape[0]
-    if vn is not None:
+    uv, orco = scene.get("uv"), scene.get("orco")
+    if uv is not None or orco is not None:
+        # texture coordinates (shader nodes): per-vertex path with orco and UVs, one mesh, triangles keep their order
+        uv = None if uv is None else np.asarray(uv, dtype=np.float32).reshape(-1, 3, 2)
+        orco = None if orco is None else np.asarray(orco, dtype=np.float32).reshape(-1, 3, 3)
+        vn = None if vn is None else np.asarray(vn, dtype=np.float32).reshape(-1, 3, 3)
+        yi.startTriMesh(yi.getNextFreeId(), 3 * n, n, orco is not None, uv is not None, 0)
+        for t in range(n):
+            for c in range(3):
+                if orco is not None:
+                    yi.addVertexWithOrco(*[float(x) for x in verts[t, c]], *[float(x) for x in orco[t, c]])
+                else:
+                    yi.addVertex(*[float(x) for x in verts[t, c]])
+                if vn is not None and np.any(vn[t, c] != 0):
+                    yi.addNormal(*[float(x) for x in vn[t, c]])
+                if uv is not None:
+                    yi.addUv(float(uv[t, c, 0]), float(uv[t, c, 1]))
+            if uv is not None:
+                yi.addTriangleWithUv(3 * t, 3 * t + 1, 3 * t + 2, 3 * t, 3 * t + 1, 3 * t + 2, handles[int(tri_mat[t])])
+            else:
+                yi.addTriangle(3 * t, 3 * t + 1, 3 * t + 2, handles[int(tri_mat[t])])
+        yi.endTriMesh()
+    elif vn is not None:
         # per-vertex path so that addNormal is exercised (one mesh; triangles keep their order)
         vn = np.asarray(vn, dtype=np.float32).reshape(-1, 3, 3)
         yi.startTriMesh(yi.getNextFreeId(), 3 * n, n, False, False, 0)

@@ -97,7 +97,7 @@ def texture_desc(t):
     d.adj_saturation, d.adj_hue = t.get("adj_saturation", 1.0), t.get("adj_hue", 0.0)
     d.adj_red, d.adj_green, d.adj_blue = t.get("adj_mult_factor_red", 1.0), t.get("adj_mult_factor_green", 1.0), t.get("adj_mult_factor_blue", 1.0)
     d.adj_clamp = int(t.get("adj_clamp", False))
-    d.color_space = COLOR_SPACE.get(t.get("color_space", "sRGB"), 0)
+    d.color_space = COLOR_SPACE.get(t.get("color_space", "Raw_Manual_Gamma"), 0)   # the factory's default (:552); unknown names read as sRGB (:613)
     d.gamma = t.get("gamma", 1.0)
     return d
 

@@ -931,7 +931,7 @@ static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, 
 	}
 	else sp->n = sp->ng;
 	sp->tri = ti;
-	if(s->tri_orco)
+	if(s->tri_orco && s->tri_orco[9 * (size_t)ti] == s->tri_orco[9 * (size_t)ti])   /* has_orco_ is per mesh: a NaN first word = "this triangle's mesh has none" */
 	{	/* :46-57 */
 		const float *q = s->tri_orco + 9 * (size_t)ti;
 		v3 p_0 = V(q[0], q[1], q[2]), p_1 = V(q[3], q[4], q[5]), p_2 = V(q[6], q[7], q[8]);

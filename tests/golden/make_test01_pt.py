@@ -15,12 +15,17 @@ With --expected it copies the one rendered image the reference's tests hold for 
 (tests/test01/"test01 - expected render result.png": 480x340 RGBA = a 70-row parameters badge on top of the 480x270
 render, sRGB, 8 bit) to tests/golden/test01_expected.png and writes tests/golden/test01_expected.json: the badge height
 and the names of the materials that carry NO shader node in the shipped scene (their pixels can be compared with a
-render of test01_dl.xml; the six textured cubes cannot until textures exist on the device path)."""
+render of test01_dl.xml), and the names of the materials whose texture file is one this build decodes (TGA, HDR, PNG).
+
+With --textured it writes tests/golden/test01_tex.xml: the shipped settings again, this time KEEPING the image textures, shader
+nodes and orco coordinates of the cubes whose texture file has a decoder here (test01_tex.tga / .hdr / .png, committed next
+to it as data); the cubes textured from TIFF, JPEG and OpenEXR files (libraries this image lacks) keep their plain colours."""
 import os
 import re
 import sys
 
 SRC = "/root/reference/tests/test01/test01.xml"
+DECODABLE = ("tga", "hdr", "png")
 DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test01_pt.xml")
 
 
@@ -32,15 +37,63 @@ def expected():
     shutil.copyfile(src_png, os.path.join(here, "test01_expected.png"))
     x = re.sub(r"<!--.*?-->", "", open(SRC).read(), flags=re.S)
     plain = [m.group(1) for m in re.finditer(r'<material name="([^"]*)">(.*?)</material>', x, flags=re.S) if "<list_element>" not in m.group(2)]
+    tex_file = {m.group(1): re.search(r'<filename sval="([^"]*)"/>', m.group(2)).group(1) for m in re.finditer(r'<texture name="([^"]*)">(.*?)</texture>', x, flags=re.S)}
+    decodable = []
+    for m in re.finditer(r'<material name="([^"]*)">(.*?)</material>', x, flags=re.S):
+        t = re.search(r'<texture sval="([^"]*)"/>', m.group(2))
+        if t and tex_file[t.group(1)].rsplit(".", 1)[-1].lower() in DECODABLE:
+            decodable.append(m.group(1))
     meta = {"source": "tests/test01/test01 - expected render result.png of the reference", "badge_rows_on_top": 70, "width": 480, "height": 270,
-            "color_space": "sRGB", "untextured_materials": plain}
+            "color_space": "sRGB", "untextured_materials": plain, "decodable_textured_materials": decodable}
     json.dump(meta, open(os.path.join(here, "test01_expected.json"), "w"), indent=1)
     print(meta)
+
+
+def textured():
+    """test01.xml with the shipped settings; textures / nodes / orco kept where the texture file can be decoded here"""
+    import shutil
+    here = os.path.dirname(os.path.abspath(__file__))
+    x = re.sub(r"<!--.*?-->", "", open(SRC).read(), flags=re.S)
+    tex_file = {m.group(1): re.search(r'<filename sval="([^"]*)"/>', m.group(2)).group(1) for m in re.finditer(r'<texture name="([^"]*)">(.*?)</texture>', x, flags=re.S)}
+    keep = {n for n, f in tex_file.items() if f.rsplit(".", 1)[-1].lower() in DECODABLE}
+    for n in keep:
+        shutil.copyfile(os.path.join(os.path.dirname(SRC), tex_file[n]), os.path.join(here, tex_file[n]))
+
+    def texture_block(m):
+        return m.group(0) if m.group(1) in keep else ""
+    x = re.sub(r'<texture name="([^"]*)">.*?</texture>\s*', texture_block, x, flags=re.S)
+
+    def material_block(m):
+        body = m.group(0)
+        t = re.search(r'<texture sval="([^"]*)"/>', body)
+        if t and t.group(1) not in keep:
+            body = re.sub(r"\s*<list_element>.*?</list_element>", "", body, flags=re.S)
+            body = re.sub(r"\s*<\w+_shader sval=\"[^\"]*\"/>", "", body)
+        return body
+    x = re.sub(r'<material name="[^"]*">.*?</material>', material_block, x, flags=re.S)
+    for el in ("render_passes", "logging_badge"):
+        x = re.sub(rf"<{el} name=.*?</{el}>\s*", "", x, flags=re.S)
+
+    def render_block(m):
+        r = m.group(0)
+        r = re.sub(r'<threads ival="[^"]*"/>', '<threads ival="1"/>', r)
+        r = re.sub(r'<tiles_order sval="[^"]*"/>', '<tiles_order sval="linear"/>', r)
+        return re.sub(r'<color_space sval="[^"]*"/>', '<color_space sval="LinearRGB"/>', r)
+    x = re.sub(r"<render>.*?</render>", render_block, x, flags=re.S)
+    x = re.sub(r"\n\s*\n+", "\n", x)
+    x = re.sub(r"^<\?xml[^>]*\?>\s*", "", x)
+    head = ("<?xml version=\"1.0\"?>\n<!-- derived from the reference's tests/test01/test01.xml by tests/golden/make_test01_pt.py, option textured "
+            "(shipped settings; TGA / HDR / PNG textures kept, TIFF / JPEG / OpenEXR ones removed) -->\n")
+    dst = os.path.join(here, "test01_tex.xml")
+    open(dst, "w").write(head + x.strip() + "\n")
+    print(dst, len(x), "bytes; textures kept:", sorted(keep))
 
 
 def main():
     if "--expected" in sys.argv[1:]:
         return expected()
+    if "--textured" in sys.argv[1:]:
+        return textured()
     shipped = "--shipped" in sys.argv[1:]
     dst = DST.replace("test01_pt", "test01_dl") if shipped else DST
     if not os.path.exists(SRC):

@@ -15,15 +15,19 @@ CHILD = textwrap.dedent('''
     seed0, n_seq = int(sys.argv[1]), int(sys.argv[2])
     names = ["type", "color", "from", "to", "up", "resx", "resy", "focal", "power", "samples", "corner", "point1", "point2", "width", "height",
              "AA_passes", "AA_minsamples", "camera_name", "integrator_name", "bounces", "path_samples", "IOR", "exponent", "transparency",
-             "filter_type", "AA_pixelwidth", "raydepth", "absorption", "visibility", "aperture", "bokeh_type", "tile_size", "xstart"]
+             "filter_type", "AA_pixelwidth", "raydepth", "absorption", "visibility", "aperture", "bokeh_type", "tile_size", "xstart",
+             "element", "name", "texture", "input", "upper_layer", "input1", "input2", "factor", "diffuse_shader", "mirror_shader", "IOR_shader",
+             "texco", "mapping", "mode", "filename", "interpolate", "clipping", "xrepeat", "cropmin_x", "color1", "color2", "value", "bump_shader"]
     strings = ["shinydiffusemat", "glossy", "glass", "mirror", "light_mat", "coated_glossy", "arealight", "pointlight", "perspective", "pathtracing",
-               "directlighting", "constant", "none", "box", "gauss", "nonsense", "", "cam", "default", "blend_mat", "photonmapping", "sunlight"]
+               "directlighting", "constant", "none", "box", "gauss", "nonsense", "", "cam", "default", "blend_mat", "photonmapping", "sunlight",
+               "shader_node", "texture_mapper", "layer", "mix", "value", "image", "t0", "n0", "n1", "uv", "orco", "cube", "sphere", "checker",
+               %(root)r + "/tests/golden/test01_tex.png", "bilinear", "mipmap_ewa"]
     for seq in range(n_seq):
         rng = random.Random(seed0 + seq)
         yi = Interface()
         handles = [None]
         for step in range(rng.randint(5, 120)):
-            op = rng.randrange(26)
+            op = rng.randrange(32)
             try:
                 if op == 0: yi.startScene(rng.choice([0, 0, 1, -3]))
                 elif op == 1: yi.startGeometry()
@@ -50,6 +54,12 @@ CHILD = textwrap.dedent('''
                 elif op == 22: yi.clearAll()
                 elif op == 23: yi.setShard(rng.randint(-1, 3), rng.randint(-1, 3))
                 elif op == 24: yi.getRenderSize(); yi.getLastError(); yi.getVersion()
+                elif op == 26: yi.createTexture(rng.choice(["t0", "t1", ""]))
+                elif op == 27: yi.createTextureFromMemory(rng.choice(["t0", "t1"]), np.random.default_rng(seq).uniform(0, 1, (rng.choice([1, 3]), rng.choice([1, 4]), 4)).astype(np.float32))
+                elif op == 28: yi.addVertexWithOrco(rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1))
+                elif op == 29: yi.addUv(rng.uniform(-2, 2), rng.choice([rng.uniform(-2, 2), float("nan")]))
+                elif op == 30: yi.addTriangleWithUv(rng.randint(-2, 40), rng.randint(-2, 40), rng.randint(-2, 40), rng.randint(-2, 40), rng.randint(-2, 40), rng.randint(-2, 40), rng.choice(handles))
+                elif op == 31: yi.paramsPushList(); yi.paramsSetString("element", "shader_node"); yi.paramsSetString("name", rng.choice(["n0", "n1", "n2"])); yi.paramsSetString("type", rng.choice(["layer", "mix", "value", "texture_mapper", "x"])); yi.paramsSetString(rng.choice(["input", "input1", "upper_layer", "factor", "texture"]), rng.choice(["n0", "n1", "n2", "t0"])); yi.paramsEndList() if rng.random() < 0.8 else None
                 elif op == 25:
                     v = np.random.default_rng(seq).uniform(-1, 1, (rng.choice([0, 1, 5]), 3, 3)).astype(np.float32)
                     yi.addTriangles(v, None, rng.choice(handles)) if hasattr(yi, "addTriangles") else None
@@ -122,7 +132,8 @@ XML_CHILD = textwrap.dedent('''
     import sys, random, os, tempfile
     sys.path.insert(0, %(root)r)
     from libyafaray_amd import Interface
-    src = open(os.path.join(%(root)r, "tests", "golden", "test01_dl.xml"), "rb").read()
+    src = open(os.path.join(%(root)r, "tests", "golden", sys.argv[2] if len(sys.argv) > 2 else "test01_dl.xml"), "rb").read()
+    os.chdir(os.path.join(%(root)r, "tests", "golden"))      # texture file names in the scene are relative
     n = int(sys.argv[1])
     tmp = tempfile.mkdtemp()
     loaded = 0
@@ -154,12 +165,57 @@ XML_CHILD = textwrap.dedent('''
 def test_damaged_scene_files_never_crash_the_xml_loader():
     r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "400"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "survived 400" in r.stdout, f"child died (rc {r.returncode}):\n{r.stdout[-500:]}\n{r.stderr[-2000:]}"
+    # the textured scene: <texture> elements, shader-node <list_element>s, orco coordinates
+    r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "150", "test01_tex.xml"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "survived 150" in r.stdout, f"child died (rc {r.returncode}):\n{r.stdout[-500:]}\n{r.stderr[-2000:]}"
+
+
+IMG_CHILD = textwrap.dedent('''
+    import sys, random, os, tempfile
+    sys.path.insert(0, %(root)r)
+    from libyafaray_amd import Interface
+    n = int(sys.argv[1])
+    tmp = tempfile.mkdtemp()
+    srcs = {ext: open(os.path.join(%(root)r, "tests", "golden", "test01_tex." + ext), "rb").read() for ext in ("tga", "hdr", "png")}
+    srcs["tga"] = srcs["tga"][:18 + 64 * 300 * 4]          # the first rows are enough to reach every branch; keeps the loop fast
+    decoded = 0
+    for i in range(n):
+        rng = random.Random(i)
+        ext = ("tga", "hdr", "png")[i %% 3]
+        data = bytearray(srcs[ext])
+        for _ in range(rng.randint(1, 6)):
+            k = rng.randrange(5)
+            p = rng.randrange(len(data)) if rng.random() < 0.5 else rng.randrange(min(len(data), 64))     # headers get half the damage
+            if k == 0: del data[p:p + rng.randint(1, 2000)]
+            elif k == 1: data[p] = rng.randrange(256)
+            elif k == 2: data = data[:p]
+            elif k == 3: data[p:p] = data[max(0, p - rng.randint(1, 300)):p]
+            else: data[p:p + 2] = rng.choice([b"\\xff\\xff", b"\\x00\\x00", b"\\x7f\\xff", b"\\x80\\x00"])
+            if not data: data = bytearray(b"\\x00")
+        path = os.path.join(tmp, "m." + ext)
+        open(path, "wb").write(bytes(data))
+        yi = Interface(strict=False)
+        yi.startScene(0)
+        yi.paramsClearAll()
+        yi.paramsSetString("type", "image"); yi.paramsSetString("filename", path)
+        yi.paramsSetString("texture_optimization", rng.choice(["none", "optimized", "compressed"])); yi.paramsSetBool("img_grayscale", rng.random() < 0.3)
+        if yi.createTexture("t"):
+            decoded += 1
+            yi.getTextureImage("t")
+        yi.close()
+    print("survived", n, "decoded", decoded)
+''')
+
+
+def test_damaged_image_files_never_crash_the_decoders():
+    r = subprocess.run([sys.executable, "-c", IMG_CHILD % {"root": ROOT}, "240"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "survived 240" in r.stdout, f"child died (rc {r.returncode}):\n{r.stdout[-500:]}\n{r.stderr[-2000:]}"
 
 
 def test_host_side_under_address_and_ub_sanitizers():
     """The host side of the C ABI (parameter maps, Interface state machine, geometry assembly, smoothMesh, XML loader,
     host kd builder) built with a stub for the device unit under AddressSanitizer + UBSan (tests/asan), driven by the
-    same random call sequences and damaged scene files.  GPU code cannot run under sanitizers on this pool."""
+    same random call sequences, damaged scene files and damaged image files (TGA / HDR / PNG decoders).  GPU code cannot run under sanitizers on this pool."""
     libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
     if not os.path.isabs(libasan) or not os.path.exists(libasan) or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
         pytest.skip("no libasan / HIP host headers here")
@@ -170,3 +226,7 @@ def test_host_side_under_address_and_ub_sanitizers():
     assert r.returncode == 0 and "calls that succeeded" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]
     r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "600"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "survived 600" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-c", XML_CHILD % {"root": ROOT}, "200", "test01_tex.xml"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "survived 200" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-c", IMG_CHILD % {"root": ROOT}, "300"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "survived 300" in r.stdout and "runtime error" not in r.stderr, r.stderr[-3000:]

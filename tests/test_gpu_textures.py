@@ -1,0 +1,245 @@
+"""SURVEY row N2 on the DEVICE — image textures and shader nodes through the C ABI (yafaray_createTexture /
+yafaray_createTextureFromMemory, shader-node list elements of yafaray_createMaterial, orco / UV geometry):
+  * the device's texture lookups and node evaluation (probe ops 13 / 14) against the reference's own sources compiled here
+    (tests/golden/ref_textures_ieee.json.gz, the fixture the oracle is pinned with in tests/test_textures_golden.py) — bit for bit;
+  * textured renders, every shader slot of shinydiffusemat, against the oracle on the same scene;
+  * the reference's shipped test scene WITH its TGA / HDR / PNG textures against the expected PNG its tests hold."""
+import os
+
+import numpy as np
+import pytest
+
+from libyafaray_amd import Interface, scenes
+from oracle import pyoracle as po
+from tests.test_gpu_parity import compare_films
+from tests.test_textures_golden import IMAGE_CASES, _node_graph, f32, golden
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(autouse=True)
+def wavefront_only(monkeypatch):
+    monkeypatch.setenv("YAFGPU_PIPELINE", "wavefront")     # the one-kernel pipeline refuses shader nodes (error -15)
+
+
+def _one_triangle_scene(yi, mat_handle, cam):
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "pointlight", "from": (0.0, 0.0, 3.0), "color": ("color", 1.0, 1.0, 1.0), "power": 1.0})
+    yi.createLight("l")
+    yi.paramsClearAll()
+    yi.paramsSet(cam)
+    yi.createCamera("cam")
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "directlighting", "caustic_type": "none"})
+    yi.createIntegrator("default")
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "none"})
+    yi.createIntegrator("volintegr")
+    yi.startGeometry()
+    yi.startTriMesh(yi.getNextFreeId(), 3, 1, False, False, 0)
+    for v in ((-1.0, 0.0, -1.0), (1.0, 0.0, -1.0), (0.0, 0.0, 1.0)):
+        yi.addVertex(*v)
+    yi.addTriangle(0, 1, 2, mat_handle)
+    yi.endTriMesh()
+    yi.endGeometry()
+    yi.paramsClearAll()
+    yi.paramsSet({"camera_name": "cam", "integrator_name": "default", "volintegrator_name": "volintegr", "width": 8, "height": 8})
+    assert yi.prepareRender()
+
+
+CAM = {"type": "perspective", "from": (0.0, -3.0, 0.0), "to": (0.0, 0.0, 0.0), "up": (0.0, -3.0, 1.0), "resx": 8, "resy": 8, "focal": 1.0}
+
+
+def test_device_image_texture_lookups_match_the_reference():
+    """ImageTexture::getColor / getFloat on the device for the harness's nine cases (clip modes, repeat / mirror / crop / rot90,
+    none and bilinear, adjustments incl. HSV, every colour space of getRawColor): 160 lookups each, bit for bit."""
+    g = golden("ieee")
+    yi = Interface()
+    yi.startScene(0)
+    names = sorted(IMAGE_CASES)
+    for name in names:
+        c = dict(IMAGE_CASES[name])
+        c.setdefault("color_space", "sRGB")
+        w, h = c.pop("w"), c.pop("h")
+        yi.paramsClearAll()
+        yi.paramsSet(dict(c, type="image"))
+        yi.createTextureFromMemory(name, f32(g[name + "_texels"]).reshape(h, w, 4))
+    # one material reading the first texture, so that the scene carries its textures to the device
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "shinydiffusemat", "diffuse_shader": "map"})
+    yi.paramsPushList()
+    yi.paramsSet({"element": "shader_node", "type": "texture_mapper", "name": "map", "texture": names[0], "texco": "global"})
+    yi.paramsEndList()
+    mat = yi.createMaterial("m")
+    _one_triangle_scene(yi, mat, CAM)
+    for ti, name in enumerate(names):
+        pts = f32(g[name + "_in"]).reshape(-1, 3)
+        want = f32(g[name + "_out"]).reshape(-1, 5)
+        inp = np.zeros((len(pts), 4), np.float32)
+        inp[:, :3] = pts
+        inp[:, 3] = np.array([ti], np.uint32).view(np.float32)[0]
+        got = yi.probe(13, inp, 5)
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+        assert len(bad) == 0, f"{name}: {len(bad)} of {len(pts)} lookups differ; first {pts[bad[0]]} -> {got[bad[0]]} vs {want[bad[0]]}"
+
+
+def _reachable(nodes, root):
+    """the nodes `root` reads, in the host's evaluation order (depth first, a node after its inputs)"""
+    by = {n["name"]: n for n in nodes}
+    order, seen = [], set()
+
+    def visit(n):
+        if n["name"] in seen:
+            return
+        seen.add(n["name"])
+        for k in ("input1", "input2", "factor", "input", "upper_layer"):
+            if k in n and n[k] in by:
+                visit(by[n[k]])
+        order.append(n["name"])
+    visit(by[root])
+    return order
+
+
+def test_device_shader_node_graph_matches_the_reference():
+    """Every node of the harness's graph (texture mappers over every texco x mapping, a value node, mix nodes in every mode,
+    layers in every blend mode and flag set): one material per node with that node as its diffuse shader — the host loads the
+    whole list, keeps what the slot reaches, sorts it (NodeMaterial::solveNodesOrder) — evaluated on the device at the
+    harness's 40 surface points: colour, alpha and scalar bit for bit."""
+    g = golden("ieee")
+    nodes = _node_graph(g)
+    c = f32(g["nodes_camera"])
+    cam = {"type": "perspective", "from": tuple(float(x) for x in c[0:3]), "to": tuple(float(x) for x in c[3:6]), "up": tuple(float(x) for x in c[6:9]),
+           "resx": int(g["nodes_camera"][9]), "resy": int(g["nodes_camera"][10]), "focal": float(c[11])}
+    yi = Interface()
+    yi.startScene(0)
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "image", "interpolate": "bilinear", "clipping": "repeat", "color_space": "sRGB"})
+    yi.createTextureFromMemory("t", f32(g["nodes_texels"]).reshape(5, 6, 4))
+    first, ranges, mats = 0, [], []
+    for n in nodes:
+        yi.paramsClearAll()
+        yi.paramsSet({"type": "shinydiffusemat", "diffuse_shader": n["name"]})
+        for nd in nodes:
+            yi.paramsPushList()
+            yi.paramsSetString("element", "shader_node")
+            for k, v in nd.items():
+                if k == "transform":
+                    yi.paramsSetMatrix(k, np.asarray(v, np.float32).reshape(16))
+                elif k in ("color", "color1", "color2", "def_col", "upper_color"):
+                    yi.paramsSetColor(k, *[float(x) for x in v])
+                else:
+                    yi.paramsSet({k: v})
+            yi.paramsEndList()
+        mats.append(yi.createMaterial("m_" + n["name"]))
+        cnt = len(_reachable(nodes, n["name"]))
+        ranges.append((first, cnt))
+        first += cnt
+    _one_triangle_scene(yi, mats[0], cam)
+    sps = f32(g["nodes_in"]).reshape(-1, 18)
+    want = f32(g["nodes_out"]).reshape(len(sps), len(nodes), 5)
+    bad_nodes = []
+    for k, (n, (start, cnt)) in enumerate(zip(nodes, ranges)):
+        inp = np.zeros((len(sps), 20), np.float32)
+        inp[:, :18] = sps
+        inp[:, 18] = np.array([start], np.uint32).view(np.float32)[0]
+        inp[:, 19] = np.array([cnt], np.uint32).view(np.float32)[0]
+        got = yi.probe(14, inp, 5 * cnt)[:, 5 * (cnt - 1):5 * cnt]           # the slot's own node is the last of its range
+        if (got.view(np.uint32) != want[:, k].view(np.uint32)).any():
+            p = int(np.nonzero((got.view(np.uint32) != want[:, k].view(np.uint32)).any(axis=1))[0][0])
+            bad_nodes.append(f"{n} at point {p}: {got[p]} vs {want[p, k]}")
+    assert not bad_nodes, f"{len(bad_nodes)} of {len(nodes)} nodes differ, first: {bad_nodes[0]}"
+
+
+def _textured_box(seed=5, n_tris=400):
+    """the Cornell soup with UVs and orcos on every triangle and a set of materials that drives every shader slot"""
+    rng = np.random.default_rng(seed)
+    sc = scenes.cornell_soup(n_tris, seed=seed, sigma=0.12, res=(48, 40))
+    n = sc["verts"].shape[0]
+    sc["uv"] = rng.uniform(-0.5, 2.5, (n, 3, 2)).astype(np.float32)
+    sc["orco"] = (sc["verts"] * 0.8 + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32)
+    img = lambda w, h: rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    sc["textures"] = [
+        dict(name="t_rgb", texels=img(16, 12), interpolate="bilinear", clipping="repeat", color_space="sRGB"),
+        dict(name="t_chk", texels=img(8, 8), interpolate="none", clipping="checker", even_tiles=True, odd_tiles=False, checker_dist=0.1, xrepeat=2, yrepeat=3,
+             color_space="LinearRGB"),
+        dict(name="t_adj", texels=img(9, 7), interpolate="bilinear", clipping="extend", adj_saturation=1.3, adj_hue=25.0, adj_contrast=0.9, mirror_x=True,
+             color_space="Raw_Manual_Gamma", gamma=2.2),
+    ]
+    mapper = lambda name, tex, texco, mapping="plain", **kw: dict(name=name, type="texture_mapper", texture=tex, texco=texco, mapping=mapping, **kw)
+    layer = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, colfac=1.0, def_col=(1.0, 0.0, 1.0, 1.0), def_val=1.0, do_color=True,
+                                              do_scalar=False, color_input=True, upper_color=(0.8, 0.8, 0.8, 1.0), upper_value=0.0), **kw)
+    scalar_layer = lambda name, inp, upper, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, valfac=1.0, def_val=1.0, do_color=False, do_scalar=True,
+                                                            color_input=True, upper_value=upper), **kw)
+    m = sc["materials"]
+    # 0 walls: the test01 pattern — a colour layer over a cube-mapped orco texture
+    m[0] = {"type": "shinydiffusemat", "color": (0.8, 0.8, 0.8), "diffuse_reflect": 0.9, "diffuse_shader": "diff",
+            "nodes": [layer("diff", "map"), mapper("map", "t_rgb", "orco", "cube", scale=(1.5, 1.5, 1.5), offset=(0.1, 0.2, 0.0))]}
+    # 1: UV-mapped colour, textured mirror strength and mirror colour, Oren-Nayar with a textured sigma
+    m[1] = {"type": "shinydiffusemat", "color": (0.7, 0.2, 0.2), "diffuse_reflect": 0.8, "specular_reflect": 0.3, "mirror_color": (0.9, 0.9, 1.0),
+            "diffuse_brdf": "oren_nayar", "sigma": 0.3,
+            "diffuse_shader": "diff", "mirror_shader": "mir", "mirror_color_shader": "mcol", "sigma_oren_shader": "sig",
+            "nodes": [layer("diff", "map", mode=2, colfac=0.7), mapper("map", "t_adj", "uv"), scalar_layer("mir", "map2", 0.3, valfac=0.5),
+                      mapper("map2", "t_chk", "uv", scale=(2.0, 2.0, 1.0)), layer("mcol", "map2", mode=1), scalar_layer("sig", "map", 0.3, valfac=0.8)]}
+    # 2: textured transparency and translucency (filtered shadows see the texture), a textured diffuse-reflection strength
+    m[2] = {"type": "shinydiffusemat", "color": (0.2, 0.7, 0.2), "diffuse_reflect": 0.9, "transparency": 0.2, "translucency": 0.2, "transmit_filter": 0.7,
+            "transparency_shader": "tr", "translucency_shader": "tl", "diffuse_refl_shader": "dr",
+            "nodes": [scalar_layer("tr", "map", 0.2, valfac=0.6), scalar_layer("tl", "mapg", 0.2, valfac=0.4), scalar_layer("dr", "mapw", 0.9, valfac=0.5),
+                      mapper("map", "t_chk", "global", "tube"), mapper("mapg", "t_rgb", "transformed", transform=np.array([[0.5, 0.1, 0, 0.2], [0, 0.7, 0.2, 0], [0.1, 0, 0.9, -0.1], [0, 0, 0, 1]], np.float32)),
+                      mapper("mapw", "t_adj", "window")]}
+    # 4 (the soup's glossy slot): fresnel with an IOR shader, a mix node feeding the colour, emission read through the diffuse shader
+    m[4] = {"type": "shinydiffusemat", "color": (0.6, 0.6, 0.9), "diffuse_reflect": 0.7, "specular_reflect": 0.4, "fresnel_effect": True, "IOR": 1.4, "emit": 0.15,
+            "diffuse_shader": "mixc", "IOR_shader": "ior",
+            "nodes": [dict(name="mixc", type="mix", mode=3, input1="mapn", input2="val", value=0.4), dict(name="val", type="value", color=(0.9, 0.6, 0.3), alpha=1.0, scalar=0.5),
+                      mapper("mapn", "t_rgb", "normal", "sphere"), scalar_layer("ior", "mapn", 0.0, valfac=0.6)]}
+    sc["tri_mat"] = np.where((np.arange(n) >= 12) & (np.arange(n) % 4 == 3), 4, sc["tri_mat"]).astype(np.int32)
+    return sc
+
+
+@pytest.mark.parametrize("integrator,kw", [("directlighting", dict(transpShad=True, shadowDepth=3)), ("pathtracing", dict(bounces=3, transpShad=True, shadowDepth=2)),
+                                           ("pathtracing", dict(bounces=4, russian_roulette_min_bounces=1))])
+def test_textured_render_matches_oracle(integrator, kw):
+    """every shader slot of shinydiffusemat driven by node graphs over three image textures, UV / orco / global / transformed /
+    window / normal coordinates, plain / cube / tube / sphere mappings: device film against the oracle's on the same scene"""
+    sc = _textured_box()
+    rd = scenes.render_settings(48, 40, 4, integrator=integrator, **kw)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film = yi.getFilm(48, 40)
+    st = yi.getRenderStats()
+    seed, skip = yi.getRandState()
+    osc = po.OracleScene(sc)
+    ofilm, ost = osc.render(dict(rd, oracle_threads=1, rand_srand=seed, rand_skip=skip))     # serial state: roulette stream, light counter
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"textured box {integrator} {kw}", exact_weights=True)
+
+
+def test_test01_with_its_textures_against_the_references_expected_png():
+    """The reference's shipped test scene with the textures this build decodes (TGA, HDR, PNG; tests/golden/test01_tex.xml) rendered
+    on the device through the product's XML loader, (a) against the oracle given the same decoded texels, and (b) against the
+    expected PNG the reference's tests hold, now including the three cubes those textures cover."""
+    from tests import png_fixture, xml_scene
+    path = os.path.join(HERE, "golden", "test01_tex.xml")
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film = yi.getFilm(480, 270)
+    sc, rd = xml_scene.load(path, texels=yi.getTextureImage)
+    seed, skip = yi.getRandState()
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=8, rand_srand=seed, rand_skip=skip))
+    compare_films(film, ofilm, "test01 with textures", exact_weights=False)
+    ref, meta = png_fixture.load_expected()
+    plain_only = png_fixture.compare(film, sc, rd, "device, untextured pixels")
+    meta_all = dict(meta, untextured_materials=meta["untextured_materials"] + meta["decodable_textured_materials"])
+    got = png_fixture.film_to_8bit(film)
+    mask = png_fixture.comparable_mask(sc, rd, meta_all)
+    d = np.abs(got - ref).max(axis=-1)[mask]
+    n = int(mask.sum())
+    stats = {"pixels_compared": n, "fraction_of_frame": n / mask.size, "exact": int((d == 0).sum()), "within_1": int((d <= 1).sum()),
+             "within_2": int((d <= 2).sum()), "max_levels": int(d.max())}
+    print(f"device with textures vs the reference's expected PNG: {stats}")
+    assert stats["pixels_compared"] > plain_only["pixels_compared"] + 3000, (stats, plain_only)       # the three cubes are in
+    assert stats["within_2"] >= 0.99 * n, stats
+    assert stats["within_1"] >= 0.95 * n, stats
+    assert stats["exact"] >= 0.78 * n, stats

@@ -295,8 +295,25 @@ def test_uv_orco_geometry_and_mesh_ptr():
     assert yi.addVertexWithOrco(1, 0, 0, 0.5, 0, 0) == 1 and yi.addVertexWithOrco(0, 1, 0, 0, 0.5, 0) == 2
     assert yi.addUv(0.0, 0.0) == 0 and yi.addUv(1.0, 0.0) == 1 and yi.addUv(0.0, 1.0) == 2
     assert yi.addTriangleWithUv(0, 1, 2, 0, 1, 2, mat)
-    assert not yi.addTriangleWithUv(0, 1, 2, 0, 1, 9, mat) and "UV index" in yi.getLastError()
     assert yi.endTriMesh()
+    # the reference never range-checks UV offsets when a face is added (exporters may list the UVs after the faces,
+    # scene.cc:652-686); the mesh is checked as a whole when it is closed — bad offsets and the reference's own
+    # "UV-offsets mismatch!" (scene.cc:319-326)
+    assert yi.startTriMesh(yi.getNextFreeId(), 3, 1, False, True)
+    for v in ((0, 0, 0), (1, 0, 0), (0, 1, 0)):
+        yi.addVertex(*v)
+    assert yi.addTriangleWithUv(0, 1, 2, 0, 1, 2, mat)                  # UVs still to come
+    assert yi.addUv(0.0, 0.0) == 0 and yi.addUv(1.0, 0.0) == 1
+    assert not yi.endTriMesh() and "UV index" in yi.getLastError()
+    assert yi.addUv(0.0, 1.0) == 2
+    assert yi.addTriangle(0, 1, 2, mat)                                 # a face without UVs on a UV mesh
+    assert not yi.endTriMesh() and "mismatch" in yi.getLastError()
+    assert yi.addTriangleWithUv(0, 1, 2, 2, 1, 0, mat)                  # (the counts now differ for good: 3 faces, 2 with UVs)
+    assert not yi.endTriMesh()
+    yi.clearAll(); yi.startScene(0)
+    yi.paramsClearAll(); yi.paramsSet({"type": "shinydiffusemat"})
+    mat = yi.createMaterial("m")
+    yi.startGeometry()
     assert yi.startTriMesh(yi.getNextFreeId(), 3, 1, False, False)
     assert yi.addVertexWithOrco(0, 0, 0, 0, 0, 0) == -1 and "orco" in yi.getLastError()
     assert not yi.addTriangleWithUv(0, 0, 0, 0, 0, 0, mat) and "UV" in yi.getLastError()

@@ -43,6 +43,7 @@ IMAGE_CASES = {   # the harness's TexCase table (ref_textures.cc sec_image), res
 def test_image_texture_lookups(name):
     g = golden("ieee")
     c = dict(IMAGE_CASES[name])
+    c.setdefault("color_space", "sRGB")               # the harness builds its ImageTexture with Srgb unless the case says otherwise
     w, h = c.pop("w"), c.pop("h")
     texels = f32(g[name + "_texels"]).reshape(h, w, 4)
     d = po.texture_desc(dict(c, texels=texels))
@@ -106,7 +107,7 @@ def test_shader_node_graph():
     colour, alpha and scalar bit for bit.  tube / sphere mappings go through libm's atan2 / acos in double on both sides."""
     g = golden("ieee")
     nodes = _node_graph(g)
-    tex = dict(name="t", texels=f32(g["nodes_texels"]).reshape(5, 6, 4), interpolate="bilinear", clipping="repeat")
+    tex = dict(name="t", texels=f32(g["nodes_texels"]).reshape(5, 6, 4), interpolate="bilinear", clipping="repeat", color_space="sRGB")
     arr, index = po.node_descs(nodes, {"t": 0})
     assert [index[n["name"]] for n in nodes] == list(range(len(nodes)))          # the harness built them in evaluation order
     td = po.texture_desc(tex)

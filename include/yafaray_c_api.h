@@ -168,6 +168,12 @@ yafaray_bool_t yafaray_getFilm(yafaray_interface_t *yi, float *film, int width, 
 yafaray_bool_t yafaray_getRenderStats(yafaray_interface_t *yi, yafaray_render_stats_t *stats);
 /* pixel-tile sharding: must be set before render; tile t belongs to shard t % count */
 void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count);
+/* Multi-pass (adaptive) anti-aliasing on a sharded frame: between passes the noise detection (integrator_tiled.cc:136-258)
+ * needs every rank's pixels.  `fn` receives a copy of this rank's splat planes in DEVICE memory and must sum it over all ranks
+ * in place (an all-reduce; libyafaray_amd/parallel.py does it with torch.distributed = RCCL) and return 0.  Without it a sharded
+ * multi-pass render is refused.  The film a rank returns stays its own share (sum them as for a one-pass render). */
+typedef int (*yafaray_plane_exchange_t)(void *user, float *d_values, uint64_t n_floats);
+void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user);
 /* Exact replay of the reference's serial render state (on by default): the per-tile Random that Russian roulette draws from
  * (integrator_tiled.cc:319, seeded from libc rand() as the last Material / ObjectGeometric constructor left it;
  * integrator_path_tracer.cc:282-288) and the estimateOneDirectLight counter (integrator_montecarlo.cc:62-76), both as a

@@ -54,6 +54,8 @@ typedef struct yafgpu_material
 	float gloss_color[3], diff_color[3];
 	float exponent, reflectivity, diffuse;
 	int32_t as_diffuse, with_diffuse;
+	int32_t anisotropic;           /* the Ashikhmin-Shirley lobe with exp_u / exp_v instead of Blinn (material_utils_microfacet.h:38-87) */
+	float exp_u, exp_v;
 	/* light material */
 	float light_col[3];
 	int32_t double_sided;
@@ -283,6 +285,14 @@ void yafgpu_glibc_rand(uint32_t seed, int32_t count, int32_t *out);
 /* Scene::abort (scene.cc:75-89): the render entry points poll *flag between wavefront chunks and between passes and
  * return -30 ("aborted") once it is non-zero.  The flag stays owned by the caller; NULL detaches it. */
 int yafgpu_scene_set_abort_flag(yafgpu_scene_t *scene, const volatile int32_t *flag);
+/* Multi-pass (adaptive) anti-aliasing on a sharded frame: the noise detection between passes (integrator_tiled.cc:136-258) reads
+ * every pixel, other ranks' tiles included.  With an exchange function attached, yafgpu_render_passes_to_host hands it a COPY of
+ * this rank's four splat planes (device memory, n_floats values) after every pass that is followed by a detection step; the
+ * function sums the copies over all ranks in place (an all-reduce: RCCL over xGMI) and returns 0.  Every plane element is
+ * written by exactly one rank, so the sums are exact (x + 0) and every rank derives the single-GPU render's resample mask.
+ * The rank's own planes, and the film it returns at the end, stay its own share. */
+typedef int (*yafgpu_exchange_fn)(void *user, float *d_values, uint64_t n_floats);
+int yafgpu_scene_set_exchange(yafgpu_scene_t *scene, yafgpu_exchange_fn fn, void *user);
 int yafgpu_get_profile(const yafgpu_scene_t *scene, double ms[4], uint64_t launches[4]);
 
 /* Component probe for tests: evaluates device-side leaf functions (fast-math, QMC, camera, lights,

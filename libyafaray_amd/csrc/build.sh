@@ -12,13 +12,13 @@ mkdir -p "$HERE/obj"
 "$HIPCC" $FLAGS -c "$HERE/yafgpu_device.hip" -o "$HERE/obj/yafgpu_device.o" ${YAFGPU_EXTRA_FLAGS:-} &
 PID_DEV=$!
 #   diffuse: shinydiffusemat + light_mat, no recursiveRaytrace (BASELINE configs C2, C3)
-"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=diffuse -DYAFGPU_MAT_MASK=0x5u -DYAFGPU_FEAT_RECURSE=0 -DYAFGPU_FEAT_TEXTURE=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_diffuse.o" ${YAFGPU_EXTRA_FLAGS:-} &
+"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=diffuse -DYAFGPU_MAT_MASK=0x5u -DYAFGPU_FEAT_RECURSE=0 -DYAFGPU_FEAT_TEXTURE=0 -DYAFGPU_FEAT_ANISO=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_diffuse.o" ${YAFGPU_EXTRA_FLAGS:-} &
 PID_V1=$!
 #   glossy: + glossy (as_diffuse), no recursiveRaytrace (C4)
-"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=glossy -DYAFGPU_MAT_MASK=0x7u -DYAFGPU_FEAT_RECURSE=0 -DYAFGPU_FEAT_TEXTURE=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_glossy.o" ${YAFGPU_EXTRA_FLAGS:-} &
+"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=glossy -DYAFGPU_MAT_MASK=0x7u -DYAFGPU_FEAT_RECURSE=0 -DYAFGPU_FEAT_TEXTURE=0 -DYAFGPU_FEAT_ANISO=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_glossy.o" ${YAFGPU_EXTRA_FLAGS:-} &
 PID_V2=$!
 #   full: every material type and recursiveRaytrace, no shader nodes / textures (the main unit's kernel has those too)
-"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=full -DYAFGPU_MAT_MASK=0x3fu -DYAFGPU_FEAT_RECURSE=1 -DYAFGPU_FEAT_TEXTURE=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_full.o" ${YAFGPU_EXTRA_FLAGS:-} &
+"$HIPCC" $FLAGS -DYAFGPU_VARIANT_NAME=full -DYAFGPU_MAT_MASK=0x3fu -DYAFGPU_FEAT_RECURSE=1 -DYAFGPU_FEAT_TEXTURE=0 -DYAFGPU_FEAT_ANISO=0 -c "$HERE/yafgpu_shade_variant.hip" -o "$HERE/obj/shade_full.o" ${YAFGPU_EXTRA_FLAGS:-} &
 PID_V3=$!
 wait $PID_DEV; wait $PID_V1; wait $PID_V2; wait $PID_V3
 "$HIPCC" $FLAGS -c "$HERE/kdtree_build.cpp" -o "$HERE/obj/kdtree_build.o"

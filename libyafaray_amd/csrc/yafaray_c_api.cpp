@@ -119,6 +119,7 @@ struct yafaray_interface
 	uint32_t last_srand = 0u; bool have_srand = false;
 	bool serial_replay = true;           // yafaray_setSerialReplay
 	std::vector<int32_t> tile_rand0;     // the first pass's value per tile (yafaray_renderPassDevice)
+	yafgpu_exchange_fn exchange = nullptr; void *exchange_user = nullptr;     // yafaray_setPlaneExchange
 	volatile int32_t abort_flag = 0;     // Scene::abort: set by yafaray_abort (any thread), polled by the device side between chunks and passes
 	std::string color_space = "Raw_Manual_Gamma"; float gamma = 1.f;
 	std::string color_space2 = "Raw_Manual_Gamma"; float gamma2 = 1.f;
@@ -461,7 +462,7 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	p.getColor("color", col); p.getColor("diffuse_color", dcol); p.get("diffuse_reflect", diff); p.get("glossy_reflect", refl);
 	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
-	if(aniso) return fail(yi, "glossy: the anisotropic (Ashikhmin-Shirley) lobe is not supported by the GPU path");
+	if(!as_diff) return fail(yi, "glossy: as_diffuse = false needs recursiveRaytrace's glossy branch (integrator_montecarlo.cc:861-972), which the GPU path does not implement");
 	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
 	{ int add_depth = 0; p.get("additionaldepth", add_depth); if(add_depth != 0) return fail(yi, "glossy: additionaldepth is not supported by the GPU path"); }
 	if(!yi->eparams.empty()) return fail(yi, "glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
@@ -469,6 +470,12 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	m.type = YAFGPU_MAT_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; }
 	m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
+	if(aniso)
+	{	// material_glossy.cc:464-472
+		float e_u = 50.f, e_v = 50.f;
+		p.get("exp_u", e_u); p.get("exp_v", e_v);
+		m.anisotropic = 1; m.exp_u = e_u; m.exp_v = e_v;
+	}
 	m.bsdf_flags = 0u;
 	if(diff > 0) { m.bsdf_flags = 0x4u | 0x10u; m.with_diffuse = 1; }
 	m.bsdf_flags |= as_diff ? (0x4u | 0x10u) : (0x2u | 0x10u);
@@ -506,7 +513,6 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso); p.get("IOR", ior);
 	p.getColor("mirror_color", mcol); p.get("specular_reflect", mirror);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire);
-	if(aniso) return fail(yi, "coated_glossy: the anisotropic (Ashikhmin-Shirley) lobe is not supported by the GPU path");
 	if(!as_diff) return fail(yi, "coated_glossy: as_diffuse = false needs recursiveRaytrace's glossy branch, which the GPU path does not implement");
 	if(wire != 0.f) return fail(yi, "coated_glossy: wireframe shading is not supported by the GPU path");
 	if(add_depth != 0) return fail(yi, "coated_glossy: additionaldepth is not supported by the GPU path");
@@ -516,6 +522,12 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	m.type = YAFGPU_MAT_COATED_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; m.mirror_color[k] = mcol[k]; }
 	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = 1;
+	if(aniso)
+	{	// material_coated_glossy.cc:529-537
+		float e_u = 50.f, e_v = 50.f;
+		p.get("exp_u", e_u); p.get("exp_v", e_v);
+		m.anisotropic = 1; m.exp_u = e_u; m.exp_v = e_v;
+	}
 	m.c_flags[0] = 0x1u | 0x10u;                                    // Specular | Reflect
 	m.c_flags[1] = 0x4u | 0x10u;                                    // as_diffuse: Diffuse | Reflect
 	if(diff > 0.f) { m.c_flags[2] = 0x4u | 0x10u; m.with_diffuse = 1; m.n_bsdf = 3; }
@@ -1223,6 +1235,11 @@ void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip)
 	if(skip) *skip = yi->have_srand ? colour_loop_draws(yi->last_srand) : 0;
 }
 void yafaray_setSerialReplay(yafaray_interface_t *yi, yafaray_bool_t on) { yi->serial_replay = on != 0; yi->prepared = false; }
+void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user)
+{
+	yi->exchange = fn; yi->exchange_user = user;
+	if(yi->gpu) yafgpu_scene_set_exchange(yi->gpu, fn, user);
+}
 void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count) { yi->shard_index = shard_index; yi->shard_count = std::max(1, shard_count); }
 
 // RenderEnvironment::setupScene (environment.cc:679-813) + createImageFilm (:456-584) + Scene::update (scene.cc:784-894)
@@ -1396,6 +1413,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	int threads = -1; p.get("threads", threads); if(threads > 0) d.build_threads = threads;
 	if(yafgpu_scene_create(&d, &yi->gpu)) return fail(yi, std::string("scene upload: ") + yafgpu_last_error());
 	yafgpu_scene_set_abort_flag(yi->gpu, &yi->abort_flag);
+	yafgpu_scene_set_exchange(yi->gpu, yi->exchange, yi->exchange_user);
 	yafgpu_tree_info ti{};
 	yafgpu_scene_info(yi->gpu, &ti);
 	yi->stats = yafaray_render_stats_t{};

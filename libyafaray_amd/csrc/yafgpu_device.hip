@@ -66,7 +66,7 @@ struct DevScene
 	const int *faure;            // concatenated Faure permutations
 	const int *faure_off;        // [50] offsets into faure
 	const double *inv_prims;     // [50]
-	int n_lights, n_tris;
+	int n_lights, n_tris, n_mats;
 	uint32_t n_nodes;
 	float blo[3], bhi[3];
 	yafgpu_camera cam;
@@ -1090,6 +1090,7 @@ struct yafgpu_scene
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
+	bool has_aniso = false;              // some material has the anisotropic glossy lobe: the general shading kernel
 	bool has_textures = false;           // some material in use has shader nodes: the general shading kernel, texture coordinates parked per path
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
@@ -1098,6 +1099,7 @@ struct yafgpu_scene
 	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
 	std::vector<uint32_t> h_listed;                      // pixels of a masked (adaptive) pass, in tile order
 	std::vector<uint32_t> h_seg_begin, h_seg_seed;       // every chunk's segments of the pass, uploaded once (scene-owned: an async copy may read them late)
+	yafgpu_exchange_fn exchange = nullptr; void *exchange_user = nullptr;     // yafgpu_scene_set_exchange
 	const volatile int32_t *abort_flag = nullptr;      // polled between chunks and passes (yafgpu_scene_set_abort_flag)
 	bool aborted() const { return abort_flag && *abort_flag != 0; }
 	bool profiling = false;
@@ -1299,6 +1301,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			if(m.n_nodes < 0 || m.n_nodes > kMaxNodes || m.node_first < 0 || m.node_first + m.n_nodes > d->n_nodes)
 			{ yafgpu_scene_destroy(s); return fail(-24, "a material's shader nodes: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
 			if(m.n_nodes > 0) s->has_textures = true;
+			if(m.anisotropic) s->has_aniso = true;
 		}
 		for(int i = 0; i < d->n_nodes; ++i)
 		{
@@ -1321,7 +1324,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	if((rc = upload(s, faure.data(), faure.size(), &dv.faure))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, foff.data(), foff.size(), &dv.faure_off))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, invp.data(), invp.size(), &dv.inv_prims))) { yafgpu_scene_destroy(s); return rc; }
-	dv.n_lights = d->n_lights; dv.n_tris = d->n_tris; dv.n_nodes = (uint32_t)s->tree.nodes.size();
+	dv.n_lights = d->n_lights; dv.n_tris = d->n_tris; dv.n_mats = d->n_materials; dv.n_nodes = (uint32_t)s->tree.nodes.size();
 	for(int k = 0; k < 3; ++k) { dv.blo[k] = s->tree.bound_lo[k]; dv.bhi[k] = s->tree.bound_hi[k]; }
 	dv.cam = d->camera;
 	{	// PerspectiveCamera ctor, camera_perspective.cc:42-54: corner table of the polygonal bokeh shapes
@@ -1509,7 +1512,7 @@ static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
 {
 	if(const char *e = std::getenv("YAFGPU_SHADE_VARIANT")) if(std::strcmp(e, "general") == 0) return nullptr;
 	const bool needs_recurse = frames > 0 || s->has_volumetric;
-	if(s->has_textures) return nullptr;        // the variants are built without shader nodes
+	if(s->has_textures || s->has_aniso) return nullptr;        // the variants are built without shader nodes and without the anisotropic lobe
 	for(const ShadeVariant &v : kShadeVariants)
 	{
 		uint32_t mask = 0u; int recurse = 0;
@@ -2092,7 +2095,8 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	yafgpu_aa_schedule aa{};
 	if(aa_in) aa = *aa_in;
 	if(aa.passes < 1) aa.passes = 1;
-	if(aa.passes > 1 && rp_in->shard_count > 1) return fail(-16, "multi-pass anti-aliasing needs the whole frame on one GPU: the noise detection between passes reads every pixel");
+	const bool exchange = aa.passes > 1 && rp_in->shard_count > 1;
+	if(exchange && !s->exchange) return fail(-16, "multi-pass anti-aliasing on a sharded frame needs an exchange function (yafgpu_scene_set_exchange): the noise detection between passes reads every pixel");
 	yafgpu_render_params rp = *rp_in;
 	const int w = rp.width, h = rp.height;
 	if(w <= 0 || h <= 0) return fail(-10, "empty image");
@@ -2104,6 +2108,19 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
 	auto film_now = [&]() -> int {
 		int rc = yafgpu_film_combine(d_planes, d_film, w, h, nullptr);
+		if(!rc && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
+		return rc;
+	};
+	// the whole frame's film for the detection step of a sharded render: all ranks' planes summed (exactly: one writer per
+	// element), then combined in the single-GPU order
+	DevMem<float> d_all;
+	const size_t plane_floats = yafgpu_planes_bytes(w, h) / sizeof(float);
+	auto film_of_all_ranks = [&]() -> int {
+		if(!d_all.p && d_all.alloc(plane_floats) != hipSuccess) return fail(-3, "out of device memory (plane exchange)");
+		if(hipMemcpy(d_all, d_planes, plane_floats * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return fail(-100, "plane copy failed");
+		if(hipDeviceSynchronize() != hipSuccess) return fail(-100, "render failed before the plane exchange");
+		if(s->exchange(s->exchange_user, d_all, (uint64_t)plane_floats)) return fail(-31, "the plane exchange function reported a failure");
+		int rc = yafgpu_film_combine(d_all, d_film, w, h, nullptr);
 		if(!rc && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
 		return rc;
 	};
@@ -2136,7 +2153,7 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 		light_mult *= aa.light_sample_multiplier_factor;
 		if(!(resampled <= 0 && !threshold_changed))
 		{
-			if((rc = film_now())) break;
+			if((rc = exchange ? film_of_all_ranks() : film_now())) break;
 			resampled = next_pass_mask(h_film, w, h, aa, threshold, mask);
 			threshold_changed = false;
 		}
@@ -2223,6 +2240,13 @@ void yafgpu_glibc_rand(uint32_t seed, int32_t count, int32_t *out)
 	for(size_t i = 31; i < 34; ++i) r[i] = r[i - 31];
 	for(size_t i = 34; i < r.size(); ++i) r[i] = r[i - 31] + r[i - 3];
 	for(int32_t k = 0; k < count; ++k) out[k] = (int32_t)(r[(size_t)k + 344] >> 1);
+}
+
+int yafgpu_scene_set_exchange(yafgpu_scene_t *s, yafgpu_exchange_fn fn, void *user)
+{
+	if(!s) return fail(-1, "null argument");
+	s->exchange = fn; s->exchange_user = user;
+	return 0;
 }
 
 int yafgpu_scene_set_abort_flag(yafgpu_scene_t *s, const volatile int32_t *flag)

@@ -222,6 +222,43 @@ YG_DEV V3 vec_reflect(V3 v, V3 n)      // Vec3::reflect, vector.h:291-298
 	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
 	return mk(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
 }
+// the anisotropic Ashikhmin-Shirley lobe, material_utils_microfacet.h:38-87.  tanf: the reference calls libm's; here the double
+// tan narrowed once, which agrees with a correctly rounded tanf except in double-rounding ties (glibc's is within 1 ulp)
+YG_DEV V3 sample_quadrant_aniso(float s_1, float s_2, float e_u, float e_v) // :38-51
+{
+	const float t = (float)tan((double)(float)(1.57079632679489661923 * (double)s_1));
+	const float phi = (float)atan((double)(f_sqrt((e_u + 1.f) / (e_v + 1.f)) * t));
+	const float cos_phi = f_cos(phi), sin_phi = f_sin(phi);
+	const float cos_phi_2 = cos_phi * cos_phi;
+	const float sin_phi_2 = 1.f - cos_phi_2;
+	const float cos_theta = f_pow(1.f - s_2, 1.f / (e_u * cos_phi_2 + e_v * sin_phi_2 + 1.f));
+	const float sin_theta = f_sqrt(1.f - cos_theta * cos_theta);
+	return mk(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+YG_DEV float as_aniso_d(V3 h, float e_u, float e_v) // :53-58
+{
+	if(h.z <= 0.f) return 0.f;
+	const float exponent = (e_u * h.x * h.x + e_v * h.y * h.y) / (1.00001f - h.z * h.z);
+	return f_sqrt((e_u + 1.f) * (e_v + 1.f)) * f_pow(smax(0.f, h.z), exponent);
+}
+YG_DEV V3 as_aniso_sample(float s_1, float s_2, float e_u, float e_v) // :65-87
+{
+	V3 h;
+	if(s_1 < 0.25f) h = sample_quadrant_aniso(4.f * s_1, s_2, e_u, e_v);
+	else if(s_1 < 0.5f) { h = sample_quadrant_aniso(1.f - 4.f * (0.5f - s_1), s_2, e_u, e_v); h.x = -h.x; }
+	else if(s_1 < 0.75f) { h = sample_quadrant_aniso(4.f * (s_1 - 0.5f), s_2, e_u, e_v); h.x = -h.x; h.y = -h.y; }
+	else { h = sample_quadrant_aniso(1.f - 4.f * (1.f - s_1), s_2, e_u, e_v); h.y = -h.y; }
+	return h;
+}
+// the material's glossy lobe: Blinn on cos(n, h), or the anisotropic lobe on h in the shading frame (hs)
+#ifndef YAFGPU_FEAT_ANISO
+#define YAFGPU_FEAT_ANISO 1      // the specialised shading kernels are built without the anisotropic lobe (a scene that has one runs the general kernel)
+#endif
+YG_DEV float lobe_d(const yafgpu_material &m, V3 hs, float cos_n_h) { return (YAFGPU_FEAT_ANISO && m.anisotropic) ? as_aniso_d(hs, m.exp_u, m.exp_v) : blinn_d(cos_n_h, m.exponent); }
+YG_DEV float lobe_pdf(const yafgpu_material &m, V3 hs, float cos_n_h, float cos_w_h) { return (float)((double)lobe_d(m, hs, cos_n_h) / pdf_divisor(cos_w_h)); }
+YG_DEV V3 lobe_sample(const yafgpu_material &m, float s_1, float s_2) { return (YAFGPU_FEAT_ANISO && m.anisotropic) ? as_aniso_sample(s_1, s_2, m.exp_u, m.exp_v) : blinn_sample(s_1, s_2, m.exponent); }
+YG_DEV V3 local_h(const yafgpu_material &m, const SurfPt &sp, V3 h, float cos_n_h) { return (YAFGPU_FEAT_ANISO && m.anisotropic) ? mk(dot(h, sp.nu), dot(h, sp.nv), cos_n_h) : mk(0.f, 0.f, cos_n_h); }
+
 // Material::eval — material_shiny_diffuse.cc:244-293, material_glossy.cc:113-173
 YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 wl, uint32_t bsdfs)
 {
@@ -252,7 +289,8 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		{
 			const V3 h = normalize(wo + wl);
 			const float cos_wi_h = smax(0.f, dot(wl, h));
-			const float glossy = (float)((double)(blinn_d(dot(h, n), m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			const float cos_n_h = dot(h, n);
+			const float glossy = (float)((double)(lobe_d(m, local_h(m, sp, h, cos_n_h), cos_n_h) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 			col = col3(m.gloss_color) * glossy;
 		}
 		if(m.with_diffuse)
@@ -276,7 +314,8 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		{
 			const V3 h = normalize(wo + wl);
 			const float cos_wi_h = dot(wl, h);
-			const float glossy = (float)((double)(kt * blinn_d(dot(h, n), m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			const float cos_n_h = dot(h, n);
+			const float glossy = (float)((double)(kt * lobe_d(m, local_h(m, sp, h, cos_n_h), cos_n_h) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 			col = col3(m.gloss_color) * glossy;
 		}
 		if(m.with_diffuse && diffuse_flag)
@@ -332,14 +371,16 @@ YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &s
 			if(use_glossy)
 			{
 				const V3 h = normalize(wi + wo);
-				pdf = pdf * d.p_diffuse + blinn_pdf(dot(n, h), dot(wo, h), m.exponent) * (1.f - d.p_diffuse);
+				const float cos_n_h = dot(n, h);
+				pdf = pdf * d.p_diffuse + lobe_pdf(m, local_h(m, sp, h, cos_n_h), cos_n_h, dot(wo, h)) * (1.f - d.p_diffuse);
 			}
 			return pdf;
 		}
 		if(use_glossy)
 		{
 			const V3 h = normalize(wi + wo);
-			pdf = blinn_pdf(dot(n, h), dot(wo, h), m.exponent);
+			const float cos_n_h = dot(n, h);
+			pdf = lobe_pdf(m, local_h(m, sp, h, cos_n_h), cos_n_h, dot(wo, h));
 		}
 		return pdf;
 	}
@@ -361,7 +402,8 @@ YG_MAT float mat_pdf(const yafgpu_material &m, const BsdfDat &d, const SurfPt &s
 				if(i == 1)
 				{
 					const V3 h = normalize(wi + wo);
-					pdf += blinn_pdf(dot(n, h), dot(wo, h), m.exponent) * width;
+					const float cos_n_h = dot(n, h);
+					pdf += lobe_pdf(m, local_h(m, sp, h, cos_n_h), cos_n_h, dot(wo, h)) * width;
 				}
 				else if(i == 2) pdf += fabsf(dot(wi, n)) * width;
 				++n_match;
@@ -596,7 +638,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 			scolor = (col3(m.mirror_color) * kr) * m.mirror_strength;
 			s.pdf = w_pick;
 		}
-		else if(ci == 1) hs = blinn_sample(s_1, s.s_2, m.exponent);
+		else if(ci == 1) hs = lobe_sample(m, s_1, s.s_2);
 		else
 		{
 			wi = sample_cos_hemisphere(n, sp.nu, sp.nv, s_1, s.s_2);
@@ -614,6 +656,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 				if(ci != 1)
 				{
 					h = normalize(wi + wo);
+					hs = local_h(m, sp, h, dot(h, n));
 					cos_wo_h = dot(wo, h);
 				}
 				else
@@ -627,8 +670,8 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 				}
 				wi_n = fabsf(dot(wi, n));
 				const float cos_hn = dot(h, n);
-				s.pdf += blinn_pdf(cos_hn, cos_wo_h, m.exponent) * w_glossy;
-				const float glossy = (float)((double)(blinn_d(cos_hn, m.exponent) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+				s.pdf += lobe_pdf(m, hs, cos_hn, cos_wo_h) * w_glossy;
+				const float glossy = (float)((double)(lobe_d(m, hs, cos_hn) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
 				scolor = col3(m.gloss_color) * (glossy * kt);
 			}
 			if(use2)
@@ -748,8 +791,9 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 					const float cos_wo_h = dot(wo, h);
 					const float cos_wi_h = fabsf(dot(wi, h));
 					const float cos_n_h = dot(n, h);
-					s.pdf = s.pdf * cur_p + blinn_pdf(cos_n_h, cos_wo_h, m.exponent) * (1.f - cur_p);
-					glossy = (float)((double)(blinn_d(cos_n_h, m.exponent) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+					const V3 hl = local_h(m, sp, h, cos_n_h);
+					s.pdf = s.pdf * cur_p + lobe_pdf(m, hl, cos_n_h, cos_wo_h) * (1.f - cur_p);
+					glossy = (float)((double)(lobe_d(m, hl, cos_n_h) * schlick_fresnel(cos_wi_h, d.m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 				}
 				s.sampled = kDiffuse | kReflect;
 				if(!(s.flags & kReflect)) return mkc(0.f, 0.f, 0.f);
@@ -765,7 +809,7 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		}
 		if(use_glossy)
 		{
-			const V3 hs = blinn_sample(s_1, s.s_2, m.exponent);
+			const V3 hs = lobe_sample(m, s_1, s.s_2);
 			V3 h = sp.nu * hs.x + sp.nv * hs.y + n * hs.z;
 			float cos_wo_h = dot(wo, h);
 			if(cos_wo_h < 0.f)
@@ -778,8 +822,9 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 			if(cos_ng_wo * dot(sp.ng, wi) < 0.f) return mkc(0.f, 0.f, 0.f);
 			wi_n = fabsf(dot(wi, n));
 			const float cos_hn = dot(h, n);
-			s.pdf = blinn_pdf(cos_hn, cos_wo_h, m.exponent);
-			glossy = (float)((double)(blinn_d(cos_hn, m.exponent) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+			// the anisotropic branch keeps the sampled Hs (:299-300), Blinn takes h * n of the (possibly reflected) h (:325-328)
+			s.pdf = lobe_pdf(m, hs, cos_hn, cos_wo_h);
+			glossy = (float)((double)(lobe_d(m, hs, cos_hn) * schlick_fresnel(cos_wo_h, d.m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
 			scolor = col3(m.gloss_color) * glossy;
 			s.sampled = m.as_diffuse ? (kDiffuse | kReflect) : (kGlossy | kReflect);
 		}

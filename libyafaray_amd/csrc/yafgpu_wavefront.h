@@ -1250,8 +1250,36 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 #ifndef YAFGPU_SHADE_WAVES
 #define YAFGPU_SHADE_WAVES 3     // 168 VGPRs, 44 B of scratch; C2: 3 -> 7.25, 4 -> 8.5 ms per pass (4: 224 B of scratch)
 #endif
-__global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a)
+// Material and light tables staged in LDS: the path program reads dozens of their fields per step through per-lane indices,
+// i.e. as vector loads, each a trip to the vector cache the wave then waits for (PMC: 92 VMEM reads per wave item, 79 % of
+// wave cycles waiting at 3 waves per SIMD).  Scenes whose tables fit kShadeTabBytes read them from LDS instead.
+#ifndef YAFGPU_SHADE_LDS_TABLES
+#define YAFGPU_SHADE_LDS_TABLES 1
+#endif
+constexpr int kShadeTabBytes = 16384;     // 3 blocks per CU at 3 waves per SIMD: 60 KB of the 160 KB
+__global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a_in)
 {
+#if YAFGPU_SHADE_LDS_TABLES
+	__shared__ uint4 s_tab[kShadeTabBytes / 16];
+	WfArgs a = a_in;
+	{
+		const uint32_t mat_bytes = (uint32_t)a_in.ra.sc.n_mats * (uint32_t)sizeof(yafgpu_material);      // multiples of 8
+		const uint32_t light_off = (mat_bytes + 15u) & ~15u;
+		const uint32_t light_bytes = (uint32_t)a_in.ra.sc.n_lights * (uint32_t)sizeof(yafgpu_light);
+		if(light_off + light_bytes <= (uint32_t)kShadeTabBytes)
+		{
+			uint32_t *dst = (uint32_t *)s_tab;
+			const uint32_t *src_m = (const uint32_t *)a_in.ra.sc.mats, *src_l = (const uint32_t *)a_in.ra.sc.lights;
+			for(uint32_t w = threadIdx.x; w < mat_bytes / 4u; w += blockDim.x) dst[w] = src_m[w];
+			for(uint32_t w = threadIdx.x; w < light_bytes / 4u; w += blockDim.x) dst[light_off / 4u + w] = src_l[w];
+			__syncthreads();
+			a.ra.sc.mats = (const yafgpu_material *)s_tab;
+			a.ra.sc.lights = (const yafgpu_light *)((const char *)s_tab + light_off);
+		}
+	}
+#else
+	const WfArgs &a = a_in;
+#endif
 	// Queue appends are aggregated per workgroup over kItems items per thread: one returning atomic per queue
 	// per 1024 paths.  (A single counter word sustains ~90 returning atomics per microsecond; one per wave and
 	// queue — 2 M per pass on C2 — was the whole cost of this kernel.)

@@ -7,6 +7,7 @@ with the diagnostic available from getLastError(); `strict=True` raises instead.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -34,6 +35,7 @@ class RenderStats(C.Structure):
 
 PUTPIXEL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float)
 FLUSH = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)      # yafaray_plane_exchange_t
 AREA = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 
 
@@ -63,7 +65,7 @@ C_API_SYMBOLS = [
     "yafaray_createTexture", "yafaray_createTextureFromMemory", "yafaray_getTextureImage",
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
-    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_prepareRender",
+    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setPlaneExchange", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_prepareRender",
     "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
 ]
 GPU_ABI_SYMBOLS = [
@@ -71,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host", "yafgpu_render_passes_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
     "yafgpu_kdtree_build", "yafgpu_kdtree_build_device", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
-    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag", "yafgpu_glibc_rand",
+    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag", "yafgpu_scene_set_exchange", "yafgpu_glibc_rand",
 ]
 
 
@@ -124,7 +126,7 @@ def load():
         "yafaray_render": (ci, [vp, C.POINTER(Output), vp]), "yafaray_abort": (None, [vp]),
         "yafaray_getRenderedImage": (ci, [vp, ci, C.POINTER(Output)]),
         "yafaray_getFilm": (ci, [vp, C.POINTER(cf), ci, ci]), "yafaray_getRenderStats": (ci, [vp, C.POINTER(RenderStats)]),
-        "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_setSerialReplay": (None, [vp, ci]), "yafaray_prepareRender": (ci, [vp]),
+        "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_setPlaneExchange": (None, [vp, EXCHANGE, vp]), "yafaray_setSerialReplay": (None, [vp, ci]), "yafaray_prepareRender": (ci, [vp]),
         "yafaray_renderPassDevice": (ci, [vp, vp, vp, vp]), "yafaray_getRenderSize": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
         "yafaray_loadXml": (ci, [vp, cp]), "yafaray_getRandState": (None, [vp, C.POINTER(ci), C.POINTER(ci)]),
         "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
@@ -416,6 +418,24 @@ class Interface:
     # -- additions (measurement / multi-GPU)
     def setShard(self, index, count):
         self._L.yafaray_setShard(self._h, index, count)
+
+    def setPlaneExchange(self, fn):
+        """fn(device_pointer: int, n_floats: int): sum that float32 device array over all ranks in place (see
+        libyafaray_amd.parallel.plane_exchange); None detaches it"""
+        if fn is None:
+            self._exchange = None
+            self._L.yafaray_setPlaneExchange(self._h, EXCHANGE(0), None)
+            return
+
+        def thunk(user, ptr, n):
+            try:
+                fn(int(ptr or 0), int(n))
+                return 0
+            except Exception as e:            # an exception must not unwind through the C caller
+                print(f"plane exchange failed: {e!r}", file=sys.stderr)
+                return 1
+        self._exchange = EXCHANGE(thunk)
+        self._L.yafaray_setPlaneExchange(self._h, self._exchange, None)
 
     def setSerialReplay(self, on):
         self._L.yafaray_setSerialReplay(self._h, int(bool(on)))

@@ -23,3 +23,29 @@ def reduce_film(film: torch.Tensor, dst: int = 0):
 
 
 reduce_planes = reduce_film      # the same collective on the four uncombined splat planes
+
+
+class _DeviceFloats:
+    """a float32 device array by address, for torch.as_tensor (the CUDA array interface; zero copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def plane_exchange(device=None):
+    """The function yafaray_setPlaneExchange wants (Interface.setPlaneExchange): all-reduce(sum) of a float32 device array
+    over the process group, in place — RCCL over xGMI with the nccl backend, staged through the host with gloo.  Used
+    between the passes of a multi-pass (adaptive anti-aliasing) render of a sharded frame: every rank gets every rank's
+    splat planes, so every rank takes the single-GPU render's decision about which pixels to sample again."""
+    def exchange(ptr, n):
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        t = torch.as_tensor(_DeviceFloats(ptr, n), device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        if dist.get_backend() == "gloo":          # CPU rehearsals / one-GPU boxes: through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    return exchange

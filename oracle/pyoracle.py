@@ -31,12 +31,13 @@ class MaterialDesc(C.Structure):
         ("glossy_color", f3), ("diffuse_color", f3),
         ("glossy_reflect", C.c_float), ("glossy_diffuse_reflect", C.c_float), ("exponent", C.c_float),
         ("as_diffuse", C.c_int32),
-        ("light_color", f3), ("light_power", C.c_float), ("double_sided", C.c_int32), ("pad1", C.c_int32),
+        ("light_color", f3), ("light_power", C.c_float), ("double_sided", C.c_int32), ("anisotropic", C.c_int32),
         ("absorption", f3), ("has_absorption", C.c_int32), ("absorption_dist", C.c_double),
         ("n_nodes", C.c_int32),
         ("sh_diffuse", C.c_int32), ("sh_mirror_color", C.c_int32), ("sh_mirror", C.c_int32), ("sh_transparency", C.c_int32),
         ("sh_translucency", C.c_int32), ("sh_sigma_oren", C.c_int32), ("sh_diffuse_refl", C.c_int32), ("sh_ior", C.c_int32),
         ("pad2", C.c_int32), ("nodes", C.c_void_p),
+        ("exp_u", C.c_float), ("exp_v", C.c_float),
     ]
 
 
@@ -325,6 +326,7 @@ def material_desc(m):
         d.glossy_reflect = m.get("glossy_reflect", 1.0)
         d.exponent = m.get("exponent", 50.0)
         d.as_diffuse = int(m.get("as_diffuse", True))
+        d.anisotropic, d.exp_u, d.exp_v = int(m.get("anisotropic", False)), m.get("exp_u", 50.0), m.get("exp_v", 50.0)
         d.oren_nayar = int(m.get("diffuse_brdf", "") == "Oren-Nayar")
         d.sigma = m.get("sigma", 0.1)
     elif t == "coated_glossy":
@@ -336,6 +338,7 @@ def material_desc(m):
         d.glossy_reflect = m.get("glossy_reflect", 1.0)
         d.exponent = m.get("exponent", 50.0)
         d.as_diffuse = int(m.get("as_diffuse", True))
+        d.anisotropic, d.exp_u, d.exp_v = int(m.get("anisotropic", False)), m.get("exp_u", 50.0), m.get("exp_v", 50.0)
         d.specular_reflect = m.get("specular_reflect", 1.0)
         ior = m.get("IOR", 1.4)
         d.ior = 1.0000001 if ior == 1.0 else ior

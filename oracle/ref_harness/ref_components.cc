@@ -562,6 +562,30 @@ static void sec_materials(Json &j)
 		Material *m = GlossyMaterial::factory(pm, no_nodes, fake_env());
 		run_material(j, "gl2", m, 160, true);
 	}
+	{	// gl3: the anisotropic Ashikhmin-Shirley lobe (material_utils_microfacet.h:38-87) over a diffuse substrate
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.9f, 0.8f, 0.85f, 1.f)); pm["diffuse_color"] = Parameter(Rgba(0.5f, 0.4f, 0.6f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.5f); pm["glossy_reflect"] = Parameter(0.5f);
+		pm["anisotropic"] = Parameter(true); pm["exp_u"] = Parameter(400.f); pm["exp_v"] = Parameter(12.f);
+		Material *m = GlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "gl3", m, 240, true);
+	}
+	{	// gl4: anisotropic lobe alone, exponents the other way round
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(1.f, 1.f, 1.f, 1.f)); pm["glossy_reflect"] = Parameter(0.9f);
+		pm["anisotropic"] = Parameter(true); pm["exp_u"] = Parameter(8.f); pm["exp_v"] = Parameter(900.f);
+		Material *m = GlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "gl4", m, 160, true);
+	}
+	{	// cg3: coated glossy with the anisotropic lobe
+		ParamMap pm;
+		pm["color"] = Parameter(Rgba(0.9f, 0.9f, 0.8f, 1.f)); pm["diffuse_color"] = Parameter(Rgba(0.2f, 0.6f, 0.5f, 1.f));
+		pm["diffuse_reflect"] = Parameter(0.6f); pm["glossy_reflect"] = Parameter(0.5f);
+		pm["specular_reflect"] = Parameter(0.7f); pm["IOR"] = Parameter(1.5); pm["as_diffuse"] = Parameter(true);
+		pm["anisotropic"] = Parameter(true); pm["exp_u"] = Parameter(30.f); pm["exp_v"] = Parameter(250.f);
+		Material *m = CoatedGlossyMaterial::factory(pm, no_nodes, fake_env());
+		run_material(j, "cg3", m, 200, true, 1);
+	}
 	{	// light material emit
 		ParamMap pm;
 		pm["color"] = Parameter(Rgba(1.f, 0.9f, 0.8f, 1.f)); pm["power"] = Parameter(17.5);

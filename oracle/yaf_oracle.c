@@ -444,6 +444,7 @@ typedef struct
 	rgb gloss_color, diff_color;
 	float exponent, reflectivity, diffuse;
 	int as_diffuse, with_diffuse;
+	int anisotropic; float exp_u, exp_v;
 	/* light mat */
 	rgb light_col; int double_sided;
 	/* glass (material_glass.cc:32-49) and mirror (material_glass.h:74-79) */
@@ -1617,6 +1618,7 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 		m->diff_color = C(d->diffuse_color[0], d->diffuse_color[1], d->diffuse_color[2]);
 		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
 		m->as_diffuse = d->as_diffuse;
+		m->anisotropic = d->anisotropic; m->exp_u = d->exp_u; m->exp_v = d->exp_v;
 		m->flags = BSDF_NONE;
 		if(m->diffuse > 0) { m->flags = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; }
 		m->flags |= m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
@@ -1637,6 +1639,7 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 		m->ior = d->ior;
 		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
 		m->as_diffuse = d->as_diffuse;
+		m->anisotropic = d->anisotropic; m->exp_u = d->exp_u; m->exp_v = d->exp_v;
 		m->c_flags[0] = BSDF_SPECULAR | BSDF_REFLECT;
 		m->c_flags[1] = m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
 		if(m->diffuse > 0) { m->c_flags[2] = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; m->n_bsdf = 3; }
@@ -1895,6 +1898,41 @@ static inline v3 blinn_sample(float s_1, float s_2, float exponent) /* :99-106 *
 	return V(sin_theta * yor_fcos(phi), sin_theta * yor_fsin(phi), cos_theta);
 }
 
+/* the anisotropic Ashikhmin-Shirley lobe, material_utils_microfacet.h:38-87 */
+static inline v3 sample_quadrant_aniso(float s_1, float s_2, float e_u, float e_v) /* :38-51 */
+{
+	float phi = (float)atan((double)(yor_fsqrt((e_u + 1.f) / (e_v + 1.f)) * tanf((float)(Y_M_PI_2 * (double)s_1))));
+	float cos_phi = yor_fcos(phi);
+	float sin_phi = yor_fsin(phi);
+	float cos_theta, sin_theta;
+	float cos_phi_2 = cos_phi * cos_phi;
+	float sin_phi_2 = 1.f - cos_phi_2;
+	cos_theta = yor_fpow(1.f - s_2, 1.f / (e_u * cos_phi_2 + e_v * sin_phi_2 + 1.f));
+	sin_theta = yor_fsqrt(1.f - cos_theta * cos_theta);
+	return V(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+static inline float as_aniso_d(v3 h, float e_u, float e_v) /* :53-58 */
+{
+	if(h.z <= 0.f) return 0.f;
+	float exponent = (e_u * h.x * h.x + e_v * h.y * h.y) / (1.00001f - h.z * h.z);
+	return yor_fsqrt((e_u + 1.f) * (e_v + 1.f)) * yor_fpow(fmaxf_(0.f, h.z), exponent);
+}
+static inline float as_aniso_pdf(v3 h, float cos_w_h, float e_u, float e_v) { return (float)((double)as_aniso_d(h, e_u, e_v) / pdf_divisor(cos_w_h)); } /* :60-63 */
+static inline v3 as_aniso_sample(float s_1, float s_2, float e_u, float e_v) /* :65-87 */
+{
+	v3 h;
+	if(s_1 < 0.25f) h = sample_quadrant_aniso(4.f * s_1, s_2, e_u, e_v);
+	else if(s_1 < 0.5f) { h = sample_quadrant_aniso(1.f - 4.f * (0.5f - s_1), s_2, e_u, e_v); h.x = -h.x; }
+	else if(s_1 < 0.75f) { h = sample_quadrant_aniso(4.f * (s_1 - 0.5f), s_2, e_u, e_v); h.x = -h.x; h.y = -h.y; }
+	else { h = sample_quadrant_aniso(1.f - 4.f * (1.f - s_1), s_2, e_u, e_v); h.y = -h.y; }
+	return h;
+}
+/* the material's glossy lobe: Blinn on cos(n, h), or the anisotropic lobe on h in the shading frame (hs) */
+static inline float lobe_d(const mat_t *m, v3 hs, float cos_n_h) { return m->anisotropic ? as_aniso_d(hs, m->exp_u, m->exp_v) : blinn_d(cos_n_h, m->exponent); }
+static inline float lobe_pdf(const mat_t *m, v3 hs, float cos_n_h, float cos_w_h) { return m->anisotropic ? as_aniso_pdf(hs, cos_w_h, m->exp_u, m->exp_v) : blinn_pdf(cos_n_h, cos_w_h, m->exponent); }
+static inline v3 lobe_sample(const mat_t *m, float s_1, float s_2) { return m->anisotropic ? as_aniso_sample(s_1, s_2, m->exp_u, m->exp_v) : blinn_sample(s_1, s_2, m->exponent); }
+static inline v3 local_h(const sp_t *sp, v3 h, float cos_n_h) { return V(vdot(h, sp->nu), vdot(h, sp->nv), cos_n_h); }
+
 static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 wl, unsigned bsdfs)
 {
 	if(m->type == YOR_MAT_SHINYDIFFUSE)
@@ -1928,7 +1966,8 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		{
 			v3 h = vnormalize(vadd(wo, wl));
 			float cos_wi_h = fmaxf_(0.f, vdot(wl, h));
-			float glossy = (float)((double)(blinn_d(vdot(h, n), m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			float cos_n_h = vdot(h, n);
+			float glossy = (float)((double)(lobe_d(m, local_h(sp, h, cos_n_h), cos_n_h) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 			col = cscale(m->gloss_color, glossy);
 		}
 		if(m->with_diffuse && diffuse_flag)
@@ -1953,7 +1992,8 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		{
 			v3 h = vnormalize(vadd(wo, wl));
 			float cos_wi_h = vdot(wl, h);
-			float glossy = (float)((double)(kt * blinn_d(vdot(h, n), m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+			float cos_n_h = vdot(h, n);
+			float glossy = (float)((double)(kt * lobe_d(m, local_h(sp, h, cos_n_h), cos_n_h) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 			col = cscale(m->gloss_color, glossy);
 		}
 		if(m->with_diffuse && diffuse_flag)
@@ -2022,7 +2062,7 @@ static float mat_pdf(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo,
 					v3 h = vnormalize(vadd(wi, wo));
 					float cos_wo_h = vdot(wo, h);
 					float cos_n_h = vdot(n, h);
-					pdf += blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * width;
+					pdf += lobe_pdf(m, local_h(sp, h, cos_n_h), cos_n_h, cos_wo_h) * width;
 				}
 				else if(i == 2) pdf += fabsf(vdot(wi, n)) * width;
 				++n_match;
@@ -2047,7 +2087,7 @@ static float mat_pdf(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo,
 				v3 h = vnormalize(vadd(wi, wo));
 				float cos_wo_h = vdot(wo, h);
 				float cos_n_h = vdot(n, h);
-				pdf = pdf * cur_p_diffuse + blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * (1.f - cur_p_diffuse);
+				pdf = pdf * cur_p_diffuse + lobe_pdf(m, local_h(sp, h, cos_n_h), cos_n_h, cos_wo_h) * (1.f - cur_p_diffuse);
 			}
 			return pdf;
 		}
@@ -2056,7 +2096,7 @@ static float mat_pdf(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo,
 			v3 h = vnormalize(vadd(wi, wo));
 			float cos_wo_h = vdot(wo, h);
 			float cos_n_h = vdot(n, h);
-			pdf = blinn_pdf(cos_n_h, cos_wo_h, m->exponent);
+			pdf = lobe_pdf(m, local_h(sp, h, cos_n_h), cos_n_h, cos_wo_h);
 		}
 		return pdf;
 	}
@@ -2360,8 +2400,9 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 					cos_wo_h = vdot(wo, h);
 					float cos_wi_h = fabsf(vdot(*wi, h));
 					float cos_n_h = vdot(n, h);
-					s->pdf = s->pdf * cur_p_diffuse + blinn_pdf(cos_n_h, cos_wo_h, m->exponent) * (1.f - cur_p_diffuse);
-					glossy = (float)((double)(blinn_d(cos_n_h, m->exponent) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
+					v3 hl = local_h(sp, h, cos_n_h);
+					s->pdf = s->pdf * cur_p_diffuse + lobe_pdf(m, hl, cos_n_h, cos_wo_h) * (1.f - cur_p_diffuse);
+					glossy = (float)((double)(lobe_d(m, hl, cos_n_h) * schlick_fresnel(cos_wi_h, dat->m_glossy)) / as_divisor(cos_wi_h, wo_n, wi_n));
 				}
 				s->sampled_flags = BSDF_DIFFUSE | BSDF_REFLECT;
 				if(!(s->flags & BSDF_REFLECT)) return C(0, 0, 0);
@@ -2379,7 +2420,7 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 		}
 		if(use_glossy)
 		{
-			v3 hs = blinn_sample(s_1, s->s_2, m->exponent);
+			v3 hs = lobe_sample(m, s_1, s->s_2);
 			v3 h = vadd(vadd(vmul(sp->nu, hs.x), vmul(sp->nv, hs.y)), vmul(n, hs.z));
 			cos_wo_h = vdot(wo, h);
 			if(cos_wo_h < 0.f)
@@ -2394,8 +2435,9 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 			wi_n = fabsf(vdot(*wi, n));
 			{
 				float cos_hn = vdot(h, n);
-				s->pdf = blinn_pdf(cos_hn, cos_wo_h, m->exponent);
-				glossy = (float)((double)(blinn_d(cos_hn, m->exponent) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+				/* the anisotropic branch keeps the sampled Hs (:299-300), Blinn takes h * n of the (possibly reflected) h (:325-328) */
+				s->pdf = lobe_pdf(m, hs, cos_hn, cos_wo_h);
+				glossy = (float)((double)(lobe_d(m, hs, cos_hn) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
 			}
 			scolor = cscale(m->gloss_color, glossy);
 			s->sampled_flags = m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
@@ -2467,7 +2509,7 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 				s->pdf = width[pick];
 				break;
 			case 1:
-				hs = blinn_sample(s_1, s->s_2, m->exponent);
+				hs = lobe_sample(m, s_1, s->s_2);
 				break;
 			default:
 				*wi = sample_cos_hemisphere(n, sp->nu, sp->nv, s_1, s->s_2);
@@ -2505,8 +2547,8 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 				wi_n = fabsf(vdot(*wi, n));
 				{
 					float cos_hn = vdot(h, n);
-					s->pdf += blinn_pdf(cos_hn, cos_wo_h, m->exponent) * width[rc_index[1]];
-					glossy = (float)((double)(blinn_d(cos_hn, m->exponent) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
+					s->pdf += lobe_pdf(m, hs, cos_hn, cos_wo_h) * width[rc_index[1]];
+					glossy = (float)((double)(lobe_d(m, hs, cos_hn) * schlick_fresnel(cos_wo_h, dat->m_glossy)) / as_divisor(cos_wo_h, wo_n, wi_n));
 				}
 				scolor = cscale(m->gloss_color, glossy * kt);
 			}

@@ -68,7 +68,7 @@ typedef struct yor_material_desc
 	float light_color[3];
 	float light_power;
 	int32_t double_sided;
-	int32_t pad1;
+	int32_t anisotropic;      /* glossy / coated_glossy "anisotropic": the Ashikhmin-Shirley lobe with exp_u / exp_v (below) instead of Blinn */
 	/* glass "absorption" / "absorption_dist": a BeerVolumeHandler inside the material (material_glass.cc:371-398) */
 	float absorption[3];
 	int32_t has_absorption;
@@ -80,6 +80,7 @@ typedef struct yor_material_desc
 	int32_t sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int32_t pad2;
 	const struct yor_node_desc *nodes;
+	float exp_u, exp_v;       /* material_glossy.cc:464-472, material_coated_glossy.cc:529-537 */
 } yor_material_desc;
 
 /* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has

@@ -739,6 +739,30 @@ def test_coated_glossy_material(pipeline):
     compare_films(film, ofilm, "coated glossy")
 
 
+def test_anisotropic_glossy_lobe(pipeline):
+    """The Ashikhmin-Shirley lobe of glossy / coated_glossy (`anisotropic`, exp_u / exp_v; material_utils_microfacet.h:38-87) in a
+    path-traced box: MIS pairs, bounces and the coat's recursion all sample it.  Its sampling calls libm's tanf (double tan
+    narrowed on the device): the tolerance is north_star's, the ray counts must still agree."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(300, seed=41, res=(48, 40), sigma=0.07)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5,
+                            "anisotropic": True, "exp_u": 400.0, "exp_v": 12.0})
+    sc["materials"].append({"type": "glossy", "color": (1.0, 1.0, 1.0), "glossy_reflect": 0.9, "anisotropic": True, "exp_u": 8.0, "exp_v": 900.0})
+    sc["materials"].append({"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.6, "glossy_reflect": 0.5,
+                            "specular_reflect": 0.7, "IOR": 1.5, "anisotropic": True, "exp_u": 30.0, "exp_v": 250.0})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[0:2] = nm - 3; tm[4:6] = nm - 2                 # floor, back wall
+    free = np.arange(10, len(tm)); tm[free[0::3]] = nm - 1; tm[free[1::5]] = nm - 3
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(48, 40, 6, bounces=3, raydepth=2)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "anisotropic glossy")
+
+
 def test_xml_scene_with_every_feature(pipeline, tmp_path):
     """The C++ XML loader driven with everything the device path does — glass, mirror, coated glossy, mirror /
     transparent shinydiffuse, depth of field, recursion depth, transparent shadows, adaptive multi-pass AA with a
@@ -826,7 +850,8 @@ def _random_material(rng):
         return {"type": "shinydiffusemat", "color": col(), "diffuse_reflect": 0.6, "translucency": float(rng.uniform(0.2, 0.6)), "transmit_filter": float(rng.uniform(0.0, 1.0))}
     if kind == "glossy":
         return {"type": "glossy", "color": col(0.6), "diffuse_color": col(), "diffuse_reflect": float(rng.uniform(0.0, 0.6)), "glossy_reflect": float(rng.uniform(0.3, 0.9)),
-                "exponent": float(rng.uniform(5, 400)), "as_diffuse": True}
+                "exponent": float(rng.uniform(5, 400)), "as_diffuse": True,
+                **({"anisotropic": True, "exp_u": float(rng.uniform(2, 600)), "exp_v": float(rng.uniform(2, 600))} if rng.random() < 0.3 else {})}
     if kind == "coated":
         return {"type": "coated_glossy", "color": col(0.6), "diffuse_color": col(), "mirror_color": col(0.8), "diffuse_reflect": float(rng.uniform(0.0, 0.6)),
                 "glossy_reflect": float(rng.uniform(0.3, 0.9)), "exponent": float(rng.uniform(5, 400)), "specular_reflect": float(rng.uniform(0.3, 1.0)),

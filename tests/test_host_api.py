@@ -57,7 +57,7 @@ def test_factories_fail_loudly_outside_scope():
     yi.startScene(0)
     for kind, params, needle in [
         ("material", {"type": "rough_glass"}, "scope"), ("material", {"type": "coated_glossy", "as_diffuse": False}, "as_diffuse"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
-        ("material", {"type": "glossy", "anisotropic": True}, "anisotropic"),
+        ("material", {"type": "glossy", "as_diffuse": False}, "as_diffuse"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),

@@ -261,6 +261,11 @@ MATERIALS = {
     "gl1": {"type": "glossy", "color": (1, 1, 1), "glossy_reflect": 0.8, "exponent": 500.0, "as_diffuse": True},
     "gl2": {"type": "glossy", "color": (0.9, 0.9, 0.9), "diffuse_color": (0.6, 0.2, 0.2), "diffuse_reflect": 0.7,
             "glossy_reflect": 0.3, "exponent": 20.0, "diffuse_brdf": "Oren-Nayar", "sigma": 0.25},
+    "gl3": {"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5,
+            "anisotropic": True, "exp_u": 400.0, "exp_v": 12.0},
+    "gl4": {"type": "glossy", "color": (1, 1, 1), "glossy_reflect": 0.9, "anisotropic": True, "exp_u": 8.0, "exp_v": 900.0},
+    "cg3": {"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.6, "glossy_reflect": 0.5,
+            "specular_reflect": 0.7, "IOR": 1.5, "as_diffuse": True, "anisotropic": True, "exp_u": 30.0, "exp_v": 250.0},
 }
 
 

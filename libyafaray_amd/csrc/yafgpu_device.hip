@@ -1185,6 +1185,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	}
 	auto *s = new yafgpu_scene();
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
+	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].anisotropic) s->has_aniso = true;
 	{	// material types some triangle actually uses (a definition nothing refers to does not cost a kernel variant)
 		std::vector<char> used((size_t)d->n_materials, 0);
 		for(int i = 0; i < d->n_tris; ++i) used[(size_t)d->tri_mat[i]] = 1;
@@ -1301,7 +1302,6 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			if(m.n_nodes < 0 || m.n_nodes > kMaxNodes || m.node_first < 0 || m.node_first + m.n_nodes > d->n_nodes)
 			{ yafgpu_scene_destroy(s); return fail(-24, "a material's shader nodes: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
 			if(m.n_nodes > 0) s->has_textures = true;
-			if(m.anisotropic) s->has_aniso = true;
 		}
 		for(int i = 0; i < d->n_nodes; ++i)
 		{

@@ -462,7 +462,6 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	p.getColor("color", col); p.getColor("diffuse_color", dcol); p.get("diffuse_reflect", diff); p.get("glossy_reflect", refl);
 	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
-	if(!as_diff) return fail(yi, "glossy: as_diffuse = false needs recursiveRaytrace's glossy branch (integrator_montecarlo.cc:861-972), which the GPU path does not implement");
 	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
 	{ int add_depth = 0; p.get("additionaldepth", add_depth); if(add_depth != 0) return fail(yi, "glossy: additionaldepth is not supported by the GPU path"); }
 	if(!yi->eparams.empty()) return fail(yi, "glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
@@ -513,7 +512,6 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso); p.get("IOR", ior);
 	p.getColor("mirror_color", mcol); p.get("specular_reflect", mirror);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire);
-	if(!as_diff) return fail(yi, "coated_glossy: as_diffuse = false needs recursiveRaytrace's glossy branch, which the GPU path does not implement");
 	if(wire != 0.f) return fail(yi, "coated_glossy: wireframe shading is not supported by the GPU path");
 	if(add_depth != 0) return fail(yi, "coated_glossy: additionaldepth is not supported by the GPU path");
 	if(!yi->eparams.empty()) return fail(yi, "coated_glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
@@ -521,7 +519,7 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	std::memset(&m, 0, sizeof m);
 	m.type = YAFGPU_MAT_COATED_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; m.mirror_color[k] = mcol[k]; }
-	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = 1;
+	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
 	if(aniso)
 	{	// material_coated_glossy.cc:529-537
 		float e_u = 50.f, e_v = 50.f;
@@ -529,7 +527,7 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 		m.anisotropic = 1; m.exp_u = e_u; m.exp_v = e_v;
 	}
 	m.c_flags[0] = 0x1u | 0x10u;                                    // Specular | Reflect
-	m.c_flags[1] = 0x4u | 0x10u;                                    // as_diffuse: Diffuse | Reflect
+	m.c_flags[1] = as_diff ? (0x4u | 0x10u) : (0x2u | 0x10u);         // :55: as_diffuse ? Diffuse | Reflect : Glossy | Reflect (recursiveRaytrace's glossy branch then samples it)
 	if(diff > 0.f) { m.c_flags[2] = 0x4u | 0x10u; m.with_diffuse = 1; m.n_bsdf = 3; }
 	else { m.c_flags[2] = 0u; m.n_bsdf = 2; }
 	m.bsdf_flags = m.c_flags[0] | m.c_flags[1] | m.c_flags[2];

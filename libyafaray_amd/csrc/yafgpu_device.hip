@@ -1090,6 +1090,7 @@ struct yafgpu_scene
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
+	bool has_glossy = false;             // some material has a glossy lobe that recursiveRaytrace samples (glossy / coated_glossy with as_diffuse off): 12-record frames
 	bool has_aniso = false;              // some material has the anisotropic glossy lobe: the general shading kernel
 	bool has_textures = false;           // some material in use has shader nodes: the general shading kernel, texture coordinates parked per path
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
@@ -1178,14 +1179,17 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if(d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(-3, "triangle material index out of range");
 	for(int i = 0; i < d->n_materials; ++i)
 	{
-		// recursiveRaytrace (integrator_montecarlo.cc:782-1028): the perfect specular branch is on the device path (shinydiffuse's
-		// mirror and transparency); its glossy and dispersive branches are not (row N3)
-		if(d->materials[i].bsdf_flags & (kGlossy | kDispersive))
-			return fail(-4, "material with glossy-recursive / dispersive lobes needs recursiveRaytrace branches the GPU path does not implement");
+		// recursiveRaytrace (integrator_montecarlo.cc:782-1028): the perfect specular branch and the glossy branch for materials
+		// that reflect only are on the device path; the dispersive branch and the reflect + transmit glossy case (rough glass) are not
+		if(d->materials[i].bsdf_flags & kDispersive)
+			return fail(-4, "material with a dispersive lobe needs recursiveRaytrace's dispersive branch, which the GPU path does not implement");
+		if((d->materials[i].bsdf_flags & kGlossy) && (d->materials[i].bsdf_flags & kTransmit))
+			return fail(-4, "material with a glossy transmission lobe (rough glass) needs the reflect + transmit case of recursiveRaytrace's glossy branch, which the GPU path does not implement");
 	}
 	auto *s = new yafgpu_scene();
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].anisotropic) s->has_aniso = true;
+	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & kGlossy) s->has_glossy = true;
 	{	// material types some triangle actually uses (a definition nothing refers to does not cost a kernel variant)
 		std::vector<char> used((size_t)d->n_materials, 0);
 		for(int i = 0; i < d->n_tris; ++i) used[(size_t)d->tri_mat[i]] = 1;
@@ -1562,7 +1566,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	uint32_t max_paths = kWfMaxPaths;
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
-	const int frames = (s->has_specular && rp.raydepth > 0) ? rp.raydepth : 0;
+	const int frames = ((s->has_specular || s->has_glossy) && rp.raydepth > 0) ? rp.raydepth : 0;
+	const int frame_recs = s->has_glossy ? 12 : 5;
 	if(frames > 7) return fail(-17, "raydepth > 7 with mirror / transparent materials: the device path keeps at most 7 recursion frames per sample");
 	// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
 	// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
@@ -1601,7 +1606,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	for(const Chunk &ch : chunks) cap_pixels = std::max(cap_pixels, ch.n_pixels);
 	if((uint64_t)cap_pixels * spp > (1ull << 27)) return fail(-23, "one tile's samples exceed the 2^27 paths a wavefront chunk can hold: reduce tile_size or the samples per pass");
 	const uint32_t cap = cap_pixels * spp;
-	if(cap > s->wf_cap || frames > s->wf_frames)
+	if(cap > s->wf_cap || frames * frame_recs > s->wf_frames)
 	{
 		HIP_OK(hipStreamSynchronize(stream));
 		if(s->wf_state) (void)hipFree(s->wf_state);
@@ -1610,8 +1615,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 		if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
 		s->wf_state = nullptr; s->wf_results = nullptr; s->wf_queues = nullptr; s->wf_verdict = nullptr; s->wf_pix_xy = nullptr; s->wf_cap = 0;
-		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)(kWfRecs + 5 * frames) * cap * sizeof(float4)));
-		s->wf_frames = frames;
+		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)(kWfRecs + frame_recs * frames) * cap * sizeof(float4)));
+		s->wf_frames = frames * frame_recs;      // frame records allocated per path
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
 		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
 		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
@@ -1745,7 +1750,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(s->aborted()) return fail(-30, "aborted");
 		WfArgs a{};
 		a.ra = ra;
-		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results; a.frames = frames;
+		a.state = s->wf_state; a.cap = s->wf_cap; a.results = s->wf_results; a.frames = frames; a.frame_recs = frame_recs; a.has_glossy = s->has_glossy ? 1 : 0;
 		a.pixel_begin = ch.pixel_begin; a.n_pixels = ch.n_pixels; a.n_paths = a.n_pixels * spp;
 		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy; a.pix_listed = masked ? 1 : 0;
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -1768,7 +1773,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
 			if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
 			int cur = 0;
-			const int iter_cap = n_iters * (frames > 0 ? (1 << (frames + 1)) : 1);
+			const int iter_cap = n_iters * (frames > 0 ? (1 << (frames + 1)) : 1) * (s->has_glossy ? 16 : 1);      // (a safety net: the loop ends when the queues are empty)
 			for(int it = 0; it < iter_cap; ++it)
 			{
 				if(frames > 0 && it >= n_iters)
@@ -1943,7 +1948,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
 		// transpShad changes which hits occlude even without a transparent material (intersectTs skips hits before tmin_)
 		if(rp->transp_shad) return fail(-15, "the one-kernel pipeline has no transparent shadows (transpShad); use the wavefront pipeline");
-		if(s->has_specular && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent materials");
+		if((s->has_specular || s->has_glossy) && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent / glossy-recursive materials");
 		if(s->has_textures) return fail(-15, "the one-kernel pipeline has no shader nodes / textures; use the wavefront pipeline");
 		if(rp->serial_replay && rp->integrator == YAFGPU_INTEGRATOR_PATH && (rp->bounces - 1 > rp->rr_min_bounces || s->n_lights > 1))
 			return fail(-15, "the one-kernel pipeline cannot replay the reference's serial state (Russian roulette stream, light counter); use the wavefront pipeline or switch the replay off");

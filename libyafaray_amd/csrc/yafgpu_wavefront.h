@@ -29,6 +29,7 @@ struct WfArgs
 	uint32_t n_paths, pixel_begin, n_pixels;
 	const uint32_t *pix_prefix;       // n_tiles+1 prefix sums of pixels per tile of this shard
 	int frames;                       // levels of recursiveRaytrace frames behind the kWfRecs records (0: none allocated)
+	int frame_recs, has_glossy;       // records per frame: 5, or 12 when a material has a glossy lobe recursiveRaytrace samples (its loop state)
 	int pix_listed;                   // the chunk's pixels are given by pix_xy (a resample mask picked them), not by the tile list
 	uint32_t *pix_xy;                 // px | py << 16 per pixel of the chunk: written by wf_generate, so that resuming a path
 	                                  // costs one load instead of a binary search over the tile prefix (9 dependent loads)
@@ -82,9 +83,15 @@ YG_DEV void make_sp(V3 p, V3 n, V3 ng, int mat, SurfPt &sp) { sp.p = p; sp.n = n
 
 // The (s_1, s_2) of light sample `is`: doLightEstimation restarts Halton(2)/Halton(3) at offs-1 for both
 // halves of the MIS pair (integrator_montecarlo.cc:164-165,285-286), so the pair shares them.
-YG_DEV void dl_samples(const RenderArgs &ra, const yafgpu_light &light, int li, int is, uint32_t pixel_sample, uint32_t sampling_offs, float &s_1, float &s_2)
+YG_DEV int dl_area_samples(const RenderArgs &ra, const yafgpu_light &light, int division)      // integrator_montecarlo.cc:153-154
 {
-	const int n = (int)ceilf((float)light.samples * ra.rp.aa_light_sample_multiplier);
+	int n = (int)ceilf((float)light.samples * ra.rp.aa_light_sample_multiplier);
+	if(division > 1) n = max(1, n / division);
+	return n;
+}
+YG_DEV void dl_samples(const RenderArgs &ra, const yafgpu_light &light, int li, int is, int division, uint32_t pixel_sample, uint32_t sampling_offs, float &s_1, float &s_2)
+{
+	const int n = dl_area_samples(ra, light, division);
 	const uint32_t offs = (uint32_t)n * pixel_sample + sampling_offs + (uint32_t)li * 4567u;
 	Halton hal_2, hal_3;
 	hal_2.init(2u); hal_3.init(3u);
@@ -214,7 +221,8 @@ YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 }
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
 
-enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECURSE, W_RETURN, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW };
+enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECURSE, W_RETURN, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW,
+       W_GLOSSY_NEXT, W_RECURSE_SPEC };
 
 // register-resident copies of records 11, 12, 14, 18 (and, with YAFGPU_HOT_ACC, the accumulators 15..17) during
 // one advance (see wf_advance); the other records of the 11..18 range go straight to memory
@@ -271,11 +279,27 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 #define HGET(k) hot_get<k>(a, slot, h)
 #define HSET(k, v) hot_set<k>(a, slot, h, (v))
 
-#define FREC(L, j) wf_rec(a, kWfRecs + 5 * (L) + (j), slot)      // recursion frames, see st_recurse
+#define FREC(L, j) wf_rec(a, kWfRecs + a.frame_recs * (L) + (j), slot)      // recursion frames, see st_recurse
 // recursiveRaytrace (frames, absorption): a kernel built with 0 serves scenes without specular / filter materials
 #ifndef YAFGPU_FEAT_RECURSE
 #define YAFGPU_FEAT_RECURSE 1
 #endif
+// Trajectory splitting (RenderState::ray_division_ / ray_offset_ / dc_1_ / dc_2_, scene.h:88-91): set by recursiveRaytrace's
+// glossy branch for the integrate() calls below it, read by the light, path and glossy samplers of that level.  The level
+// above keeps it in its frame (record 5); level 0 and scenes without such materials have (1, 0, 0, 0).
+struct DivState { int division, offset; float dc_1, dc_2; };
+YG_DEV DivState wf_div(const WfArgs &a, uint32_t slot, int level)
+{
+	DivState d; d.division = 1; d.offset = 0; d.dc_1 = 0.f; d.dc_2 = 0.f;
+	if(YAFGPU_FEAT_RECURSE && a.has_glossy && level > 0)
+	{
+		const float4 f = FREC(level - 1, 5);
+		d.division = (int)ubits(f.x); d.offset = (int)ubits(f.y); d.dc_1 = f.z; d.dc_2 = f.w;
+	}
+	return d;
+}
+YG_DEV float add_mod_1(float x, float y) { const float t = x + y; return t > 1 ? t - 1.f : t; }      // util_sample.h:183-187
+
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
 YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal, const float4 ans)
 {
@@ -417,9 +441,10 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict
 // The loops are cut in two steps.  st_dl_next is the bookkeeping: it closes every light whose samples are all in
 // and says whether a candidate pair has to be evaluated next (W_DL_EVAL).  st_dl_eval evaluates that pair — the
 // widest step of the path program (81 VGPRs).
-YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h)
+YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h, int level)
 {
-	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
+	const int division = wf_div(a, slot, level).division;
 	const uint32_t w = ubits(HGET(14).w);
 	int li = (int)(w & 0xffu), is = (int)(w >> 20);
 	const int l_end = (int)((w >> 8) & 0xffu);
@@ -427,7 +452,7 @@ YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h)
 	{
 		const yafgpu_light &light = sc.lights[li];
 		const bool dirac = light.type == YAFGPU_LIGHT_POINT;
-		const int n = dirac ? 1 : (int)ceilf((float)light.samples * rp.aa_light_sample_multiplier);
+		const int n = dirac ? 1 : dl_area_samples(ra, light, division);
 		if(is < n)
 		{
 			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is))));
@@ -461,7 +486,7 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 	const bool dirac = light.type == YAFGPU_LIGHT_POINT;
 	const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
 	float s_1 = 0.f, s_2 = 0.f;
-	if(!dirac) dl_samples(ra, light, li, is, pixel_sample, sampling_offs, s_1, s_2);
+	if(!dirac) dl_samples(ra, light, li, is, wf_div(a, slot, c.level).division, pixel_sample, sampling_offs, s_1, s_2);
 	V3 d; float tmin, tmax; Col contrib;
 	int mask = 0;
 	Col pending_a = mkc(0.f, 0.f, 0.f);
@@ -607,7 +632,8 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	const int n_paths = rp.path_samples > 1 ? rp.path_samples : 1;
+	const DivState dv = wf_div(a, slot, c.level);
+	const int n_paths = max(1, rp.path_samples / dv.division);                                     // :182 n_samples
 	if(c.path_i >= n_paths) { c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
 	c.incl = 0;                                                                                   // :211 state.include_lights_ = false
 	const float4 p = REC(3);
@@ -620,6 +646,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	BsdfSample bs;
 	bs.s_1 = ri_vdc(offs, 0u);
 	bs.s_2 = (float)scr_halton(sc, 2, offs);
+	if(dv.division > 1) { bs.s_1 = add_mod_1(bs.s_1, dv.dc_1); bs.s_2 = add_mod_1(bs.s_2, dv.dc_2); }   // :201-205
 	bs.pdf = 0.f; bs.sampled = kNone;
 	bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
 	const float4 r6 = REC(6);
@@ -648,10 +675,11 @@ YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
 	REC(0) = f4(p, a.ra.ray_min_dist); REC(1) = f4(dir, -1.f);      // DiffRay(sp.p_, dir, scene_->ray_min_dist_)
 	c.stage = kStPrimary; c.depth = 0; c.path_i = 0; c.dl_on_sp0 = 0;
 }
-YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
+// recursiveRaytrace's perfect specular branch (:971-1025) at level c.level, whose working records hold the level's hit
+YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 {
-	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp; (void)sc;
-	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp; (void)sc; (void)rp;
+	if(!YAFGPU_FEAT_RECURSE) return W_RETURN;
 	const float4 r5 = REC(5);
 	if(!(ubits(r5.w) & (kSpecular | kFilter))) return W_RETURN;
 	const float4 p = REC(3);
@@ -666,6 +694,11 @@ YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 	if(!refl && !refr) return W_RETURN;
 	const float m_alpha = mat_alpha(m, dat0, sp0, wo0);
 	const int L = c.level;
+	if(a.has_glossy)
+	{	// the rays below keep this level's trajectory-splitting state
+		const DivState dv = wf_div(a, slot, L);
+		FREC(L, 5) = make_float4(fbits((uint32_t)dv.division), fbits((uint32_t)dv.offset), dv.dc_1, dv.dc_2);
+	}
 	FREC(L, 0) = f4(c.col, REC(19).w);
 	FREC(L, 1) = f4(c_refr, m_alpha);
 	// :991, :1016 vol = material->getVolumeHandler(sp.ng_ * ref_ray.dir_ < 0): flags 4 / 8 = the reflected / transmitted ray
@@ -680,6 +713,70 @@ YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 	c.level = L + 1;
 	return W_PARK_CLOSEST;
 }
+// recursiveRaytrace's glossy branch (:861-972) for materials that reflect only (:897-918): gsam trajectories through the glossy
+// lobe, each a full integrate() one level down under the trajectory-splitting state of frame record 5.  The loop lives in the
+// frame (flag 16 in F2.w): F6 normal | ns, gsam   F7 geometric normal | bsdf flags   F8 wo | integrate()'s w   F9 gcol | material
+// F10 the sample's colour | weight   F11 texture coordinates of the hit (tri, bu, bv)
+YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const int L = c.level;
+	const float4 r3 = REC(3), r5 = REC(5);
+	const DivState dv = wf_div(a, slot, L);
+	const int gsam = dv.division > 1 ? max(1, 8 / dv.division) : 8;
+	FREC(L, 0) = f4(c.col, REC(19).w);
+	FREC(L, 2) = f4(v3(r3), fbits(16u));
+	FREC(L, 6) = f4(v3(REC(4)), fbits((uint32_t)gsam << 8));
+	FREC(L, 7) = r5;
+	FREC(L, 8) = REC(6);
+	FREC(L, 9) = make_float4(0.f, 0.f, 0.f, r3.w);
+	if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) FREC(L, 11) = REC(22);
+	return W_GLOSSY_NEXT;
+}
+YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
+	const int L = c.level;
+	const float4 f2 = FREC(L, 2), f6 = FREC(L, 6), f7 = FREC(L, 7);
+	const int ns = (int)(ubits(f6.w) & 0xffu), gsam = (int)(ubits(f6.w) >> 8);
+	SurfPt sp0; make_sp(v3(f2), v3(f6), v3(f7), (int)ubits(FREC(L, 9).w), sp0);
+	const V3 wo0 = v3(FREC(L, 8));
+	yafgpu_material m_tmp;
+	const yafgpu_material *mp = &sc.mats[sp0.mat];
+#if YAFGPU_FEAT_TEXTURE
+	if(sc.tex.nodes != nullptr) { const float4 t = FREC(L, 11); mp = &wf_mat_hit(sc, sp0, (int)ubits(t.x), t.y, t.z, m_tmp); }
+#endif
+	(void)m_tmp;
+	BsdfDat dat0; mat_init_bsdf(*mp, dat0);
+	const DivState old = wf_div(a, slot, L);
+	const int division = old.division * gsam;
+	const int branch = division * old.offset + ns;
+	const float dc_1 = (float)scr_halton(sc, 2 * (L + 1) + 1, (uint32_t)branch + sampling_offs);           // :886-887
+	const float dc_2 = (float)scr_halton(sc, 2 * (L + 1) + 2, (uint32_t)branch + sampling_offs);
+	FREC(L, 5) = make_float4(fbits((uint32_t)division), fbits((uint32_t)branch), dc_1, dc_2);
+	const uint32_t offs = (uint32_t)gsam * pixel_sample + sampling_offs;
+	Halton hal_2, hal_3;
+	hal_2.init(2u); hal_3.init(3u);
+	hal_2.set_start(offs); hal_3.set_start(offs);
+	float s_1 = 0.f, s_2 = 0.f;
+	for(int k = 0; k <= ns; ++k) { s_1 = hal_2.next(); s_2 = hal_3.next(); }      // the incremental sequence, replayed
+	BsdfSample bs; bs.s_1 = s_1; bs.s_2 = s_2; bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kGlossy | kReflect;
+	float w = 0.f;
+	V3 wi = mk(0.f, 0.f, 0.f);
+	const Col mcol = mat_sample(*mp, dat0, sp0, wo0, wi, bs, w);
+	FREC(L, 10) = f4(mcol, w);
+	c.incl = 1;                                                                       // :863
+	wf_start_level(a, slot, c, sp0.p, wi);
+	c.level = L + 1;
+	return W_PARK_CLOSEST;
+}
+// the level's own radiance is complete: recursiveRaytrace (:782-1028; the dispersive branch is refused on the host)
+YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
+{
+	const yafgpu_render_params &rp = a.ra.rp;
+	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
+	if(a.has_glossy && (ubits(REC(5).w) & kGlossy)) return st_glossy_begin(a, slot, c);
+	return W_RECURSE_SPEC;
+}
 // an integrate() ends with (c.col, alpha): hand it to the level above, which either sends its transmitted ray or ends too
 YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 {
@@ -693,6 +790,25 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 		const float4 f0 = FREC(P, 0), f2 = FREC(P, 2);
 		const uint32_t flags = ubits(f2.w);
 		Col integ = c.col;
+		if(flags & 16u)
+		{	// a trajectory of the glossy loop is back: gcol += integ * mcol * w (:918), then the next one or the loop's end (:958)
+			const float4 f9 = FREC(P, 9), f10 = FREC(P, 10), f6 = FREC(P, 6);
+			const Col gcol = c3(f9) + (integ * c3(f10)) * f10.w;
+			const int ns = (int)(ubits(f6.w) & 0xffu) + 1, gsam = (int)(ubits(f6.w) >> 8);
+			c.level = P;
+			if(ns < gsam)
+			{
+				FREC(P, 9) = f4(gcol, f9.w);
+				FREC(P, 6) = f4(v3(f6), fbits((uint32_t)ns | ((uint32_t)gsam << 8)));
+				return W_GLOSSY_NEXT;
+			}
+			c.col = c3(f0) + gcol * (1.f / (float)gsam);
+			// the level's hit again, for the specular branch that follows
+			REC(3) = f4(v3(f2), f9.w); REC(4) = f4(v3(f6), 0.f); REC(5) = FREC(P, 7); REC(6) = FREC(P, 8);
+			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) REC(22) = FREC(P, 11);
+			REC(19) = make_float4(0.f, 0.f, 0.f, f0.w);
+			return W_RECURSE_SPEC;
+		}
 		if(flags & ((flags & 2u) ? 8u : 4u))
 		{	// the ray ran inside absorbing glass: integ *= vcol (:991-994, :1016-1019)
 			const yafgpu_material &pm = a.ra.sc.mats[ubits(FREC(P, 4).w)];
@@ -747,14 +863,26 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
 	while(where == W_DL_NEXT || where == W_DL_EVAL)
 	{
-		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h);
+		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
 		else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
 	}
 	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
 	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs);
 	if(where == W_RECURSE) where = st_recurse(a, slot, c);
+#if YAFGPU_FEAT_RECURSE
+	// recursion: return -> (next glossy trajectory | the specular branch of the level above) -> park or return again
+	for(;;)
+	{
+		if(where == W_GLOSSY_NEXT) where = st_glossy_next(a, slot, c, pixel_sample, sampling_offs);
+		if(where == W_RECURSE_SPEC) where = st_recurse_spec(a, slot, c);
+		if(where != W_RETURN) break;
+		where = st_return(a, slot, c);
+		if(where != W_GLOSSY_NEXT && where != W_RECURSE_SPEC) break;
+	}
+#else
 	if(where == W_RETURN) where = st_return(a, slot, c);
+#endif
 	if(where != W_FINISH) hot_flush(a, slot, h);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
@@ -781,7 +909,7 @@ __global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArg
 	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
 PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot]))
 PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))
-PROBE(probe_dl_next, st_dl_next(a, slot, h))
+PROBE(probe_dl_next, st_dl_next(a, slot, h, c.level))
 PROBE(probe_dl_eval, st_dl_eval(a, slot, h, c, slot * 3u, slot * 5u, m))
 PROBE(probe_dl_done, st_dl_done(a, slot, h, c))
 PROBE(probe_extend, st_extend(a, slot, h, c))

@@ -2935,7 +2935,10 @@ typedef struct
 	mwc_t *prng;
 	unsigned correlative_sample_number; /* integrator_tiled.h:91, per thread */
 	float light_mult;                   /* aa_light_sample_multiplier_ of the current pass (integrator_tiled.cc:139,215) */
+	/* trajectory splitting (scene.h:88-91): set by recursiveRaytrace's glossy branch, read by every sampler below it */
+	int ray_division, ray_offset; float dc_1, dc_2;
 } rstate_t;
+static inline float add_mod_1(float a, float b) { float s = a + b; return s > 1 ? s - 1.f : s; } /* util_sample.h:183-187 */
 
 /* MonteCarloIntegrator::doLightEstimation, integrator_montecarlo.cc:78-345 (render passes disabled,
  * tr_shad_ false, volume integrator = identity) */
@@ -2973,6 +2976,7 @@ static rgb do_light_estimation(rstate_t *st, const light_t *light, const sp_t *s
 		halton_t hal_2, hal_3;
 		halton_init(&hal_2, 2); halton_init(&hal_3, 3);
 		int n = (int)ceilf((float)light->samples * st->light_mult);
+		if(st->ray_division > 1) { n = n / st->ray_division; if(n < 1) n = 1; }      /* :154 */
 		float inv_ns = 1.f / (float)n;
 		unsigned offs = (unsigned)n * st->pixel_sample + st->sampling_offs + l_offs;
 		rgb ccol = C(0, 0, 0);
@@ -3103,7 +3107,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		{
 			rgb path_col = C(0, 0, 0);
 			path_flags |= (BSDF_DIFFUSE | BSDF_REFLECT | BSDF_TRANSMIT);
-			int n_samples = rd->path_samples > 1 ? rd->path_samples : 1; /* max(1, n_paths_/ray_division_) */
+			int n_samples = rd->path_samples / st->ray_division; if(n_samples < 1) n_samples = 1; /* max(1, n_paths_ / ray_division_) :182 */
 			for(int i = 0; i < n_samples; ++i)
 			{
 				unsigned offs = (unsigned)rd->path_samples * st->pixel_sample + st->sampling_offs + (unsigned)i;
@@ -3115,6 +3119,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 				bsdf_dat dat_n;
 				float s_1 = yor_ri_vdc(offs, 0);
 				float s_2 = (float)yor_scr_halton(2, offs);
+				if(st->ray_division > 1) { s_1 = add_mod_1(s_1, st->dc_1); s_2 = add_mod_1(s_2, st->dc_2); }   /* :201-205 (the same lines in the bounce loop, :238-242, shift locals nothing reads) */
 				sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.flags = path_flags; sm.sampled_flags = BSDF_NONE;
 				scol = mat_sample(material, &dat0, &sp, pwo, &p_dir, &sm, &w);
 				scol = cscale(scol, w);
@@ -3167,6 +3172,47 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		}
 		/* recursiveRaytrace, integrator_montecarlo.cc:782-1028: the perfect specular branch (:971-1025); no dispersive
 		 * or glossy-recursive materials on this path, additional depth and transparent bias 0 */
+		/* the glossy branch, :861-972: gsam trajectories through the glossy lobe, each a full integrate() one level down with the
+		 * trajectory-splitting state set (materials here reflect only: the Reflect && !Transmit case, :897-918) */
+		if(raylevel + 1 <= rd->raydepth && (bsdfs & BSDF_GLOSSY) && raylevel + 1 < 20)
+		{
+			st->include_lights = 1;
+			int gsam = 8;
+			const int old_division = st->ray_division, old_offset = st->ray_offset;
+			const float old_dc_1 = st->dc_1, old_dc_2 = st->dc_2;
+			if(st->ray_division > 1) { gsam = gsam / old_division; if(gsam < 1) gsam = 1; }
+			st->ray_division *= gsam;
+			int branch = st->ray_division * old_offset;
+			unsigned offs = (unsigned)gsam * st->pixel_sample + st->sampling_offs;
+			float d_1 = 1.f / (float)gsam;
+			rgb gcol = C(0, 0, 0);
+			halton_t hal_2, hal_3;
+			halton_init(&hal_2, 2); halton_init(&hal_3, 3);
+			halton_set_start(&hal_2, offs);
+			halton_set_start(&hal_3, offs);
+			for(int ns = 0; ns < gsam; ++ns)
+			{
+				st->dc_1 = (float)yor_scr_halton(2 * (raylevel + 1) + 1, (unsigned)branch + st->sampling_offs);
+				st->dc_2 = (float)yor_scr_halton(2 * (raylevel + 1) + 2, (unsigned)branch + st->sampling_offs);
+				st->ray_offset = branch;
+				++offs; ++branch;
+				float s_1 = halton_next(&hal_2);
+				float s_2 = halton_next(&hal_3);
+				if((material->flags & BSDF_GLOSSY) && (material->flags & BSDF_REFLECT) && !(material->flags & BSDF_TRANSMIT))
+				{
+					float gw = 0.f; v3 wi = V(0, 0, 0);
+					sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.flags = BSDF_GLOSSY | BSDF_REFLECT; sm.sampled_flags = BSDF_NONE;
+					rgb mcol = mat_sample(material, &dat0, &sp, wo, &wi, &sm, &gw);
+					float integ[4], ref_tmax;
+					integrate(st, sp.p, wi, st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+					rgb ic = C(integ[0], integ[1], integ[2]);
+					if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, wi) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
+					gcol = cadd(gcol, cscale(cmul(ic, mcol), gw));
+				}
+			}
+			col = cadd(col, cscale(gcol, d_1));
+			st->ray_division = old_division; st->ray_offset = old_offset; st->dc_1 = old_dc_1; st->dc_2 = old_dc_2;
+		}
 		if(raylevel + 1 <= rd->raydepth && (bsdfs & (BSDF_SPECULAR | BSDF_FILTER)) && raylevel + 1 < 20)
 		{
 			st->include_lights = 1;
@@ -3432,6 +3478,7 @@ static void *worker_main(void *arg)
 	st.shadow_bias = rd->shadow_bias_auto ? (float)YAF_SHADOW_BIAS : rd->shadow_bias;   /* scene.cc:825 */
 	st.ray_min_dist = rd->min_raydist_auto ? (float)MIN_RAYDIST : rd->min_raydist;      /* scene.cc:826 */
 	st.light_mult = wk->light_mult;
+	st.ray_division = 1;                                                                /* RenderState(), scene.h:76 */
 	st.correlative_sample_number = wk->correlative_sample_number;
 	int n_tiles = wk->n_tiles_x * wk->n_tiles_y;
 	int shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
@@ -3615,7 +3662,7 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 	if(rd->aa_passes < 1) return -1;
 	if(rd->bounces > 12) return -2; /* scrHalton__ dims >= 50 are a racy LCG in the reference */
 	for(int i = 0; i < s->n_mats; ++i)
-		if(s->mats[i].flags & (BSDF_GLOSSY | BSDF_DISPERSIVE)) return -4; /* recursiveRaytrace: only the perfect specular branch is restated */
+		if(s->mats[i].flags & BSDF_DISPERSIVE) return -4; /* recursiveRaytrace: the dispersive branch is not restated */
 	if(rd->tile_size <= 0 || rd->width <= 0 || rd->height <= 0 || rd->aa_minsamples <= 0) return -5;
 	if(rd->aa_passes > 1 && rd->shard_count > 1) return -6; /* the noise detection needs the whole frame */
 	struct timespec t0, t1;

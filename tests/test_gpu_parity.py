@@ -763,6 +763,36 @@ def test_anisotropic_glossy_lobe(pipeline):
     compare_films(film, ofilm, "anisotropic glossy")
 
 
+@pytest.mark.parametrize("raydepth,integrator", [(1, "pathtracing"), (2, "pathtracing"), (3, "pathtracing"), (2, "directlighting")])
+def test_glossy_branch_of_recursive_raytrace(raydepth, integrator, pipeline):
+    """recursiveRaytrace's glossy branch (integrator_montecarlo.cc:861-972): glossy / coated_glossy with as_diffuse off are not
+    path-traced but followed by 8 trajectories through the glossy lobe, each a full integrate() one level down with the
+    trajectory-splitting state set — fewer light samples (:154) and path samples (:182), shifted first-segment samples (:201-205),
+    one trajectory per level below the first (:869).  Mirrors and glass in the scene nest the specular branch inside it and the
+    other way round."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(260, seed=43, res=(40, 32), sigma=0.08)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["lights"] = [dict(l, samples=4) for l in sc["lights"]]
+    sc["materials"].append({"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5,
+                            "exponent": 60.0, "as_diffuse": False})
+    sc["materials"].append({"type": "glossy", "color": (1.0, 0.9, 0.8), "glossy_reflect": 0.9, "as_diffuse": False, "anisotropic": True, "exp_u": 20.0, "exp_v": 300.0})
+    sc["materials"].append({"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.4, "glossy_reflect": 0.6,
+                            "exponent": 150.0, "specular_reflect": 0.7, "IOR": 1.5, "as_diffuse": False})
+    sc["materials"].append({"type": "mirror", "color": (0.9, 0.9, 0.9), "reflect": 0.9})
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[0:2] = nm - 5; tm[4:6] = nm - 3; tm[6:8] = nm - 2          # floor glossy, back wall coated, left wall mirror
+    free = np.arange(10, len(tm)); tm[free[0::4]] = nm - 4; tm[free[1::6]] = nm - 1; tm[free[2::7]] = nm - 5
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(40, 32, 3, bounces=2, raydepth=raydepth, path_samples=8, integrator=integrator)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"glossy branch raydepth {raydepth} {integrator}")
+
+
 def test_xml_scene_with_every_feature(pipeline, tmp_path):
     """The C++ XML loader driven with everything the device path does — glass, mirror, coated glossy, mirror /
     transparent shinydiffuse, depth of field, recursion depth, transparent shadows, adaptive multi-pass AA with a
@@ -850,12 +880,12 @@ def _random_material(rng):
         return {"type": "shinydiffusemat", "color": col(), "diffuse_reflect": 0.6, "translucency": float(rng.uniform(0.2, 0.6)), "transmit_filter": float(rng.uniform(0.0, 1.0))}
     if kind == "glossy":
         return {"type": "glossy", "color": col(0.6), "diffuse_color": col(), "diffuse_reflect": float(rng.uniform(0.0, 0.6)), "glossy_reflect": float(rng.uniform(0.3, 0.9)),
-                "exponent": float(rng.uniform(5, 400)), "as_diffuse": True,
+                "exponent": float(rng.uniform(5, 400)), "as_diffuse": bool(rng.random() < 0.6),
                 **({"anisotropic": True, "exp_u": float(rng.uniform(2, 600)), "exp_v": float(rng.uniform(2, 600))} if rng.random() < 0.3 else {})}
     if kind == "coated":
         return {"type": "coated_glossy", "color": col(0.6), "diffuse_color": col(), "mirror_color": col(0.8), "diffuse_reflect": float(rng.uniform(0.0, 0.6)),
                 "glossy_reflect": float(rng.uniform(0.3, 0.9)), "exponent": float(rng.uniform(5, 400)), "specular_reflect": float(rng.uniform(0.3, 1.0)),
-                "IOR": float(rng.uniform(1.1, 2.2))}
+                "IOR": float(rng.uniform(1.1, 2.2)), "as_diffuse": bool(rng.random() < 0.6)}
     if kind in ("glass", "glass_abs"):
         m = {"type": "glass", "IOR": float(rng.uniform(1.1, 2.2)), "filter_color": col(0.5), "transmit_filter": float(rng.uniform(0.0, 1.0)), "mirror_color": col(0.8),
              "fake_shadows": bool(rng.random() < 0.5)}

@@ -56,8 +56,7 @@ def test_factories_fail_loudly_outside_scope():
     yi = fresh()
     yi.startScene(0)
     for kind, params, needle in [
-        ("material", {"type": "rough_glass"}, "scope"), ("material", {"type": "coated_glossy", "as_diffuse": False}, "as_diffuse"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
-        ("material", {"type": "glossy", "as_diffuse": False}, "as_diffuse"),
+        ("material", {"type": "rough_glass"}, "scope"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),

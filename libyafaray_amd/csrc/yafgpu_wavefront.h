@@ -730,6 +730,7 @@ YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
 	FREC(L, 8) = REC(6);
 	FREC(L, 9) = make_float4(0.f, 0.f, 0.f, r3.w);
 	if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) FREC(L, 11) = REC(22);
+	c.incl = 1;            // :863 state.include_lights_ = true, once: a later trajectory starts with what the one before left (its path samples clear it, :211)
 	return W_GLOSSY_NEXT;
 }
 YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
@@ -764,7 +765,6 @@ YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel
 	V3 wi = mk(0.f, 0.f, 0.f);
 	const Col mcol = mat_sample(*mp, dat0, sp0, wo0, wi, bs, w);
 	FREC(L, 10) = f4(mcol, w);
-	c.incl = 1;                                                                       // :863
 	wf_start_level(a, slot, c, sp0.p, wi);
 	c.level = L + 1;
 	return W_PARK_CLOSEST;

@@ -66,7 +66,7 @@ struct DevScene
 	const int *faure;            // concatenated Faure permutations
 	const int *faure_off;        // [50] offsets into faure
 	const double *inv_prims;     // [50]
-	int n_lights, n_tris, n_mats;
+	int n_lights, n_tris, n_mats, n_faure;      // n_faure: ints in the concatenated Faure permutations
 	uint32_t n_nodes;
 	float blo[3], bhi[3];
 	yafgpu_camera cam;
@@ -1326,6 +1326,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if(d->tri_orco && (rc = upload(s, d->tri_orco, nt * 9, &dv.tex.tri_orco))) { yafgpu_scene_destroy(s); return rc; }
 	}
 	if((rc = upload(s, faure.data(), faure.size(), &dv.faure))) { yafgpu_scene_destroy(s); return rc; }
+	dv.n_faure = (int)faure.size();
 	if((rc = upload(s, foff.data(), foff.size(), &dv.faure_off))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, invp.data(), invp.size(), &dv.inv_prims))) { yafgpu_scene_destroy(s); return rc; }
 	dv.n_lights = d->n_lights; dv.n_tris = d->n_tris; dv.n_mats = d->n_materials; dv.n_nodes = (uint32_t)s->tree.nodes.size();

@@ -1041,6 +1041,9 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_FUSED
 #define YAFGPU_TRACE_FUSED 0
 #endif
+#ifndef YAFGPU_TRACE_BELOW_MASKS
+#define YAFGPU_TRACE_BELOW_MASKS 1
+#endif
 #ifndef YAFGPU_TRACE_WAVES
 #define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
 #endif
@@ -1227,7 +1230,12 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				const float tplane = (split - o) * oi.y;
 				// (o < split) || (o == split && d <= 0), kdtree_triangle.cc:725-760, without the short-circuit branches
 				const bool dn = ((dneg >> axis) & 1u) != 0u;
+#if YAFGPU_TRACE_BELOW_MASKS
+				// the same predicate as lane-mask logic: three compares, combined on the scalar unit (the kernel is VALU-bound)
+				const bool below = __builtin_amdgcn_inverse_ballot_w64(__ballot(o < split) | (__ballot(o == split) & __ballot(dn)));
+#else
 				const bool below = dn ? (o <= split) : (o < split);
+#endif
 				const uint32_t left = node + 1u, right = nd.y >> 2;
 				const uint32_t near_c = below ? left : right, far_c = below ? right : left;
 				if(kStats) { ++cn.interior; if(p_cur < p_end) ++spec; }
@@ -1384,12 +1392,25 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 #ifndef YAFGPU_SHADE_LDS_TABLES
 #define YAFGPU_SHADE_LDS_TABLES 1
 #endif
-constexpr int kShadeTabBytes = 16384;     // 3 blocks per CU at 3 waves per SIMD: 60 KB of the 160 KB
+constexpr int kShadeTabBytes = 16384;     // 3 blocks per CU at 3 waves per SIMD
+// ... and the Faure permutations: scrHalton__ looks one digit up per loop turn (13 dependent loads for a base-5 sample index
+// of 2^30), two to four calls per path segment
+#ifndef YAFGPU_SHADE_LDS_FAURE
+#define YAFGPU_SHADE_LDS_FAURE 1
+#endif
+constexpr int kShadeFaureBytes = YAFGPU_SHADE_LDS_FAURE ? 20480 : 0;      // 5117 ints for the 50 dimensions
 __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfArgs a_in)
 {
 #if YAFGPU_SHADE_LDS_TABLES
-	__shared__ uint4 s_tab[kShadeTabBytes / 16];
+	__shared__ uint4 s_tab[(kShadeTabBytes + kShadeFaureBytes) / 16];
 	WfArgs a = a_in;
+	if(YAFGPU_SHADE_LDS_FAURE && (uint32_t)a_in.ra.sc.n_faure * 4u <= (uint32_t)kShadeFaureBytes)
+	{
+		int *dst = (int *)s_tab + kShadeTabBytes / 4;
+		for(uint32_t w = threadIdx.x; w < (uint32_t)a_in.ra.sc.n_faure; w += blockDim.x) dst[w] = a_in.ra.sc.faure[w];
+		a.ra.sc.faure = dst;        // (the barrier below, or the one of the first queue round, orders the copy before any use)
+		__syncthreads();
+	}
 	{
 		const uint32_t mat_bytes = (uint32_t)a_in.ra.sc.n_mats * (uint32_t)sizeof(yafgpu_material);      // multiples of 8
 		const uint32_t light_off = (mat_bytes + 15u) & ~15u;

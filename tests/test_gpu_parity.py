@@ -793,6 +793,27 @@ def test_glossy_branch_of_recursive_raytrace(raydepth, integrator, pipeline):
     compare_films(film, ofilm, f"glossy branch raydepth {raydepth} {integrator}")
 
 
+def test_light_count_and_sample_count_limits(pipeline):
+    """The light-estimate bookkeeping packs the light index in 8 bits and the sample index in 12: 255 lights render and equal
+    the oracle, 256 are refused; an area light asking for more than 4095 samples per estimate is refused."""
+    if pipeline == "megakernel":
+        pytest.skip("limits are checked on the default pipeline")
+    sc = scenes.cornell_soup(120, seed=51, res=(24, 20), sigma=0.1)
+    rng = np.random.default_rng(7)
+    points = [{"type": "pointlight", "from": tuple(float(x) for x in rng.uniform(-0.8, 0.8, 3)), "color": (1.0, 0.9, 0.8), "power": 0.02} for _ in range(255)]
+    rd = scenes.render_settings(24, 20, 1, integrator="directlighting")
+    sc255 = dict(sc, lights=list(sc["lights"]) + points[:254])
+    film, st, ofilm, ost = render_both(sc255, rd)
+    assert st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "255 lights")
+    yi = Interface(strict=False)
+    scenes.load_scene(yi, dict(sc, lights=list(sc["lights"]) + points), rd)
+    assert not yi.render() and "255" in yi.getLastError(), yi.getLastError()
+    yi = Interface(strict=False)
+    scenes.load_scene(yi, dict(sc, lights=[dict(sc["lights"][0], samples=5000)]), rd)
+    assert not yi.render() and "4095" in yi.getLastError(), yi.getLastError()
+
+
 def test_xml_scene_with_every_feature(pipeline, tmp_path):
     """The C++ XML loader driven with everything the device path does — glass, mirror, coated glossy, mirror /
     transparent shinydiffuse, depth of field, recursion depth, transparent shadows, adaptive multi-pass AA with a

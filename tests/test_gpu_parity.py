@@ -929,7 +929,7 @@ def _push_to_extremes(m, rng):
     return m
 
 
-def _feature_mix(seed):
+def _feature_mix(seed, textures=True):
     rng = np.random.default_rng(1000 + seed)
     w, h = int(rng.integers(36, 60)), int(rng.integers(28, 48))
     # bounce vertices of the path tracer pick ONE light through a counter that is serial state in the reference
@@ -1021,8 +1021,91 @@ def _feature_mix(seed):
         cw, ch = int(rng.integers(8, w - 4)), int(rng.integers(8, h - 4))
         kw.update(xstart=int(rng.integers(0, w - cw)), ystart=int(rng.integers(0, h - ch)))
         w, h = cw, ch
+    if textures and rng.random() < 0.4:
+        _texturize(sc, rng)
     rd = scenes.render_settings(w, h, spp, **kw)
     return sc, rd, w, h, base, kw
+
+
+def _texturize(sc, rng):
+    """image textures and shader-node graphs on the scene's shinydiffuse materials: random textures, texture
+    coordinates on every triangle, a random graph on a random subset of the slots the material's lobes make meaningful"""
+    n = np.asarray(sc["verts"]).reshape(-1, 3, 3).shape[0]
+    sc["uv"] = rng.uniform(-0.5, 2.5, (n, 3, 2)).astype(np.float32)
+    if rng.random() < 0.7:
+        sc["orco"] = (np.asarray(sc["verts"], np.float32).reshape(-1, 3, 3) * 0.8 + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32)
+    img = lambda: rng.uniform(0, 1, (int(rng.integers(2, 12)), int(rng.integers(2, 12)), 4)).astype(np.float32)
+    sc["textures"] = []
+    for k in range(int(rng.integers(1, 4))):
+        t = dict(name=f"t{k}", texels=img(), interpolate=str(rng.choice(["bilinear", "none"])), clipping=str(rng.choice(["repeat", "extend", "clip", "clipcube", "checker"])),
+                 color_space=str(rng.choice(["sRGB", "LinearRGB", "Raw_Manual_Gamma", "XYZ"])), gamma=float(rng.uniform(1.0, 2.4)))
+        if rng.random() < 0.4:
+            t.update(xrepeat=int(rng.integers(1, 4)), yrepeat=int(rng.integers(1, 4)), mirror_x=bool(rng.random() < 0.5), mirror_y=bool(rng.random() < 0.5))
+        if rng.random() < 0.3:
+            t.update(rot90=bool(rng.random() < 0.5), cropmin_x=float(rng.uniform(0, 0.3)), cropmax_x=float(rng.uniform(0.6, 1.0)), cropmin_y=float(rng.uniform(0, 0.3)))
+        if rng.random() < 0.3:
+            t.update(adj_intensity=float(rng.uniform(0.5, 1.5)), adj_contrast=float(rng.uniform(0.5, 1.5)), adj_saturation=float(rng.uniform(0.0, 2.0)),
+                     adj_hue=float(rng.uniform(-90, 90)), adj_clamp=bool(rng.random() < 0.5))
+        if t["clipping"] == "checker":
+            t.update(even_tiles=bool(rng.random() < 0.5), odd_tiles=bool(rng.random() < 0.7), checker_dist=float(rng.uniform(0.0, 0.4)))
+        sc["textures"].append(t)
+    tex = lambda: str(rng.choice([t["name"] for t in sc["textures"]]))
+    texcos = ["uv", "global", "orco", "transformed", "window", "normal"]
+    for m in sc["materials"]:
+        if m.get("type", "shinydiffusemat") != "shinydiffusemat" or rng.random() < 0.4:
+            continue
+        nodes, k = [], [0]
+        def mapper():
+            k[0] += 1
+            nd = dict(name=f"map{k[0]}", type="texture_mapper", texture=tex(), texco=str(rng.choice(texcos)), mapping=str(rng.choice(["plain", "cube", "tube", "sphere"])),
+                      scale=tuple(float(x) for x in rng.uniform(0.5, 3.0, 3)), offset=tuple(float(x) for x in rng.uniform(-0.5, 0.5, 3)))
+            if nd["texco"] == "transformed":
+                mtx = np.eye(4, dtype=np.float32); mtx[:3, :] = rng.uniform(-1, 1, (3, 4)); nd["transform"] = mtx
+            nodes.append(nd)
+            return nd["name"]
+        def layer(scalar, upper):
+            k[0] += 1
+            nd = dict(name=f"lay{k[0]}", type="layer", input=mapper(), mode=int(rng.integers(0, 9)), colfac=float(rng.uniform(0.3, 1.0)), valfac=float(rng.uniform(0.3, 1.0)),
+                      def_col=tuple(float(x) for x in rng.uniform(0, 1, 3)) + (1.0,), def_val=float(rng.uniform(0, 1)), do_color=not scalar, do_scalar=scalar,
+                      color_input=bool(rng.random() < 0.8), noRGB=bool(rng.random() < 0.2), stencil=bool(rng.random() < 0.2), negative=bool(rng.random() < 0.2),
+                      use_alpha=bool(rng.random() < 0.2), upper_color=tuple(float(x) for x in rng.uniform(0, 1, 3)) + (1.0,), upper_value=float(upper))
+            nodes.append(nd)
+            if rng.random() < 0.3:          # a second layer stacked on the first
+                k[0] += 1
+                top = dict(nd, name=f"lay{k[0]}", input=mapper(), upper_layer=nd["name"], mode=int(rng.integers(0, 9)))
+                top.pop("upper_color"); top.pop("upper_value")
+                nodes.append(top)
+                return top["name"]
+            return nd["name"]
+        if rng.random() < 0.8:
+            if rng.random() < 0.2:
+                k[0] += 1
+                val = f"val{k[0]}"
+                nodes.append(dict(name=val, type="value", color=tuple(float(x) for x in rng.uniform(0, 1, 3)), alpha=1.0, scalar=float(rng.uniform(0, 1))))
+                mix = dict(name=f"mix{k[0]}", type="mix", mode=int(rng.integers(0, 10)), input1=mapper(), input2=val, value=float(rng.uniform(0, 1)))
+                nodes.append(mix)
+                m["diffuse_shader"] = mix["name"]
+            else:
+                m["diffuse_shader"] = layer(False, 0.0)
+        if m.get("specular_reflect", 0.0) > 0 and rng.random() < 0.6:
+            m["mirror_shader"] = layer(True, m["specular_reflect"])
+            if rng.random() < 0.5:
+                m["mirror_color_shader"] = layer(False, 0.0)
+            if m.get("fresnel_effect") and rng.random() < 0.5:
+                m["IOR_shader"] = layer(True, 0.0)
+        if m.get("transparency", 0.0) > 0 and rng.random() < 0.6:
+            m["transparency_shader"] = layer(True, m["transparency"])
+        if m.get("translucency", 0.0) > 0 and rng.random() < 0.6:
+            m["translucency_shader"] = layer(True, m["translucency"])
+        if m.get("diffuse_brdf") == "oren_nayar" and rng.random() < 0.6:
+            m["sigma_oren_shader"] = layer(True, m.get("sigma", 0.1))
+        if rng.random() < 0.3:
+            m["diffuse_refl_shader"] = layer(True, m.get("diffuse_reflect", 1.0))
+        if nodes and len(nodes) <= 16:
+            m["nodes"] = nodes
+        else:
+            for key in [key for key in m if key.endswith("_shader")]:
+                m.pop(key)
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_FUZZ_FIRST", "0")), int(__import__("os").environ.get("YAFGPU_FUZZ_SEEDS", "16")))))
@@ -1050,7 +1133,7 @@ def test_random_feature_mixes_through_the_xml_loader(seed, pipeline, tmp_path):
     if pipeline == "megakernel":
         pytest.skip("the one-kernel pipeline renders the single-pass pinhole diffuse subset only")
     from tests import xml_writer
-    sc, rd, w, h, base, kw = _feature_mix(seed)
+    sc, rd, w, h, base, kw = _feature_mix(seed, textures=False)      # (texels in memory have no place in a scene file)
     sc = dict(sc, vnormals=None)                     # the writer emits positions and faces only
     path = str(tmp_path / f"mix{seed}.xml")
     xml_writer.write(path, sc, rd)

@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the film reduce goes through gloo "
                          "(host staging). Exercises sharding + reduce + combine with the real kernels; not a measurement.")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="debug: render shard 0 of K on this one GPU (what one rank of a K-GPU run does per pass); not a measurement of K GPUs")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +182,8 @@ def main():
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.setShard(rank, world)            # pixel-tile sharding: tile t -> rank t % world
+    if args.emulate_shard > 1 and world == 1:
+        yi.setShard(0, args.emulate_shard)
     t0 = time.time()
     yi.prepareRender()                  # Scene::update: kd-tree build + upload (untimed, reported)
     setup_s = time.time() - t0

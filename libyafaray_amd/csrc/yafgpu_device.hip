@@ -1722,7 +1722,11 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	const int iters_record = 1 + (path ? std::max(1, rp.path_samples) * std::max(1, rp.bounces) : 0);
 	// opt-in (YAFGPU_OVERLAP=1): +2-4 % on the bench scenes, but per-kernel durations then overlap in a profiler trace, so
 	// the default keeps one kernel on the GPU at a time and the roofline numbers comparable with rocprofv3's
-	const bool overlap = std::getenv("YAFGPU_OVERLAP") != nullptr;
+	// ... except for small chunks (a tile shard of a multi-GPU render, a small frame): with a few rays per lane a persistent
+	// launch is mostly tail, and the two traversal launches of an iteration side by side are worth +5 % at half the metric
+	// frame, +8 % at a quarter, +12 % at an eighth (bench.py --emulate-shard).  YAFGPU_OVERLAP=0 / 1 force either.
+	bool overlap = (uint64_t)cap_pixels * spp < (12ull << 20);
+	if(const char *e = std::getenv("YAFGPU_OVERLAP")) overlap = std::atoi(e) != 0;
 	if(overlap && !s->side_stream)
 	{
 		HIP_OK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));

@@ -803,7 +803,17 @@ def test_light_count_and_sample_count_limits(pipeline):
     points = [{"type": "pointlight", "from": tuple(float(x) for x in rng.uniform(-0.8, 0.8, 3)), "color": (1.0, 0.9, 0.8), "power": 0.02} for _ in range(255)]
     rd = scenes.render_settings(24, 20, 1, integrator="directlighting")
     sc255 = dict(sc, lights=list(sc["lights"]) + points[:254])
-    film, st, ofilm, ost = render_both(sc255, rd)
+    yi = Interface()
+    scenes.load_scene(yi, sc255, rd)
+    yi.render()
+    film, st = yi.getFilm(24, 20), yi.getRenderStats()
+    # at this resolution three camera rays run exactly into an edge two walls of different colour share: an exact tie in t
+    # that TriKdTree::intersect resolves by visiting order, i.e. by tree topology (see test_multi_pass_anti_aliasing) —
+    # the oracle walks the product's tree
+    from libyafaray_amd import interface
+    osc = po.OracleScene(sc255)
+    osc.set_tree(*interface.build_kdtree(sc255["verts"], threads=4, device=DEVICE_TREE)[:3])
+    ofilm, ost = osc.render(rd)
     assert st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, "255 lights")
     yi = Interface(strict=False)

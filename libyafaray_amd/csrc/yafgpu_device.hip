@@ -57,6 +57,7 @@ constexpr float kShadowBias = (float)0.0005;    // YAF_SHADOW_BIAS, CMakeLists.t
 struct DevScene
 {
 	const uint2 *nodes;          // 8-byte kd nodes (kdtree_build.h)
+	const uint4 *nodes2;         // (node i, a copy of its right child): the pair layout of the traversal kernels (YAFGPU_TRACE_PAIR), or nullptr
 	const uint32_t *refs;        // leaf references
 	const float4 *tri;           // 3 x float4 per triangle: (a, eps) (e1, mat|vis<<30) (e2, 0)
 	const float4 *tri_ng;        // geometric normal + smooth flag
@@ -1290,6 +1291,23 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if((rc = upload(s, (const uint2 *)padded.data(), padded.size(), &nodes))) { yafgpu_scene_destroy(s); return rc; }
 	}
 	dv.nodes = nodes;
+	dv.nodes2 = nullptr;
+#if YAFGPU_TRACE_PAIR
+	{
+		const std::vector<KdNode> &tn = s->tree.nodes;
+		std::vector<uint4> pairs(tn.size() + 8, make_uint4(0u, 3u, 0u, 3u));
+		for(size_t i = 0; i < tn.size(); ++i)
+		{
+			const uint2 nd = *(const uint2 *)&tn[i];
+			uint4 pr = make_uint4(nd.x, nd.y, 0u, 3u);
+			if((nd.y & 3u) != 3u) { const uint2 r = *(const uint2 *)&tn[nd.y >> 2]; pr.z = r.x; pr.w = r.y; }
+			pairs[i] = pr;
+		}
+		const uint4 *d_pairs = nullptr;
+		if((rc = upload(s, pairs.data(), pairs.size(), &d_pairs))) { yafgpu_scene_destroy(s); return rc; }
+		dv.nodes2 = d_pairs;
+	}
+#endif
 	if((rc = upload(s, s->tree.refs.data(), s->tree.refs.size(), &dv.refs))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, rec.data(), rec.size(), &dv.tri))) { yafgpu_scene_destroy(s); return rc; }
 	if((rc = upload(s, ng.data(), ng.size(), &dv.tri_ng))) { yafgpu_scene_destroy(s); return rc; }

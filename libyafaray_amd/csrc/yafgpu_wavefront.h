@@ -1044,6 +1044,9 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_BELOW_MASKS
 #define YAFGPU_TRACE_BELOW_MASKS 1
 #endif
+#ifndef YAFGPU_TRACE_PAIR
+#define YAFGPU_TRACE_PAIR 1      // closest-hit launches -6.5 % on the 1 M-triangle scenes, -4.5 % on the 100 k one (pair4 in profiles/r02_ab_pair.txt)
+#endif
 #ifndef YAFGPU_TRACE_WAVES
 #define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
 #endif
@@ -1305,8 +1308,30 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 		}
 		else
 		{
+#if YAFGPU_TRACE_PAIR
+			// Two node steps per memory round trip: nodes2[i] holds node i and a copy of its right child, the left child is node
+			// i + 1, so one 32-byte fetch at i brings both children along and the step after an interior node needs no fetch.
+			// Closest-hit rays only: the doubled node footprint costs the any-hit rays (L2 hit rate 75 %) more than the saved
+			// round trips give them (1 M triangles: closest-hit launches -7 %, any-hit launches +8.5 %).
 #pragma unroll 1
-			for(int s = 0; s < kNodeBurst; ++s)
+			for(int s = 0; s < (kAny ? 0 : kNodeBurst / 2); ++s)
+			{
+				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
+				if(ws == kWalk)
+				{
+					const uint32_t n0 = node;
+					const uint4 a0 = sc.nodes2[n0], a1 = sc.nodes2[n0 + 1u];
+					node_step(make_uint2(a0.x, a0.y));
+					if((a0.y & 3u) != 3u)          // an interior node hands the walk to one of its two children
+					{
+						const bool to_left = node == n0 + 1u;
+						node_step(to_left ? make_uint2(a1.x, a1.y) : make_uint2(a0.z, a0.w));
+					}
+				}
+			}
+#endif
+#pragma unroll 1
+			for(int s = 0; s < ((YAFGPU_TRACE_PAIR && !kAny) ? 0 : kNodeBurst); ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
 				if(ws == kWalk) node_step(sc.nodes[node]);

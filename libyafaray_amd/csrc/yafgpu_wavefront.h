@@ -1044,6 +1044,9 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_BELOW_MASKS
 #define YAFGPU_TRACE_BELOW_MASKS 1
 #endif
+#ifndef YAFGPU_TRACE_TRIPF
+#define YAFGPU_TRACE_TRIPF 0     // measured, off: the pending leaf's next triangle record fetched a round ahead (10 more VGPRs, loads for tests that never run, a wait for the reference where the fetch is issued): 2035 against 2245 Mrays/s on the 1 M-triangle scene
+#endif
 #ifndef YAFGPU_TRACE_PAIR
 #define YAFGPU_TRACE_PAIR 1      // closest-hit launches -6.5 % on the 1 M-triangle scenes, -4.5 % on the 100 k one (pair4 in profiles/r02_ab_pair.txt)
 #endif
@@ -1089,6 +1092,10 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 	uint32_t ws = kNoRay;
 	uint32_t p_cur = 0u, p_end = 0u, ti = 0u;       // pending leaf: references [p_cur, p_end) still to test, ti = refs[p_cur] (in flight)
 	float p_tmax = 0.f;                              // exit distance of the pending leaf's cell
+#if YAFGPU_TRACE_TRIPF
+	float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;      // record of triangle `ti`, fetched ahead of its test
+	bool q_ok = false;
+#endif
 	bool done = false;
 	uint32_t spec = 0u;                              // kStats: node steps + leaves of the walk ahead of the pending leaf
 	uint32_t spec_leaves = 0u;
@@ -1302,8 +1309,17 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			{
 				uint32_t ref_v = 0u;
 				if(p_cur + 1u < p_end) ref_v = sc.refs[p_cur + 1u];
+#if YAFGPU_TRACE_TRIPF
+				if(!q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; }
+				tri_step(q0, q1, q2, ref_v);
+				// the next triangle of the leaf (its reference has arrived meanwhile): its record is in flight until the next
+				// triangle round — behind whatever the wave waits for in between
+				q_ok = p_cur < p_end;
+				if(q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; }
+#else
 				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
 				tri_step(r0, r1, r2, ref_v);
+#endif
 			}
 		}
 		else
@@ -1317,6 +1333,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			for(int s = 0; s < (kAny ? 0 : kNodeBurst / 2); ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
+#if YAFGPU_TRACE_TRIPF
+				if(p_cur < p_end && !q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; q_ok = true; }
+#endif
 				if(ws == kWalk)
 				{
 					const uint32_t n0 = node;
@@ -1334,6 +1353,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			for(int s = 0; s < ((YAFGPU_TRACE_PAIR && !kAny) ? 0 : kNodeBurst); ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
+#if YAFGPU_TRACE_TRIPF
+				if(p_cur < p_end && !q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; q_ok = true; }
+#endif
 				if(ws == kWalk) node_step(sc.nodes[node]);
 			}
 		}
@@ -1343,6 +1365,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			if(kAny) answer_any(hit);
 			else a.state[2 * c + qi] = make_float4(fbits((uint32_t)(hit ? tri : -1)), z, bu, bv);
 			ws = kNoRay; done = false; p_cur = p_end = 0u;
+#if YAFGPU_TRACE_TRIPF
+			q_ok = false;
+#endif
 		}
 	}
 	if(a.ra.counters != nullptr)

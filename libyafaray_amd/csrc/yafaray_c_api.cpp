@@ -199,6 +199,7 @@ inline void clear_shader_slots(yafgpu_material &m)
 {
 	m.node_first = 0; m.n_nodes = 0;
 	m.sh_diffuse = m.sh_mirror_color = m.sh_mirror = m.sh_transparency = m.sh_translucency = m.sh_sigma_oren = m.sh_diffuse_refl = m.sh_ior = -1;
+	m.sh_glossy = m.sh_glossy_reflect = m.sh_exponent = -1;
 }
 
 constexpr int kMaxMaterialNodes = 16;    // yafgpu_texture.h kMaxNodes: the per-lane node stack of the shading kernels
@@ -452,8 +453,38 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	return true;
 }
 
+// shader slots of glossy / coated_glossy (material_glossy.cc:490-530, material_coated_glossy.cc:556-602): loads the node list, maps the
+// named slots and keeps what they reach in evaluation order.  false: refused (err set).
+bool glossy_nodes(yafaray_interface *yi, const ParamMap &p, const char *what, bool coated, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
+{
+	enum { kDiffuse, kGlossy, kGlossyReflect, kSigmaOren, kExponent, kDiffuseRefl, kIor, kMirror, kMirrorColor, kBump, kWireframe, kSlots };
+	static const char *names[kSlots] = {"diffuse_shader", "glossy_shader", "glossy_reflect_shader", "sigma_oren_shader", "exponent_shader", "diffuse_refl_shader",
+	                                    "IOR_shader", "mirror_shader", "mirror_color_shader", "bump_shader", "wireframe_shader"};
+	int slots[kSlots]; for(int &v : slots) v = -1;
+	nodes.clear();
+	clear_shader_slots(m);
+	if(yi->eparams.empty()) return true;
+	LoadedNodes ld;
+	const int rc = load_nodes(yi, yi->eparams, ld);
+	if(rc == 0) return false;
+	if(rc < 0) { std::fprintf(stderr, "WARNING: %s: Loading shader nodes failed! (the material is built without them, as the reference does)\n", what); return true; }
+	std::string node;
+	for(int k = 0; k < kSlots; ++k)
+	{
+		if(!coated && (k == kIor || k == kMirror || k == kMirrorColor)) continue;       // glossy has no such slots
+		if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
+	}
+	if(slots[kBump] >= 0) return fail(yi, std::string(what) + ": bump_shader (bump / normal mapping) is not supported by the GPU path");
+	if(slots[kWireframe] >= 0) return fail(yi, std::string(what) + ": wireframe_shader is not supported by the GPU path");
+	if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
+	m.n_nodes = (int32_t)nodes.size();
+	m.sh_diffuse = slots[kDiffuse]; m.sh_glossy = slots[kGlossy]; m.sh_glossy_reflect = slots[kGlossyReflect]; m.sh_sigma_oren = slots[kSigmaOren];
+	m.sh_exponent = slots[kExponent]; m.sh_diffuse_refl = slots[kDiffuseRefl]; m.sh_ior = slots[kIor]; m.sh_mirror = slots[kMirror]; m.sh_mirror_color = slots[kMirrorColor];
+	return true;
+}
+
 // GlossyMaterial::factory + ctor, material_glossy.cc:407-472, :32-50
-bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
 {
 	float col[3] = {1, 1, 1}, dcol[3] = {1, 1, 1};
 	float refl = 1.f, diff = 0.f, exponent = 50.f, wire = 0.f;
@@ -464,8 +495,8 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
 	{ int add_depth = 0; p.get("additionaldepth", add_depth); if(add_depth != 0) return fail(yi, "glossy: additionaldepth is not supported by the GPU path"); }
-	if(!yi->eparams.empty()) return fail(yi, "glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
 	std::memset(&m, 0, sizeof m);
+	if(!glossy_nodes(yi, p, "glossy", false, m, nodes)) return false;
 	m.type = YAFGPU_MAT_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; }
 	m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
@@ -503,7 +534,7 @@ bool make_lightmat(const ParamMap &p, yafgpu_material &m)
 }
 
 // CoatedGlossyMaterial::factory + ctor, material_coated_glossy.cc:464-560, :41-66 (Blinn lobe, as_diffuse only)
-bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
 {
 	float col[3] = {1, 1, 1}, dcol[3] = {1, 1, 1}, mcol[3] = {1, 1, 1};
 	float refl = 1.f, diff = 0.f, exponent = 50.f, mirror = 1.f, wire = 0.f; double ior = 1.4, sigma = 0.1;
@@ -514,9 +545,10 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "coated_glossy: wireframe shading is not supported by the GPU path");
 	if(add_depth != 0) return fail(yi, "coated_glossy: additionaldepth is not supported by the GPU path");
-	if(!yi->eparams.empty()) return fail(yi, "coated_glossy: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
 	if(ior == 1.0) ior = 1.0000001f;                                // :512
 	std::memset(&m, 0, sizeof m);
+	if(!glossy_nodes(yi, p, "coated_glossy", true, m, nodes)) return false;
+	m.ior_base = (float)ior;
 	m.type = YAFGPU_MAT_COATED_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; m.mirror_color[k] = mcol[k]; }
 	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
@@ -1003,14 +1035,14 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	auto m = std::make_unique<yafaray_material>();
 	bool ok;
 	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m, m->nodes);
-	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m);
+	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
 	else if(type == "glass") ok = make_glass(yi, yi->params, m->m);
-	else if(type == "coated_glossy") ok = make_coated_glossy(yi, yi->params, m->m);
+	else if(type == "coated_glossy") ok = make_coated_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
 	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }
 	if(!ok) return nullptr;
-	if(type != "shinydiffusemat") clear_shader_slots(m->m);
+	if(type != "shinydiffusemat" && type != "glossy" && type != "coated_glossy") clear_shader_slots(m->m);
 	note_srand(yi, ++g_material_index_auto);        // Material::Material, material.cc:53-57
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();

@@ -296,7 +296,8 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		if(m.with_diffuse)
 		{
 			Col add = col3(m.diff_color) * (d.m_diffuse * (1.f - d.m_glossy));
-			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wl, wo, n);
+			if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) add = add * m.diffuse_refl;      // diffuse_reflection_shader_
+			if(m.use_oren) add = add * sd_oren(m, wl, wo, n);
 			col = col + add;
 		}
 		return col;
@@ -321,7 +322,8 @@ YG_MAT Col mat_eval(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp
 		if(m.with_diffuse && diffuse_flag)
 		{
 			Col add = (col3(m.diff_color) * (d.m_diffuse * (1.f - d.m_glossy))) * kt;
-			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wl, wo, n);
+			if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) add = add * m.diffuse_refl;      // diffuse_reflection_shader_
+			if(m.use_oren) add = add * sd_oren(m, wl, wo, n);
 			col = col + add;
 		}
 		return col;
@@ -677,7 +679,8 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 			if(use2)
 			{
 				Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color)) * kt;
-				if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+				if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) add = add * m.diffuse_refl;
+			if(m.use_oren) add = add * sd_oren(m, wi, wo, n);
 				scolor = scolor + add;
 				s.pdf += wi_n * w_diffuse;
 			}
@@ -799,7 +802,8 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 				if(!(s.flags & kReflect)) return mkc(0.f, 0.f, 0.f);
 				scolor = col3(m.gloss_color) * glossy;
 				Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color));
-				if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+				if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) add = add * m.diffuse_refl;
+			if(m.use_oren) add = add * sd_oren(m, wi, wo, n);
 				scolor = scolor + add;
 				w = wi_n / (s.pdf * 0.99f + 0.01f);
 				return scolor;
@@ -831,7 +835,8 @@ YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 		if(use_diffuse)
 		{
 			Col add = diffuse_reflect(wi_n, wo_n, d.m_glossy, d.m_diffuse, col3(m.diff_color));
-			if(m.use_oren) add = add * oren_nayar(m.oren_a, m.oren_b, wi, wo, n);
+			if(YAFGPU_FEAT_TEXTURE && m.has_diffuse_refl) add = add * m.diffuse_refl;
+			if(m.use_oren) add = add * sd_oren(m, wi, wo, n);
 			s.pdf = wi_n * cur_p + s.pdf * (1.f - cur_p);
 			scolor = scolor + add;
 		}

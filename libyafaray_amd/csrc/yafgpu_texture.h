@@ -481,6 +481,24 @@ YG_DEV void mat_resolve(const TexScene &ts, const yafgpu_camera &cam, const yafg
 	const int nn = m.n_nodes < kMaxNodes ? m.n_nodes : kMaxNodes;
 	nodes_eval(ts, ts.nodes + m.node_first, nn, cam, tp, stack);
 	out = m;
+	if(m.type != YAFGPU_MAT_SHINYDIFFUSE)
+	{	// glossy / coated glossy: every use of a shader is `shader ? shader->get...(stack) : member` (material_glossy.cc:62,144-160,
+		// material_coated_glossy.cc:78,147-174,253-256,448-451), so the members of the per-hit copy carry them
+		if(m.sh_diffuse >= 0) { const Rgba4 c = stack[m.sh_diffuse].col; out.diff_color[0] = c.r; out.diff_color[1] = c.g; out.diff_color[2] = c.b; }
+		if(m.sh_glossy >= 0) { const Rgba4 c = stack[m.sh_glossy].col; out.gloss_color[0] = c.r; out.gloss_color[1] = c.g; out.gloss_color[2] = c.b; }
+		if(m.sh_glossy_reflect >= 0) out.reflectivity = stack[m.sh_glossy_reflect].f;
+		if(m.sh_exponent >= 0) out.exponent = stack[m.sh_exponent].f;
+		if(m.sh_sigma_oren >= 0)
+		{
+			const double sigma = (double)stack[m.sh_sigma_oren].f, s2 = sigma * sigma;
+			out.oren_tex = 1; out.oren_ad = 1.0 - 0.5 * (s2 / (s2 + 0.33)); out.oren_bd = 0.45 * s2 / (s2 + 0.09);
+		}
+		if(m.sh_diffuse_refl >= 0) { out.has_diffuse_refl = 1; out.diffuse_refl = stack[m.sh_diffuse_refl].f; }
+		if(m.sh_mirror_color >= 0) { const Rgba4 c = stack[m.sh_mirror_color].col; out.mirror_color[0] = c.r; out.mirror_color[1] = c.g; out.mirror_color[2] = c.b; }
+		if(m.sh_mirror >= 0) out.mirror_strength = stack[m.sh_mirror].f;
+		if(m.sh_ior >= 0) out.glass_ior = m.ior_base + stack[m.sh_ior].f;
+		return;
+	}
 	if(m.sh_diffuse >= 0)
 	{
 		const Rgba4 c = stack[m.sh_diffuse].col;

@@ -453,6 +453,8 @@ typedef struct
 	/* shader nodes: the list in evaluation order and the node each slot reads (-1: none) */
 	int n_nodes; struct node_s *nodes;
 	int sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
+	int sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader */
+	float ior_plain;                                   /* coated_glossy: ior_ before the IOR shader's offset */
 	float ior_base;                       /* ior_, for the IOR shader (material_shiny_diffuse.cc:258-262) */
 	/* values a resolved copy carries (mat_resolve): orenNayar with a texture sigma computes A and B in double (:230-235) */
 	int oren_tex; double oren_ad, oren_bd;
@@ -1544,6 +1546,20 @@ static rgb beer_transmittance(rgb sigma, float tmax)
 	return C(yor_fexp2(l2e * (-dist * sigma.r)), yor_fexp2(l2e * (-dist * sigma.g)), yor_fexp2(l2e * (-dist * sigma.b)));
 }
 
+static void mat_copy_nodes(mat_t *m, const yor_material_desc *d)      /* glossy / coated glossy shader slots (material_glossy.cc:504-511, material_coated_glossy.cc:572-582) */
+{
+	m->sh_diffuse = m->sh_mirror_color = m->sh_mirror = m->sh_transparency = m->sh_translucency = m->sh_sigma_oren = m->sh_diffuse_refl = m->sh_ior = -1;
+	m->sh_glossy = m->sh_glossy_reflect = m->sh_exponent = -1;
+	if(d->n_nodes > 0 && d->nodes)
+	{
+		m->n_nodes = d->n_nodes;
+		m->nodes = (node_t *)calloc((size_t)d->n_nodes, sizeof(node_t));
+		for(int k = 0; k < d->n_nodes; ++k) node_configure(&m->nodes[k], &d->nodes[k]);
+		m->sh_diffuse = d->sh_diffuse; m->sh_sigma_oren = d->sh_sigma_oren; m->sh_diffuse_refl = d->sh_diffuse_refl;
+		m->sh_glossy = d->sh_glossy; m->sh_glossy_reflect = d->sh_glossy_reflect; m->sh_exponent = d->sh_exponent;
+		if(d->type == YOR_MAT_COATED_GLOSSY) { m->sh_mirror_color = d->sh_mirror_color; m->sh_mirror = d->sh_mirror; m->sh_ior = d->sh_ior; }
+	}
+}
 static void mat_configure(mat_t *m, const yor_material_desc *d)
 {
 	memset(m, 0, sizeof *m);
@@ -1619,6 +1635,7 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
 		m->as_diffuse = d->as_diffuse;
 		m->anisotropic = d->anisotropic; m->exp_u = d->exp_u; m->exp_v = d->exp_v;
+		mat_copy_nodes(m, d);
 		m->flags = BSDF_NONE;
 		if(m->diffuse > 0) { m->flags = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; }
 		m->flags |= m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
@@ -1640,6 +1657,7 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 		m->exponent = d->exponent; m->reflectivity = d->glossy_reflect; m->diffuse = d->glossy_diffuse_reflect;
 		m->as_diffuse = d->as_diffuse;
 		m->anisotropic = d->anisotropic; m->exp_u = d->exp_u; m->exp_v = d->exp_v;
+		mat_copy_nodes(m, d); m->ior_plain = d->ior;
 		m->c_flags[0] = BSDF_SPECULAR | BSDF_REFLECT;
 		m->c_flags[1] = m->as_diffuse ? (BSDF_DIFFUSE | BSDF_REFLECT) : (BSDF_GLOSSY | BSDF_REFLECT);
 		if(m->diffuse > 0) { m->c_flags[2] = BSDF_DIFFUSE | BSDF_REFLECT; m->with_diffuse = 1; m->n_bsdf = 3; }
@@ -1824,10 +1842,28 @@ static v3 glass_normal(const sp_t *sp, v3 wo)
 static const mat_t *mat_resolve(const yor_scene *s, const sp_t *sp, mat_t *out)
 {
 	const mat_t *m = &s->mats[sp->mat];
-	if(m->n_nodes <= 0 || m->type != YOR_MAT_SHINYDIFFUSE) return m;
+	if(m->n_nodes <= 0 || (m->type != YOR_MAT_SHINYDIFFUSE && m->type != YOR_MAT_GLOSSY && m->type != YOR_MAT_COATED_GLOSSY)) return m;
 	node_result_t stack[YOR_MAX_NODES];
 	nodes_eval(m->nodes, m->n_nodes < YOR_MAX_NODES ? m->n_nodes : YOR_MAX_NODES, s->tex, s->n_tex, &s->cam, sp, stack);
 	*out = *m;
+	if(m->type != YOR_MAT_SHINYDIFFUSE)
+	{	/* glossy / coated glossy: every use of a shader is `shader ? shader->get…(stack) : member` (material_glossy.cc:62,144-160,
+		 * material_coated_glossy.cc:78,147-174,253-256,448-451), so the members of a per-hit copy carry them */
+		if(m->sh_diffuse >= 0) out->diff_color = C(stack[m->sh_diffuse].col.r, stack[m->sh_diffuse].col.g, stack[m->sh_diffuse].col.b);
+		if(m->sh_glossy >= 0) out->gloss_color = C(stack[m->sh_glossy].col.r, stack[m->sh_glossy].col.g, stack[m->sh_glossy].col.b);
+		if(m->sh_glossy_reflect >= 0) out->reflectivity = stack[m->sh_glossy_reflect].f;
+		if(m->sh_exponent >= 0) out->exponent = stack[m->sh_exponent].f;
+		if(m->sh_sigma_oren >= 0)
+		{
+			double sigma = (double)stack[m->sh_sigma_oren].f, s2 = sigma * sigma;
+			out->oren_tex = 1; out->oren_ad = 1.0 - 0.5 * (s2 / (s2 + 0.33)); out->oren_bd = 0.45 * s2 / (s2 + 0.09);
+		}
+		if(m->sh_diffuse_refl >= 0) { out->has_diffuse_refl = 1; out->diffuse_refl = stack[m->sh_diffuse_refl].f; }
+		if(m->sh_mirror_color >= 0) out->mirror_color = C(stack[m->sh_mirror_color].col.r, stack[m->sh_mirror_color].col.g, stack[m->sh_mirror_color].col.b);
+		if(m->sh_mirror >= 0) out->mirror_strength = stack[m->sh_mirror].f;
+		if(m->sh_ior >= 0) out->ior = m->ior_plain + stack[m->sh_ior].f;
+		return out;
+	}
 	if(m->sh_diffuse >= 0)
 	{
 		out->diffuse_color = C(stack[m->sh_diffuse].col.r, stack[m->sh_diffuse].col.g, stack[m->sh_diffuse].col.b);
@@ -1973,7 +2009,8 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		if(m->with_diffuse && diffuse_flag)
 		{
 			rgb add_col = cscale(m->diff_color, dat->m_diffuse * (1.f - dat->m_glossy));
-			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, wl, wo, n));
+			if(m->has_diffuse_refl) add_col = cscale(add_col, m->diffuse_refl);      /* diffuse_reflection_shader_ */
+			if(m->use_oren) add_col = cscale(add_col, sd_oren(m, wl, wo, n));
 			col = cadd(col, add_col);
 		}
 		return col;
@@ -1999,7 +2036,8 @@ static rgb mat_eval(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, 
 		if(m->with_diffuse && diffuse_flag)
 		{
 			rgb add_col = cscale(cscale(m->diff_color, dat->m_diffuse * (1.f - dat->m_glossy)), kt);
-			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, wl, wo, n));
+			if(m->has_diffuse_refl) add_col = cscale(add_col, m->diffuse_refl);      /* diffuse_reflection_shader_ */
+			if(m->use_oren) add_col = cscale(add_col, sd_oren(m, wl, wo, n));
 			col = cadd(col, add_col);
 		}
 		return col;
@@ -2409,7 +2447,8 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 				scolor = cscale(m->gloss_color, glossy);
 				{
 					rgb add_col = diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color);
-					if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+					if(m->has_diffuse_refl) add_col = cscale(add_col, m->diffuse_refl);
+					if(m->use_oren) add_col = cscale(add_col, sd_oren(m, *wi, wo, n));
 					scolor = cadd(scolor, add_col);
 				}
 				*w = wi_n / (s->pdf * 0.99f + 0.01f);
@@ -2445,7 +2484,8 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 		if(use_diffuse)
 		{
 			rgb add_col = diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color);
-			if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+			if(m->has_diffuse_refl) add_col = cscale(add_col, m->diffuse_refl);
+			if(m->use_oren) add_col = cscale(add_col, sd_oren(m, *wi, wo, n));
 			s->pdf = wi_n * cur_p_diffuse + s->pdf * (1.f - cur_p_diffuse);
 			scolor = cadd(scolor, add_col);
 		}
@@ -2555,7 +2595,8 @@ static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo
 			if(use[2])
 			{
 				rgb add_col = cscale(diffuse_reflect(wi_n, wo_n, dat->m_glossy, dat->m_diffuse, m->diff_color), kt);
-				if(m->use_oren) add_col = cscale(add_col, oren_nayar(m->oren_a, m->oren_b, *wi, wo, n));
+				if(m->has_diffuse_refl) add_col = cscale(add_col, m->diffuse_refl);
+				if(m->use_oren) add_col = cscale(add_col, sd_oren(m, *wi, wo, n));
 				scolor = cadd(scolor, add_col);
 				s->pdf += wi_n * width[rc_index[2]];
 			}

@@ -1062,7 +1062,8 @@ def _texturize(sc, rng):
     tex = lambda: str(rng.choice([t["name"] for t in sc["textures"]]))
     texcos = ["uv", "global", "orco", "transformed", "window", "normal"]
     for m in sc["materials"]:
-        if m.get("type", "shinydiffusemat") != "shinydiffusemat" or rng.random() < 0.4:
+        kind = m.get("type", "shinydiffusemat")
+        if kind not in ("shinydiffusemat", "glossy", "coated_glossy") or rng.random() < 0.4:
             continue
         nodes, k = [], [0]
         def mapper():
@@ -1087,6 +1088,31 @@ def _texturize(sc, rng):
                 nodes.append(top)
                 return top["name"]
             return nd["name"]
+        if kind != "shinydiffusemat":      # glossy / coated glossy: their own slots
+            if rng.random() < 0.6:
+                m["diffuse_shader"] = layer(False, 0.0)
+            if rng.random() < 0.6:
+                m["glossy_shader"] = layer(False, 0.0)
+            if rng.random() < 0.5:
+                m["glossy_reflect_shader"] = layer(True, m.get("glossy_reflect", 1.0))
+            if rng.random() < 0.4 and not m.get("anisotropic"):
+                m["exponent_shader"] = layer(True, m.get("exponent", 50.0))
+                nodes[-1]["valfac"] = float(rng.uniform(20.0, 200.0))
+            if rng.random() < 0.3:
+                m["diffuse_refl_shader"] = layer(True, 1.0)
+            if kind == "coated_glossy":
+                if rng.random() < 0.5:
+                    m["mirror_shader"] = layer(True, m.get("specular_reflect", 1.0))
+                if rng.random() < 0.4:
+                    m["mirror_color_shader"] = layer(False, 0.0)
+                if rng.random() < 0.4:
+                    m["IOR_shader"] = layer(True, 0.0)
+            if nodes and len(nodes) <= 16:
+                m["nodes"] = nodes
+            else:
+                for key in [key for key in m if key.endswith("_shader")]:
+                    m.pop(key)
+            continue
         if rng.random() < 0.8:
             if rng.random() < 0.2:
                 k[0] += 1

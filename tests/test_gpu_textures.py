@@ -222,6 +222,42 @@ def test_textured_render_matches_oracle(integrator, kw):
     compare_films(film, ofilm, f"textured box {integrator} {kw}", exact_weights=True)
 
 
+@pytest.mark.parametrize("integrator,raydepth", [("directlighting", 2), ("pathtracing", 2)])
+def test_textured_glossy_and_coated_glossy_match_oracle(integrator, raydepth):
+    """shader nodes on every slot of glossy and coated_glossy (diffuse, glossy colour, glossy reflectivity, exponent, Oren-Nayar sigma,
+    diffuse-reflection strength; the coat's mirror strength, mirror colour and IOR offset), path-traced (`as_diffuse`) and through
+    recursiveRaytrace's glossy branch, whose frames carry the hit's texture coordinates"""
+    sc = _textured_box(specular=False)
+    mapper = lambda name, tex, texco, mapping="plain", **kw: dict(name=name, type="texture_mapper", texture=tex, texco=texco, mapping=mapping, **kw)
+    col = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, colfac=0.8, def_col=(1.0, 0.0, 1.0, 1.0), do_color=True, do_scalar=False,
+                                            color_input=True, upper_color=(0.7, 0.7, 0.7, 1.0), upper_value=0.0), **kw)
+    val = lambda name, inp, upper, fac: dict(name=name, type="layer", input=inp, mode=0, valfac=fac, def_val=1.0, do_color=False, do_scalar=True, color_input=True,
+                                             upper_value=upper)
+    m = sc["materials"]
+    m[1] = {"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5, "exponent": 60.0,
+            "as_diffuse": True, "diffuse_brdf": "Oren-Nayar", "sigma": 0.2,
+            "diffuse_shader": "dcol", "glossy_shader": "gcol", "glossy_reflect_shader": "grefl", "exponent_shader": "gexp", "sigma_oren_shader": "sig",
+            "diffuse_refl_shader": "drefl",
+            "nodes": [col("dcol", "m_uv"), col("gcol", "m_orco", mode=2), val("grefl", "m_uv", 0.5, 0.4), val("gexp", "m_glob", 60.0, 40.0), val("sig", "m_orco", 0.2, 0.5),
+                      val("drefl", "m_glob", 1.0, 0.5), mapper("m_uv", "t_rgb", "uv"), mapper("m_orco", "t_adj", "orco", "cube"), mapper("m_glob", "t_chk", "global", "sphere")]}
+    m[2] = {"type": "glossy", "color": (1.0, 0.9, 0.8), "glossy_reflect": 0.8, "exponent": 200.0, "as_diffuse": False,
+            "glossy_shader": "gcol", "exponent_shader": "gexp",
+            "nodes": [col("gcol", "m_uv"), val("gexp", "m_uv", 200.0, 150.0), mapper("m_uv", "t_rgb", "uv", scale=(2.0, 2.0, 1.0))]}
+    m[4] = {"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.5, "glossy_reflect": 0.5, "exponent": 100.0,
+            "specular_reflect": 0.6, "IOR": 1.5, "mirror_color": (0.9, 0.95, 1.0), "as_diffuse": bool(integrator == "pathtracing"),
+            "diffuse_shader": "dcol", "glossy_reflect_shader": "grefl", "mirror_shader": "mir", "mirror_color_shader": "mcol", "IOR_shader": "ior",
+            "nodes": [col("dcol", "m_orco"), val("grefl", "m_orco", 0.5, 0.5), val("mir", "m_uv", 0.6, 0.5), col("mcol", "m_uv", mode=1), val("ior", "m_orco", 0.0, 0.5),
+                      mapper("m_uv", "t_chk", "uv"), mapper("m_orco", "t_rgb", "orco", "tube")]}
+    rd = scenes.render_settings(48, 40, 3, integrator=integrator, bounces=2, raydepth=raydepth, path_samples=2)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(48, 40), yi.getRenderStats()
+    ofilm, ost = po.OracleScene(sc).render(rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"textured glossy / coated glossy, {integrator}", exact_weights=True)
+
+
 def test_test01_with_its_textures_against_the_references_expected_png():
     """The reference's shipped test scene with the textures this build decodes (TGA, HDR, PNG; tests/golden/test01_tex.xml) rendered
     on the device through the product's XML loader, (a) against the oracle given the same decoded texels, and (b) against the

@@ -199,7 +199,7 @@ inline void clear_shader_slots(yafgpu_material &m)
 {
 	m.node_first = 0; m.n_nodes = 0;
 	m.sh_diffuse = m.sh_mirror_color = m.sh_mirror = m.sh_transparency = m.sh_translucency = m.sh_sigma_oren = m.sh_diffuse_refl = m.sh_ior = -1;
-	m.sh_glossy = m.sh_glossy_reflect = m.sh_exponent = -1;
+	m.sh_glossy = m.sh_glossy_reflect = m.sh_exponent = m.sh_filter_color = -1;
 }
 
 constexpr int kMaxMaterialNodes = 16;    // yafgpu_texture.h kMaxNodes: the per-lane node stack of the shading kernels
@@ -573,7 +573,7 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 }
 
 // GlassMaterial::factory + ctor, material_glass.cc:340-443, :32-49 (no dispersion or shader nodes)
-bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
+bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
 {
 	double ior = 1.4, filt = 0.0, disp = 0.0; float fcol[3] = {1, 1, 1}, scol[3] = {1, 1, 1}, absorp[3] = {1, 1, 1}, wire = 0.f;
 	bool fake = false, recv = true; std::string vis = "normal"; int add_depth = 0;
@@ -583,8 +583,30 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m)
 	if(disp > 0.0) return fail(yi, "glass: dispersion is not supported by the GPU path (recursiveRaytrace's dispersive branch)");
 	if(add_depth != 0) return fail(yi, "glass: additionaldepth is not supported by the GPU path");
 	if(wire != 0.f) return fail(yi, "glass: wireframe shading is not supported by the GPU path");
-	if(!yi->eparams.empty()) return fail(yi, "glass: shader nodes / textures are not supported by the GPU path (SURVEY row N2)");
 	std::memset(&m, 0, sizeof m);
+	clear_shader_slots(m);
+	nodes.clear();
+	if(!yi->eparams.empty())
+	{	// material_glass.cc:402-441: mirror_color_shader, filter_color_shader, IOR_shader (bump / wireframe refused)
+		enum { kMirrorColor, kFilterColor, kIor, kBump, kWireframe, kSlots };
+		static const char *names[kSlots] = {"mirror_color_shader", "filter_color_shader", "IOR_shader", "bump_shader", "wireframe_shader"};
+		int slots[kSlots]; for(int &v : slots) v = -1;
+		LoadedNodes ld;
+		const int rc = load_nodes(yi, yi->eparams, ld);
+		if(rc == 0) return false;
+		if(rc > 0)
+		{
+			std::string node;
+			for(int k = 0; k < kSlots; ++k) if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
+			if(slots[kBump] >= 0) return fail(yi, "glass: bump_shader (bump / normal mapping) is not supported by the GPU path");
+			if(slots[kWireframe] >= 0) return fail(yi, "glass: wireframe_shader is not supported by the GPU path");
+			if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
+			m.n_nodes = (int32_t)nodes.size();
+			m.sh_mirror_color = slots[kMirrorColor]; m.sh_filter_color = slots[kFilterColor]; m.sh_ior = slots[kIor];
+		}
+		else std::fprintf(stderr, "WARNING: Glass: Loading shader nodes failed! (the material is built without them, as the reference does)\n");
+	}
+	m.ior_base = (float)ior; m.transp_ior = (float)ior;
 	m.type = YAFGPU_MAT_GLASS; m.receive_shadows = recv; m.visibility = visibility_from(vis);
 	m.glass_ior = (float)ior;
 	const float ff = (float)filt, fc = (float)(1.f - filt);       // filt * filt_col + Rgb(1.f - filt)
@@ -1037,12 +1059,12 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	if(type == "shinydiffusemat") ok = make_shinydiffuse(yi, yi->params, m->m, m->nodes);
 	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
-	else if(type == "glass") ok = make_glass(yi, yi->params, m->m);
+	else if(type == "glass") ok = make_glass(yi, yi->params, m->m, m->nodes);
 	else if(type == "coated_glossy") ok = make_coated_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
 	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }
 	if(!ok) return nullptr;
-	if(type != "shinydiffusemat" && type != "glossy" && type != "coated_glossy") clear_shader_slots(m->m);
+	if(type != "shinydiffusemat" && type != "glossy" && type != "coated_glossy" && type != "glass") clear_shader_slots(m->m);
 	note_srand(yi, ++g_material_index_auto);        // Material::Material, material.cc:53-57
 	m->index = (int)yi->material_order.size();
 	yafaray_material *raw = m.get();

@@ -450,7 +450,7 @@ YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 	{
 		const V3 n = face_forward(sp.ng, sp.n, wo);
 		float kr, kt;
-		fresnel_dielectric(wo, n, m.glass_ior, kr, kt);
+		fresnel_dielectric(wo, n, m.transp_ior, kr, kt);
 		return col3(m.filter_color) * kt;
 	}
 	return mkc(0.f, 0.f, 0.f);

@@ -481,6 +481,13 @@ YG_DEV void mat_resolve(const TexScene &ts, const yafgpu_camera &cam, const yafg
 	const int nn = m.n_nodes < kMaxNodes ? m.n_nodes : kMaxNodes;
 	nodes_eval(ts, ts.nodes + m.node_first, nn, cam, tp, stack);
 	out = m;
+	if(m.type == YAFGPU_MAT_GLASS)
+	{	// material_glass.cc:87-95,109,121,143-190,223-224,262-300
+		if(m.sh_mirror_color >= 0) { const Rgba4 c = stack[m.sh_mirror_color].col; out.mirror_color[0] = c.r; out.mirror_color[1] = c.g; out.mirror_color[2] = c.b; }
+		if(m.sh_filter_color >= 0) { const Rgba4 c = stack[m.sh_filter_color].col; out.filter_color[0] = c.r; out.filter_color[1] = c.g; out.filter_color[2] = c.b; }
+		if(m.sh_ior >= 0) { out.glass_ior = m.ior_base + stack[m.sh_ior].f; out.transp_ior = stack[m.sh_ior].f; }      // :223 sic: not added there
+		return;
+	}
 	if(m.type != YAFGPU_MAT_SHINYDIFFUSE)
 	{	// glossy / coated glossy: every use of a shader is `shader ? shader->get...(stack) : member` (material_glossy.cc:62,144-160,
 		// material_coated_glossy.cc:78,147-174,253-256,448-451), so the members of the per-hit copy carry them

@@ -38,7 +38,7 @@ class MaterialDesc(C.Structure):
         ("sh_translucency", C.c_int32), ("sh_sigma_oren", C.c_int32), ("sh_diffuse_refl", C.c_int32), ("sh_ior", C.c_int32),
         ("pad2", C.c_int32), ("nodes", C.c_void_p),
         ("exp_u", C.c_float), ("exp_v", C.c_float),
-        ("sh_glossy", C.c_int32), ("sh_glossy_reflect", C.c_int32), ("sh_exponent", C.c_int32), ("pad3", C.c_int32),
+        ("sh_glossy", C.c_int32), ("sh_glossy_reflect", C.c_int32), ("sh_exponent", C.c_int32), ("sh_filter_color", C.c_int32),
     ]
 
 
@@ -79,7 +79,7 @@ COLOR_SPACE = {"sRGB": 0, "XYZ": 1, "LinearRGB": 2, "Raw_Manual_Gamma": 3}
 SHADER_SLOTS = {"diffuse_shader": "sh_diffuse", "mirror_color_shader": "sh_mirror_color", "mirror_shader": "sh_mirror",
                 "transparency_shader": "sh_transparency", "translucency_shader": "sh_translucency",
                 "sigma_oren_shader": "sh_sigma_oren", "diffuse_refl_shader": "sh_diffuse_refl", "IOR_shader": "sh_ior",
-                "glossy_shader": "sh_glossy", "glossy_reflect_shader": "sh_glossy_reflect", "exponent_shader": "sh_exponent"}
+                "glossy_shader": "sh_glossy", "glossy_reflect_shader": "sh_glossy_reflect", "exponent_shader": "sh_exponent", "filter_color_shader": "sh_filter_color"}
 
 
 def texture_desc(t):
@@ -371,7 +371,7 @@ def material_desc(m):
     else:
         raise ValueError(t)
     d.sh_diffuse = d.sh_mirror_color = d.sh_mirror = d.sh_transparency = d.sh_translucency = d.sh_sigma_oren = d.sh_diffuse_refl = d.sh_ior = -1
-    d.sh_glossy = d.sh_glossy_reflect = d.sh_exponent = -1
+    d.sh_glossy = d.sh_glossy_reflect = d.sh_exponent = d.sh_filter_color = -1
     return d
 
 

@@ -454,6 +454,7 @@ typedef struct
 	int n_nodes; struct node_s *nodes;
 	int sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader */
+	int sh_filter_color; float transp_ior;             /* glass: filter_color_shader; the index getTransparency's fresnel sees (:223: the IOR shader's value alone) */
 	float ior_plain;                                   /* coated_glossy: ior_ before the IOR shader's offset */
 	float ior_base;                       /* ior_, for the IOR shader (material_shiny_diffuse.cc:258-262) */
 	/* values a resolved copy carries (mat_resolve): orenNayar with a texture sigma computes A and B in double (:230-235) */
@@ -1549,7 +1550,7 @@ static rgb beer_transmittance(rgb sigma, float tmax)
 static void mat_copy_nodes(mat_t *m, const yor_material_desc *d)      /* glossy / coated glossy shader slots (material_glossy.cc:504-511, material_coated_glossy.cc:572-582) */
 {
 	m->sh_diffuse = m->sh_mirror_color = m->sh_mirror = m->sh_transparency = m->sh_translucency = m->sh_sigma_oren = m->sh_diffuse_refl = m->sh_ior = -1;
-	m->sh_glossy = m->sh_glossy_reflect = m->sh_exponent = -1;
+	m->sh_glossy = m->sh_glossy_reflect = m->sh_exponent = m->sh_filter_color = -1;
 	if(d->n_nodes > 0 && d->nodes)
 	{
 		m->n_nodes = d->n_nodes;
@@ -1558,6 +1559,8 @@ static void mat_copy_nodes(mat_t *m, const yor_material_desc *d)      /* glossy 
 		m->sh_diffuse = d->sh_diffuse; m->sh_sigma_oren = d->sh_sigma_oren; m->sh_diffuse_refl = d->sh_diffuse_refl;
 		m->sh_glossy = d->sh_glossy; m->sh_glossy_reflect = d->sh_glossy_reflect; m->sh_exponent = d->sh_exponent;
 		if(d->type == YOR_MAT_COATED_GLOSSY) { m->sh_mirror_color = d->sh_mirror_color; m->sh_mirror = d->sh_mirror; m->sh_ior = d->sh_ior; }
+		if(d->type == YOR_MAT_GLASS) { m->sh_diffuse = m->sh_sigma_oren = m->sh_diffuse_refl = m->sh_glossy = m->sh_glossy_reflect = m->sh_exponent = -1;
+		                               m->sh_mirror_color = d->sh_mirror_color; m->sh_filter_color = d->sh_filter_color; m->sh_ior = d->sh_ior; }   /* material_glass.cc:419-422 */
 	}
 }
 static void mat_configure(mat_t *m, const yor_material_desc *d)
@@ -1673,7 +1676,8 @@ static void mat_configure(mat_t *m, const yor_material_desc *d)
 	}
 	else if(d->type == YOR_MAT_GLASS)
 	{	/* GlassMaterial::factory + ctor, material_glass.cc:32-49, 340-388 (no dispersion, no absorption, no nodes) */
-		m->ior = d->ior;
+		m->ior = d->ior; m->transp_ior = d->ior; m->ior_plain = d->ior;
+		mat_copy_nodes(m, d);
 		const double filt = d->sigma;                                    /* transmit_filter, a double parameter */
 		const float ff = (float)filt, fc = (float)(1.f - filt);          /* filt * filt_col + Rgb(1.f - filt) */
 		m->filter_color = C(ff * d->color[0] + fc, ff * d->color[1] + fc, ff * d->color[2] + fc);
@@ -1842,10 +1846,17 @@ static v3 glass_normal(const sp_t *sp, v3 wo)
 static const mat_t *mat_resolve(const yor_scene *s, const sp_t *sp, mat_t *out)
 {
 	const mat_t *m = &s->mats[sp->mat];
-	if(m->n_nodes <= 0 || (m->type != YOR_MAT_SHINYDIFFUSE && m->type != YOR_MAT_GLOSSY && m->type != YOR_MAT_COATED_GLOSSY)) return m;
+	if(m->n_nodes <= 0 || (m->type != YOR_MAT_SHINYDIFFUSE && m->type != YOR_MAT_GLOSSY && m->type != YOR_MAT_COATED_GLOSSY && m->type != YOR_MAT_GLASS)) return m;
 	node_result_t stack[YOR_MAX_NODES];
 	nodes_eval(m->nodes, m->n_nodes < YOR_MAX_NODES ? m->n_nodes : YOR_MAX_NODES, s->tex, s->n_tex, &s->cam, sp, stack);
 	*out = *m;
+	if(m->type == YOR_MAT_GLASS)
+	{	/* material_glass.cc:87-95,109,121,143-190,223-224,262-300 */
+		if(m->sh_mirror_color >= 0) out->spec_refl_color = C(stack[m->sh_mirror_color].col.r, stack[m->sh_mirror_color].col.g, stack[m->sh_mirror_color].col.b);
+		if(m->sh_filter_color >= 0) out->filter_color = C(stack[m->sh_filter_color].col.r, stack[m->sh_filter_color].col.g, stack[m->sh_filter_color].col.b);
+		if(m->sh_ior >= 0) { out->ior = m->ior_plain + stack[m->sh_ior].f; out->transp_ior = stack[m->sh_ior].f; }      /* :223 sic: not added there */
+		return out;
+	}
 	if(m->type != YOR_MAT_SHINYDIFFUSE)
 	{	/* glossy / coated glossy: every use of a shader is `shader ? shader->get…(stack) : member` (material_glossy.cc:62,144-160,
 		 * material_coated_glossy.cc:78,147-174,253-256,448-451), so the members of a per-hit copy carry them */
@@ -2176,7 +2187,7 @@ static rgb mat_transparency(const mat_t *m, const sp_t *sp, v3 wo)
 	{
 		v3 n = face_forward(sp->ng, sp->n, wo);
 		float kr, kt;
-		fresnel_dielectric(wo, n, m->ior, &kr, &kt);
+		fresnel_dielectric(wo, n, m->transp_ior, &kr, &kt);
 		return cscale(m->filter_color, kt);
 	}
 	return C(0, 0, 0);

@@ -81,7 +81,7 @@ typedef struct yor_material_desc
 	int32_t pad2;
 	const struct yor_node_desc *nodes;
 	float exp_u, exp_v;       /* material_glossy.cc:464-472, material_coated_glossy.cc:529-537 */
-	int32_t sh_glossy, sh_glossy_reflect, sh_exponent, pad3;      /* glossy / coated_glossy slots: glossy_shader, glossy_reflect_shader, exponent_shader */
+	int32_t sh_glossy, sh_glossy_reflect, sh_exponent, sh_filter_color;      /* glossy / coated_glossy slots: glossy_shader, glossy_reflect_shader, exponent_shader; glass: filter_color_shader */
 } yor_material_desc;
 
 /* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has

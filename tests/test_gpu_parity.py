@@ -1063,7 +1063,7 @@ def _texturize(sc, rng):
     texcos = ["uv", "global", "orco", "transformed", "window", "normal"]
     for m in sc["materials"]:
         kind = m.get("type", "shinydiffusemat")
-        if kind not in ("shinydiffusemat", "glossy", "coated_glossy") or rng.random() < 0.4:
+        if kind not in ("shinydiffusemat", "glossy", "coated_glossy", "glass") or rng.random() < 0.4:
             continue
         nodes, k = [], [0]
         def mapper():
@@ -1088,6 +1088,20 @@ def _texturize(sc, rng):
                 nodes.append(top)
                 return top["name"]
             return nd["name"]
+        if kind == "glass":
+            if rng.random() < 0.6:
+                m["filter_color_shader"] = layer(False, 0.0)
+            if rng.random() < 0.5:
+                m["mirror_color_shader"] = layer(False, 0.0)
+            if rng.random() < 0.4:
+                m["IOR_shader"] = layer(True, 0.0)
+                nodes[-1]["valfac"] = float(rng.uniform(0.1, 0.6))
+            if nodes and len(nodes) <= 16:
+                m["nodes"] = nodes
+            else:
+                for key in [key for key in m if key.endswith("_shader")]:
+                    m.pop(key)
+            continue
         if kind != "shinydiffusemat":      # glossy / coated glossy: their own slots
             if rng.random() < 0.6:
                 m["diffuse_shader"] = layer(False, 0.0)

@@ -258,6 +258,31 @@ def test_textured_glossy_and_coated_glossy_match_oracle(integrator, raydepth):
     compare_films(film, ofilm, f"textured glossy / coated glossy, {integrator}", exact_weights=True)
 
 
+@pytest.mark.parametrize("fake_shadows", [False, True])
+def test_textured_glass_matches_oracle(fake_shadows):
+    """shader nodes on glass: mirror colour, filter colour and the IOR offset (material_glass.cc:87-95, 109-121, 262-300) through
+    recursiveRaytrace, and — with fake shadows and transpShad — through getTransparency, whose fresnel sees the IOR shader's value
+    alone (:223)"""
+    sc = _textured_box(specular=False)
+    mapper = lambda name, tex, texco, mapping="plain", **kw: dict(name=name, type="texture_mapper", texture=tex, texco=texco, mapping=mapping, **kw)
+    col = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, colfac=0.6, def_col=(1.0, 0.0, 1.0, 1.0), do_color=True, do_scalar=False,
+                                            color_input=True, upper_color=(0.9, 0.9, 0.9, 1.0), upper_value=0.0), **kw)
+    val = lambda name, inp, upper, fac: dict(name=name, type="layer", input=inp, mode=0, valfac=fac, def_val=1.0, do_color=False, do_scalar=True, color_input=True,
+                                             upper_value=upper)
+    sc["materials"][4] = {"type": "glass", "IOR": 1.3, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.7, "mirror_color": (0.95, 0.9, 1.0), "fake_shadows": fake_shadows,
+                          "mirror_color_shader": "mcol", "filter_color_shader": "fcol", "IOR_shader": "ior",
+                          "nodes": [col("mcol", "m_uv"), col("fcol", "m_orco", mode=1), val("ior", "m_uv", 1.3 if fake_shadows else 0.0, 0.4),
+                                    mapper("m_uv", "t_rgb", "uv"), mapper("m_orco", "t_adj", "orco", "cube")]}
+    rd = scenes.render_settings(48, 40, 3, integrator="pathtracing", bounces=2, raydepth=3, transpShad=fake_shadows, shadowDepth=3)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(48, 40), yi.getRenderStats()
+    ofilm, ost = po.OracleScene(sc).render(rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"textured glass, fake shadows {fake_shadows}", exact_weights=True)
+
+
 def test_test01_with_its_textures_against_the_references_expected_png():
     """The reference's shipped test scene with the textures this build decodes (TGA, HDR, PNG; tests/golden/test01_tex.xml) rendered
     on the device through the product's XML loader, (a) against the oracle given the same decoded texels, and (b) against the

@@ -73,6 +73,9 @@ typedef struct yafgpu_material
 	int32_t sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int32_t sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader (material_glossy.cc:504-511) */
 	int32_t sh_filter_color;       /* glass: filter_color_shader (material_glass.cc:419-422) */
+	int32_t additional_depth;      /* Material::additional_depth_: recursiveRaytrace may go this much deeper below this material (integrator_montecarlo.cc:791) */
+	float transp_bias_factor;      /* shinydiffusemat transparentbias_factor / transparentbias_multiply_raydepth (integrator_montecarlo.cc:1003-1011) */
+	int32_t transp_bias_mult;
 	float transp_ior;              /* glass: the index getTransparency's fresnel sees — ior_, or the IOR shader's value alone (material_glass.cc:223, sic) */
 	float ior_base;                /* ior_ (the IOR shader adds to it, :258-262; coated_glossy: material_coated_glossy.cc:147) */
 	float emit_strength;           /* emit_strength_ (emit() with a diffuse shader: colour * emit_strength_, :300) */

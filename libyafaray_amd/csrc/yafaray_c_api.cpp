@@ -370,13 +370,11 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	p.get("transmit_filter", transmit_filter); p.get("receive_shadows", recv); p.get("flat_material", flat);
 	p.get("visibility", vis); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "shinydiffusemat: wireframe shading is not supported by the GPU path");
-	{	// parameters of recursiveRaytrace the device path does not honour (integrator_montecarlo.cc:791, :1003-1014): refuse them
-		// rather than render something else.  (`samplingfactor` only feeds a debug render pass, integrator_tiled.cc:597.)
-		int add_depth = 0; float tb_factor = 0.f; bool tb_mult = false;
-		p.get("additionaldepth", add_depth); p.get("transparentbias_factor", tb_factor); p.get("transparentbias_multiply_raydepth", tb_mult);
-		if(add_depth != 0) return fail(yi, "shinydiffusemat: additionaldepth is not supported by the GPU path");
-		if(tb_factor != 0.f || tb_mult) return fail(yi, "shinydiffusemat: transparentbias_factor / transparentbias_multiply_raydepth are not supported by the GPU path");
-	}
+	// recursiveRaytrace's per-material parameters (integrator_montecarlo.cc:791, :1003-1014).  (`samplingfactor` only feeds a debug
+	// render pass, integrator_tiled.cc:597.)
+	int add_depth = 0; float tb_factor = 0.f; bool tb_mult = false;
+	p.get("additionaldepth", add_depth); p.get("transparentbias_factor", tb_factor); p.get("transparentbias_multiply_raydepth", tb_mult);
+	if(add_depth < 0 || add_depth > 7) return fail(yi, "shinydiffusemat: additionaldepth outside [0, 7]: the device path keeps at most 7 recursion frames per sample");
 	// shader nodes, material_shiny_diffuse.cc:692-747: slots in the order of yafgpu_material's sh_* fields
 	enum { kDiffuse, kMirrorColor, kMirror, kTransparency, kTranslucency, kSigmaOren, kDiffuseRefl, kIor, kBump, kWireframe, kSlots };
 	int slots[kSlots]; for(int &v : slots) v = -1;
@@ -404,6 +402,7 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	m.sh_diffuse = slots[kDiffuse]; m.sh_mirror_color = slots[kMirrorColor]; m.sh_mirror = slots[kMirror]; m.sh_transparency = slots[kTransparency];
 	m.sh_translucency = slots[kTranslucency]; m.sh_sigma_oren = slots[kSigmaOren]; m.sh_diffuse_refl = slots[kDiffuseRefl]; m.sh_ior = slots[kIor];
 	m.ior_base = ior; m.emit_strength = emit;
+	m.additional_depth = add_depth; m.transp_bias_factor = tb_factor; m.transp_bias_mult = tb_mult ? 1 : 0;
 	m.type = YAFGPU_MAT_SHINYDIFFUSE; m.visibility = visibility_from(vis); m.receive_shadows = recv; m.flat = flat;
 	for(int k = 0; k < 3; ++k) { m.diffuse_color[k] = color[k]; m.mirror_color[k] = mirror_color[k]; m.emit_color[k] = emit * color[k]; }
 	m.diffuse_strength = diffuse; m.transparency_strength = transp; m.translucency_strength = transl; m.mirror_strength = mirror;
@@ -494,10 +493,12 @@ bool make_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, s
 	p.get("as_diffuse", as_diff); p.get("exponent", exponent); p.get("anisotropic", aniso);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "glossy: wireframe shading is not supported by the GPU path");
-	{ int add_depth = 0; p.get("additionaldepth", add_depth); if(add_depth != 0) return fail(yi, "glossy: additionaldepth is not supported by the GPU path"); }
+	int add_depth = 0; p.get("additionaldepth", add_depth);
+	if(add_depth < 0 || add_depth > 7) return fail(yi, "glossy: additionaldepth outside [0, 7]: the device path keeps at most 7 recursion frames per sample");
 	std::memset(&m, 0, sizeof m);
 	if(!glossy_nodes(yi, p, "glossy", false, m, nodes)) return false;
 	m.type = YAFGPU_MAT_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
+	m.additional_depth = add_depth;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; }
 	m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
 	if(aniso)
@@ -544,12 +545,13 @@ bool make_coated_glossy(yafaray_interface *yi, const ParamMap &p, yafgpu_materia
 	p.getColor("mirror_color", mcol); p.get("specular_reflect", mirror);
 	p.get("receive_shadows", recv); p.get("visibility", vis); p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire);
 	if(wire != 0.f) return fail(yi, "coated_glossy: wireframe shading is not supported by the GPU path");
-	if(add_depth != 0) return fail(yi, "coated_glossy: additionaldepth is not supported by the GPU path");
+	if(add_depth < 0 || add_depth > 7) return fail(yi, "coated_glossy: additionaldepth outside [0, 7]: the device path keeps at most 7 recursion frames per sample");
 	if(ior == 1.0) ior = 1.0000001f;                                // :512
 	std::memset(&m, 0, sizeof m);
 	if(!glossy_nodes(yi, p, "coated_glossy", true, m, nodes)) return false;
 	m.ior_base = (float)ior;
 	m.type = YAFGPU_MAT_COATED_GLOSSY; m.visibility = visibility_from(vis); m.receive_shadows = recv;
+	m.additional_depth = add_depth;
 	for(int k = 0; k < 3; ++k) { m.gloss_color[k] = col[k]; m.diff_color[k] = dcol[k]; m.mirror_color[k] = mcol[k]; }
 	m.mirror_strength = mirror; m.glass_ior = (float)ior; m.exponent = exponent; m.reflectivity = refl; m.diffuse = diff; m.as_diffuse = as_diff;
 	if(aniso)
@@ -581,7 +583,7 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, st
 	p.get("dispersion_power", disp); p.get("fake_shadows", fake); p.get("receive_shadows", recv); p.get("visibility", vis);
 	p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire); p.getColor("absorption", absorp);
 	if(disp > 0.0) return fail(yi, "glass: dispersion is not supported by the GPU path (recursiveRaytrace's dispersive branch)");
-	if(add_depth != 0) return fail(yi, "glass: additionaldepth is not supported by the GPU path");
+	if(add_depth < 0 || add_depth > 7) return fail(yi, "glass: additionaldepth outside [0, 7]: the device path keeps at most 7 recursion frames per sample");
 	if(wire != 0.f) return fail(yi, "glass: wireframe shading is not supported by the GPU path");
 	std::memset(&m, 0, sizeof m);
 	clear_shader_slots(m);
@@ -608,6 +610,7 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, st
 	}
 	m.ior_base = (float)ior; m.transp_ior = (float)ior;
 	m.type = YAFGPU_MAT_GLASS; m.receive_shadows = recv; m.visibility = visibility_from(vis);
+	m.additional_depth = add_depth;
 	m.glass_ior = (float)ior;
 	const float ff = (float)filt, fc = (float)(1.f - filt);       // filt * filt_col + Rgb(1.f - filt)
 	for(int k = 0; k < 3; ++k) { m.filter_color[k] = ff * fcol[k] + fc; m.mirror_color[k] = scol[k]; }

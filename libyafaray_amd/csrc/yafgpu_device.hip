@@ -1091,6 +1091,7 @@ struct yafgpu_scene
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
+	int max_add_depth = 0;               // the largest Material::additional_depth_ of the scene: recursion frames beyond raydepth
 	bool has_glossy = false;             // some material has a glossy lobe that recursiveRaytrace samples (glossy / coated_glossy with as_diffuse off): 12-record frames
 	bool has_aniso = false;              // some material has the anisotropic glossy lobe: the general shading kernel
 	bool has_textures = false;           // some material in use has shader nodes: the general shading kernel, texture coordinates parked per path
@@ -1190,6 +1191,7 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 	auto *s = new yafgpu_scene();
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].anisotropic) s->has_aniso = true;
+	for(int i = 0; i < d->n_materials; ++i) s->max_add_depth = std::max(s->max_add_depth, std::min(std::max(d->materials[i].additional_depth, 0), 15));
 	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & kGlossy) s->has_glossy = true;
 	{	// material types some triangle actually uses (a definition nothing refers to does not cost a kernel variant)
 		std::vector<char> used((size_t)d->n_materials, 0);
@@ -1585,9 +1587,9 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	uint32_t max_paths = kWfMaxPaths;
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
-	const int frames = ((s->has_specular || s->has_glossy) && rp.raydepth > 0) ? rp.raydepth : 0;
+	const int frames = ((s->has_specular || s->has_glossy) && rp.raydepth + s->max_add_depth > 0) ? rp.raydepth + s->max_add_depth : 0;
 	const int frame_recs = s->has_glossy ? 12 : 5;
-	if(frames > 7) return fail(-17, "raydepth > 7 with mirror / transparent materials: the device path keeps at most 7 recursion frames per sample");
+	if(frames > 7) return fail(-17, "raydepth + additionaldepth > 7 with mirror / transparent / glossy-recursive materials: the device path keeps at most 7 recursion frames per sample");
 	// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
 	// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
 	// (more than one light).  Not with recursiveRaytrace frames (a sample's events are then a tree, not a list: the
@@ -1971,7 +1973,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(s->dev.cam.aperture != 0.f) return fail(-15, "the one-kernel pipeline has the pinhole camera only; use the wavefront pipeline");
 		// transpShad changes which hits occlude even without a transparent material (intersectTs skips hits before tmin_)
 		if(rp->transp_shad) return fail(-15, "the one-kernel pipeline has no transparent shadows (transpShad); use the wavefront pipeline");
-		if((s->has_specular || s->has_glossy) && rp->raydepth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent / glossy-recursive materials");
+		if((s->has_specular || s->has_glossy) && rp->raydepth + s->max_add_depth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent / glossy-recursive materials");
 		if(s->has_textures) return fail(-15, "the one-kernel pipeline has no shader nodes / textures; use the wavefront pipeline");
 		if(rp->serial_replay && rp->integrator == YAFGPU_INTEGRATOR_PATH && (rp->bounces - 1 > rp->rr_min_bounces || s->n_lights > 1))
 			return fail(-15, "the one-kernel pipeline cannot replay the reference's serial state (Russian roulette stream, light counter); use the wavefront pipeline or switch the replay off");

@@ -208,15 +208,15 @@ YG_DEV const yafgpu_material &wf_mat_parked(const WfArgs &a, uint32_t slot, int 
 	return m;
 }
 
-struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl; };   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_
-YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.incl << 16) | ((uint32_t)c.path_i << 17); }
+struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl, add; };   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_; add: integrate()'s additional_depth
+YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.add << 12) | ((uint32_t)c.incl << 16) | ((uint32_t)c.path_i << 17); }
 YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 {
 	const float4 r = REC(13);
 	const uint32_t w = ubits(r.w);
 	Ctl c; c.col = c3(r);
 	c.pc = (int)(w & 3u); c.stage = (int)((w >> 2) & 3u); c.dl_on_sp0 = (int)((w >> 4) & 1u); c.level = (int)((w >> 5) & 7u);
-	c.depth = (int)((w >> 8) & 0xffu); c.incl = (int)((w >> 16) & 1u); c.path_i = (int)(w >> 17);
+	c.depth = (int)((w >> 8) & 0xfu); c.add = (int)((w >> 12) & 0xfu); c.incl = (int)((w >> 16) & 1u); c.path_i = (int)(w >> 17);      // depth < bounces <= 12
 	return c;
 }
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
@@ -329,6 +329,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		if(YAFGPU_FEAT_TEXTURE && sc.tex.nodes != nullptr) REC(22) = make_float4(fbits((uint32_t)tri), ans.z, ans.w, 0.f);
 		BsdfDat dat0;
 		const uint32_t bsdfs0 = mat_init_bsdf(m, dat0);
+		if(YAFGPU_FEAT_RECURSE) c.add = max(c.add, min(m.additional_depth, 15));                 // integrator_path_tracer.cc:149
 		const V3 wo0 = -dir;
 		if(bsdfs0 & kEmit) c.col = c.col + mat_emit(m, sp0, wo0, c.incl != 0);                // :152 (include_lights_ :133)
 		alpha = 1.f;
@@ -675,6 +676,14 @@ YG_DEV void wf_start_level(const WfArgs &a, uint32_t slot, Ctl &c, V3 p, V3 dir)
 	REC(0) = f4(p, a.ra.ray_min_dist); REC(1) = f4(dir, -1.f);      // DiffRay(sp.p_, dir, scene_->ray_min_dist_)
 	c.stage = kStPrimary; c.depth = 0; c.path_i = 0; c.dl_on_sp0 = 0;
 }
+// the transmitted ray's origin: pushed along the ray by the material's transparent bias (integrator_montecarlo.cc:1003-1011)
+YG_DEV V3 wf_transp_origin(const yafgpu_material &m, V3 p, V3 dir, int raylevel)
+{
+	float f = m.transp_bias_factor;
+	if(!(f > 0.f)) return p;
+	if(m.transp_bias_mult) f *= (float)raylevel;
+	return p + dir * f;
+}
 // recursiveRaytrace's perfect specular branch (:971-1025) at level c.level, whose working records hold the level's hit
 YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 {
@@ -706,10 +715,10 @@ YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 	uint32_t vol = 0u;
 	if((ubits(r5.w) & kVolumetric) && m.has_vol_i)
 		vol = (refl && dot(sp0.ng, d_refl) < 0.f ? 4u : 0u) | (refr && dot(sp0.ng, d_refr) < 0.f ? 8u : 0u);
-	FREC(L, 2) = f4(sp0.p, fbits((refl ? (refr ? 1u : 0u) : 2u) | vol));
+	FREC(L, 2) = f4(sp0.p, fbits((refl ? (refr ? 1u : 0u) : 2u) | vol | ((uint32_t)c.add << 8)));      // bits 8-11: this level's additional depth (a level below may raise its own)
 	FREC(L, 3) = f4(d_refr, 0.f);                              // .w: the tmax_ of the ray that is out (st_after_closest)
 	FREC(L, 4) = f4(c_refl, fbits((uint32_t)sp0.mat));
-	wf_start_level(a, slot, c, sp0.p, refl ? d_refl : d_refr);
+	wf_start_level(a, slot, c, refl ? sp0.p : wf_transp_origin(sc.mats[sp0.mat], sp0.p, d_refr, L + 1), refl ? d_refl : d_refr);
 	c.level = L + 1;
 	return W_PARK_CLOSEST;
 }
@@ -724,7 +733,7 @@ YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
 	const DivState dv = wf_div(a, slot, L);
 	const int gsam = dv.division > 1 ? max(1, 8 / dv.division) : 8;
 	FREC(L, 0) = f4(c.col, REC(19).w);
-	FREC(L, 2) = f4(v3(r3), fbits(16u));
+	FREC(L, 2) = f4(v3(r3), fbits(16u | ((uint32_t)c.add << 8)));
 	FREC(L, 6) = f4(v3(REC(4)), fbits((uint32_t)gsam << 8));
 	FREC(L, 7) = r5;
 	FREC(L, 8) = REC(6);
@@ -773,7 +782,7 @@ YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel
 YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 {
 	const yafgpu_render_params &rp = a.ra.rp;
-	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth || c.level >= a.frames) return W_RETURN;          // :791 (additional depth 0)
+	if(!YAFGPU_FEAT_RECURSE || c.level + 1 > rp.raydepth + c.add || c.level >= a.frames) return W_RETURN;          // :791
 	if(a.has_glossy && (ubits(REC(5).w) & kGlossy)) return st_glossy_begin(a, slot, c);
 	return W_RECURSE_SPEC;
 }
@@ -790,6 +799,7 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 		const float4 f0 = FREC(P, 0), f2 = FREC(P, 2);
 		const uint32_t flags = ubits(f2.w);
 		Col integ = c.col;
+		c.add = (int)((flags >> 8) & 0xfu);            // back in the level above: its own additional depth
 		if(flags & 16u)
 		{	// a trajectory of the glossy loop is back: gcol += integ * mcol * w (:918), then the next one or the loop's end (:958)
 			const float4 f9 = FREC(P, 9), f10 = FREC(P, 10), f6 = FREC(P, 6);
@@ -820,8 +830,8 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 			if(flags & 1u)
 			{	// :991-1023 now the transmitted one, at the same level
 				FREC(P, 0) = f4(col_p, f0.w);
-				FREC(P, 2) = f4(v3(f2), fbits(2u | (flags & 8u)));
-				wf_start_level(a, slot, c, v3(f2), v3(FREC(P, 3)));
+				FREC(P, 2) = f4(v3(f2), fbits(2u | (flags & 8u) | (flags & 0xf00u)));
+				wf_start_level(a, slot, c, wf_transp_origin(a.ra.sc.mats[ubits(FREC(P, 4).w)], v3(f2), v3(FREC(P, 3)), P + 1), v3(FREC(P, 3)));
 				return W_PARK_CLOSEST;
 			}
 			c.col = col_p; alpha = f0.w;

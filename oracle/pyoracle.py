@@ -39,6 +39,7 @@ class MaterialDesc(C.Structure):
         ("pad2", C.c_int32), ("nodes", C.c_void_p),
         ("exp_u", C.c_float), ("exp_v", C.c_float),
         ("sh_glossy", C.c_int32), ("sh_glossy_reflect", C.c_int32), ("sh_exponent", C.c_int32), ("sh_filter_color", C.c_int32),
+        ("additional_depth", C.c_int32), ("transp_bias_factor", C.c_float), ("transp_bias_mult", C.c_int32), ("pad4", C.c_int32),
     ]
 
 
@@ -372,6 +373,11 @@ def material_desc(m):
         raise ValueError(t)
     d.sh_diffuse = d.sh_mirror_color = d.sh_mirror = d.sh_transparency = d.sh_translucency = d.sh_sigma_oren = d.sh_diffuse_refl = d.sh_ior = -1
     d.sh_glossy = d.sh_glossy_reflect = d.sh_exponent = d.sh_filter_color = -1
+    if t in ("shinydiffusemat", "glossy", "coated_glossy", "glass"):
+        d.additional_depth = m.get("additionaldepth", 0)
+    if t == "shinydiffusemat":
+        d.transp_bias_factor = m.get("transparentbias_factor", 0.0)
+        d.transp_bias_mult = int(m.get("transparentbias_multiply_raydepth", False))
     return d
 
 

@@ -454,6 +454,7 @@ typedef struct
 	int n_nodes; struct node_s *nodes;
 	int sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader */
+	int additional_depth; float transp_bias_factor; int transp_bias_mult;      /* Material::additional_depth_, transparent_bias_* (material.h) */
 	int sh_filter_color; float transp_ior;             /* glass: filter_color_shader; the index getTransparency's fresnel sees (:223: the IOR shader's value alone) */
 	float ior_plain;                                   /* coated_glossy: ior_ before the IOR shader's offset */
 	float ior_base;                       /* ior_, for the IOR shader (material_shiny_diffuse.cc:258-262) */
@@ -1563,7 +1564,13 @@ static void mat_copy_nodes(mat_t *m, const yor_material_desc *d)      /* glossy 
 		                               m->sh_mirror_color = d->sh_mirror_color; m->sh_filter_color = d->sh_filter_color; m->sh_ior = d->sh_ior; }   /* material_glass.cc:419-422 */
 	}
 }
+static void mat_configure_(mat_t *m, const yor_material_desc *d);
 static void mat_configure(mat_t *m, const yor_material_desc *d)
+{
+	mat_configure_(m, d);
+	m->additional_depth = d->additional_depth; m->transp_bias_factor = d->transp_bias_factor; m->transp_bias_mult = d->transp_bias_mult;
+}
+static void mat_configure_(mat_t *m, const yor_material_desc *d)
 {
 	memset(m, 0, sizeof *m);
 	m->type = d->type; m->visibility = d->visibility; m->receive_shadows = d->receive_shadows; m->flat = d->flat_material;
@@ -3134,7 +3141,13 @@ static rgb estimate_one_direct_light(rstate_t *st, const sp_t *sp, const mat_t *
 /* PathIntegrator::integrate, integrator_path_tracer.cc:112-347 (raylevel 0, no caustics, no
  * recursive raytrace: materials with specular/glossy/filter lobes are rejected by yor_render) */
 /* ray_tmax_out (may be NULL): the ray's tmax_ after the call, i.e. the distance to the first hit or the caller's tmax on a miss */
+static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, int additional_depth, float out_rgba[4], float *ray_tmax_out);
 static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, float out_rgba[4], float *ray_tmax_out)
+{
+	integrate_d(st, from, dir, tmin, tmax, raylevel, 0, out_rgba, ray_tmax_out);
+}
+/* additional_depth: integrate()'s parameter of that name (integrator_path_tracer.cc:112,149): the largest Material::additional_depth_ met on the way down */
+static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int raylevel, int additional_depth, float out_rgba[4], float *ray_tmax_out)
 {
 	const yor_scene *s = st->s;
 	const yor_render_desc *rd = st->rd;
@@ -3151,6 +3164,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		bsdf_dat dat0;
 		mat_t mat_here; const mat_t *material = mat_resolve(s, &sp, &mat_here);
 		mat_init_bsdf(material, &dat0, &bsdfs);
+		if(additional_depth < material->additional_depth) additional_depth = material->additional_depth;     /* :149 */
 		v3 wo = vneg(dir);
 		if(bsdfs & BSDF_EMIT) col = cadd(col, mat_emit(material, &sp, wo, st->include_lights));
 		if(bsdfs & BSDF_DIFFUSE) col = cadd(col, estimate_all_direct_light(st, &sp, material, &dat0, wo));
@@ -3226,7 +3240,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 		 * or glossy-recursive materials on this path, additional depth and transparent bias 0 */
 		/* the glossy branch, :861-972: gsam trajectories through the glossy lobe, each a full integrate() one level down with the
 		 * trajectory-splitting state set (materials here reflect only: the Reflect && !Transmit case, :897-918) */
-		if(raylevel + 1 <= rd->raydepth && (bsdfs & BSDF_GLOSSY) && raylevel + 1 < 20)
+		if(raylevel + 1 <= rd->raydepth + additional_depth && (bsdfs & BSDF_GLOSSY) && raylevel + 1 < 20)
 		{
 			st->include_lights = 1;
 			int gsam = 8;
@@ -3256,7 +3270,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 					sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.flags = BSDF_GLOSSY | BSDF_REFLECT; sm.sampled_flags = BSDF_NONE;
 					rgb mcol = mat_sample(material, &dat0, &sp, wo, &wi, &sm, &gw);
 					float integ[4], ref_tmax;
-					integrate(st, sp.p, wi, st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+					integrate_d(st, sp.p, wi, st->ray_min_dist, -1.0f, raylevel + 1, additional_depth, integ, &ref_tmax);
 					rgb ic = C(integ[0], integ[1], integ[2]);
 					if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, wi) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
 					gcol = cadd(gcol, cscale(cmul(ic, mcol), gw));
@@ -3265,7 +3279,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 			col = cadd(col, cscale(gcol, d_1));
 			st->ray_division = old_division; st->ray_offset = old_offset; st->dc_1 = old_dc_1; st->dc_2 = old_dc_2;
 		}
-		if(raylevel + 1 <= rd->raydepth && (bsdfs & (BSDF_SPECULAR | BSDF_FILTER)) && raylevel + 1 < 20)
+		if(raylevel + 1 <= rd->raydepth + additional_depth && (bsdfs & (BSDF_SPECULAR | BSDF_FILTER)) && raylevel + 1 < 20)
 		{
 			st->include_lights = 1;
 			int reflect = 0, refract = 0;
@@ -3274,7 +3288,7 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 			if(reflect)
 			{
 				float integ[4], ref_tmax;
-				integrate(st, sp.p, sdir[0], st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+				integrate_d(st, sp.p, sdir[0], st->ray_min_dist, -1.0f, raylevel + 1, additional_depth, integ, &ref_tmax);
 				rgb ic = C(integ[0], integ[1], integ[2]);
 				/* :991-994 vol = material->getVolumeHandler(sp.ng_ * ref_ray.dir_ < 0); integ *= vcol */
 				if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, sdir[0]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
@@ -3283,7 +3297,14 @@ static void integrate(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, int
 			if(refract)
 			{
 				float integ[4], ref_tmax;
-				integrate(st, sp.p, sdir[1], st->ray_min_dist, -1.0f, raylevel + 1, integ, &ref_tmax);
+				v3 r_from = sp.p;
+				float transp_bias_factor = material->transp_bias_factor;                     /* :1003-1011 */
+				if(transp_bias_factor > 0.f)
+				{
+					if(material->transp_bias_mult) transp_bias_factor *= (float)(raylevel + 1);
+					r_from = vadd(sp.p, vmul(sdir[1], transp_bias_factor));
+				}
+				integrate_d(st, r_from, sdir[1], st->ray_min_dist, -1.0f, raylevel + 1, additional_depth, integ, &ref_tmax);
 				rgb ic = C(integ[0], integ[1], integ[2]);
 				if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, sdir[1]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax)); /* :1016-1019 */
 				col = cadd(col, cmul(ic, rcol[1]));

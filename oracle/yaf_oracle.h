@@ -82,6 +82,9 @@ typedef struct yor_material_desc
 	const struct yor_node_desc *nodes;
 	float exp_u, exp_v;       /* material_glossy.cc:464-472, material_coated_glossy.cc:529-537 */
 	int32_t sh_glossy, sh_glossy_reflect, sh_exponent, sh_filter_color;      /* glossy / coated_glossy slots: glossy_shader, glossy_reflect_shader, exponent_shader; glass: filter_color_shader */
+	int32_t additional_depth;  /* "additionaldepth": recursiveRaytrace may go this much deeper below this material (integrator_montecarlo.cc:791) */
+	float transp_bias_factor;  /* shinydiffusemat "transparentbias_factor" / "transparentbias_multiply_raydepth" (:1003-1011) */
+	int32_t transp_bias_mult, pad4;
 } yor_material_desc;
 
 /* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has

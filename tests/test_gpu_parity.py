@@ -793,6 +793,35 @@ def test_glossy_branch_of_recursive_raytrace(raydepth, integrator, pipeline):
     compare_films(film, ofilm, f"glossy branch raydepth {raydepth} {integrator}")
 
 
+@pytest.mark.parametrize("raydepth", [0, 1, 2])
+def test_additional_depth_and_transparent_bias(raydepth, pipeline):
+    """Material::additional_depth_ (integrate() carries the largest one met on the way down and recursiveRaytrace goes that much
+    deeper below it, integrator_path_tracer.cc:149, integrator_montecarlo.cc:791) on glass, shinydiffuse and glossy, and
+    shinydiffusemat's transparent bias (the transmitted ray starts `factor` [x raylevel] along its direction, :1003-1011)."""
+    if pipeline == "megakernel":
+        pytest.skip("the one-kernel pipeline has no recursiveRaytrace")
+    sc = scenes.cornell_soup(260, seed=47, res=(40, 32), sigma=0.08)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6, "additionaldepth": 2})
+    sc["materials"].append({"type": "shinydiffusemat", "color": (0.5, 0.7, 0.9), "diffuse_reflect": 0.6, "transparency": 0.7, "transmit_filter": 0.8,
+                            "additionaldepth": 1, "transparentbias_factor": 0.01, "transparentbias_multiply_raydepth": True})
+    sc["materials"].append({"type": "shinydiffusemat", "color": (0.9, 0.7, 0.5), "diffuse_reflect": 0.7, "transparency": 0.5, "specular_reflect": 0.3,
+                            "transparentbias_factor": 0.02})
+    sc["materials"].append({"type": "glossy", "color": (0.9, 0.9, 0.9), "glossy_reflect": 0.8, "exponent": 100.0, "as_diffuse": False, "additionaldepth": 1})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[4:6] = nm - 1                                                   # back wall glossy
+    free = np.arange(10, len(tm)); tm[free[0::4]] = nm - 4; tm[free[1::4]] = nm - 3; tm[free[2::5]] = nm - 2
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(40, 32, 3, bounces=2, raydepth=raydepth, path_samples=2)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"additional depth / transparent bias, raydepth {raydepth}")
+    yi = Interface(strict=False)
+    scenes.load_scene(yi, sc, dict(rd, raydepth=6))
+    assert not yi.render() and "7" in yi.getLastError(), yi.getLastError()          # 6 + 2 frames
+
+
 def test_light_count_and_sample_count_limits(pipeline):
     """The light-estimate bookkeeping packs the light index in 8 bits and the sample index in 12: 255 lights render and equal
     the oracle, 256 are refused; an area light asking for more than 4095 samples per estimate is refused."""

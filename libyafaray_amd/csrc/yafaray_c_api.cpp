@@ -215,6 +215,7 @@ struct LoadedNodes
 // material_shiny_diffuse.cc:709-713), 0 = refused by the GPU path (err set), 1 = loaded
 int load_nodes(yafaray_interface *yi, const std::list<ParamMap> &list, LoadedNodes &out)
 {
+	if(list.size() > 4096) { fail(yi, "shader nodes: more than 4096 nodes in one material's list"); return 0; }      // (sort_nodes walks the graph recursively)
 	std::vector<const ParamMap *> maps;
 	for(const ParamMap &pm : list)
 	{	// NodeMaterial::loadNodes, material_node.cc:150-205
@@ -1445,6 +1446,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(any_nodes)
 		for(auto *t : yi->texture_order)
 		{
+			if((texels.size() + t->texels.size()) / 4 > 0xffffffffull) return fail(yi, "render: more than 2^32 texels in the scene's image textures");
 			yafgpu_texture rec = t->t;
 			rec.texel_first = (uint32_t)(texels.size() / 4);
 			texels.insert(texels.end(), t->texels.begin(), t->texels.end());

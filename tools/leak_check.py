@@ -18,3 +18,13 @@ for rnd in range(6):
     yi.render()
     yi.close(); del planes
     print("round %d: free %.0f MB, rss %.0f MB" % (rnd, free_mb(), rss_mb()), flush=True)
+# round 2: textured scenes, the serial-state replay (two lights, roulette on) and glossy-recursive frames
+import tests.test_gpu_parity as T
+for rnd in range(6):
+    for seed in (5, 9, 13, 21, 40, 44, 61):
+        sc, rd, w, h, base, kw = T._feature_mix(seed)
+        yi = Interface(); scenes.load_scene(yi, sc, rd); yi.render(); yi.close()
+    sc = scenes.cornell_soup(20000, seed=7, res=(128, 128), n_lights=2, glossy_fraction=0.3)
+    rd = scenes.render_settings(128, 128, 8, bounces=4, russian_roulette_min_bounces=1)
+    yi = Interface(); scenes.load_scene(yi, sc, rd); yi.render(); yi.close()
+    print("round2 %d: free %.0f MB, rss %.0f MB" % (rnd, free_mb(), rss_mb()), flush=True)

@@ -73,6 +73,8 @@ typedef struct yafgpu_material
 	int32_t sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int32_t sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader (material_glossy.cc:504-511) */
 	int32_t sh_filter_color;       /* glass: filter_color_shader (material_glass.cc:419-422) */
+	int32_t bump_first, n_bump, sh_bump;   /* bump mapping: nodes[bump_first .. bump_first + n_bump) = what the bump shader reaches, in evaluation order
+	                                          (NodeMaterial::evalBump, material_node.cc:132-139); sh_bump its index in that range; n_bump 0 = none */
 	int32_t additional_depth;      /* Material::additional_depth_: recursiveRaytrace may go this much deeper below this material (integrator_montecarlo.cc:791) */
 	float transp_bias_factor;      /* shinydiffusemat transparentbias_factor / transparentbias_multiply_raydepth (integrator_montecarlo.cc:1003-1011) */
 	int32_t transp_bias_mult;
@@ -123,6 +125,9 @@ typedef struct yafgpu_node
 	float colfac, valfac, def_val, upper_val;
 	float def_col[4], upper_col[4];
 	int32_t do_color, do_scalar_l, color_input, use_alpha;
+	/* bump mapping (texture_mapper): what TextureMapperNode::setup leaves (shader_node_basic.cc:34-59): the texel steps 1 / width, 1 / height and
+	   bump_strength / |scale| / 100 */
+	float d_u, d_v, bump_str;
 } yafgpu_node;
 
 /* A light after its constructor ran on the host (light_area.cc:34-52, light_point.cc:28-36) */

@@ -200,6 +200,7 @@ inline void clear_shader_slots(yafgpu_material &m)
 	m.node_first = 0; m.n_nodes = 0;
 	m.sh_diffuse = m.sh_mirror_color = m.sh_mirror = m.sh_transparency = m.sh_translucency = m.sh_sigma_oren = m.sh_diffuse_refl = m.sh_ior = -1;
 	m.sh_glossy = m.sh_glossy_reflect = m.sh_exponent = m.sh_filter_color = -1;
+	m.bump_first = 0; m.n_bump = 0; m.sh_bump = -1;
 }
 
 constexpr int kMaxMaterialNodes = 16;    // yafgpu_texture.h kMaxNodes: the per-lane node stack of the shading kernels
@@ -255,6 +256,14 @@ int load_nodes(yafaray_interface *yi, const std::list<ParamMap> &list, LoadedNod
 			n.map_x = map[0]; n.map_y = map[1]; n.map_z = map[2];
 			for(int k = 0; k < 3; ++k) { n.scale[k] = scale[k]; n.offset[k] = 2 * offset[k]; }
 			n.do_scalar = scalar ? 1 : 0;
+			{	// setup(), shader_node_basic.cc:34-59 (image textures are discrete; normal maps are refused at createTexture)
+				float bump_str = 1.f; pm.get("bump_strength", bump_str);
+				const yafgpu_texture &t = tex->second->t;
+				n.d_u = 1.f / (float)t.width; n.d_v = 1.f / (float)t.height;
+				bump_str /= std::sqrt(scale[0] * scale[0] + scale[1] * scale[1] + scale[2] * scale[2]);
+				bump_str /= 100.0f;
+				n.bump_str = bump_str;
+			}
 		}
 		else if(type == "value")
 		{
@@ -357,6 +366,20 @@ bool sort_nodes(yafaray_interface *yi, const LoadedNodes &ld, int *slots, int n_
 	return true;
 }
 
+// NodeMaterial's bump_nodes_ (getNodeList(bump_shader_, bump_nodes_), material_shiny_diffuse.cc:746, material_glossy.cc:545, ...): what the
+// bump shader reaches, in evaluation order, kept behind the material's colour nodes.  first / count / slot: relative to `nodes`.
+struct BumpList { int first = 0, count = 0, slot = -1; };
+bool append_bump_nodes(yafaray_interface *yi, const LoadedNodes &ld, int bump_slot, std::vector<yafgpu_node> &nodes, BumpList &out)
+{
+	out = BumpList();
+	if(bump_slot < 0) return true;
+	std::vector<yafgpu_node> bump; int slot[1] = {bump_slot};
+	if(!sort_nodes(yi, ld, slot, 1, bump)) return false;
+	out.first = (int)nodes.size(); out.count = (int)bump.size(); out.slot = slot[0];
+	nodes.insert(nodes.end(), bump.begin(), bump.end());
+	return true;
+}
+
 // ShinyDiffuseMaterial::factory + ctor + config, material_shiny_diffuse.cc:599-690, :26-36, :46-92
 bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
 {
@@ -379,6 +402,7 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 	// shader nodes, material_shiny_diffuse.cc:692-747: slots in the order of yafgpu_material's sh_* fields
 	enum { kDiffuse, kMirrorColor, kMirror, kTransparency, kTranslucency, kSigmaOren, kDiffuseRefl, kIor, kBump, kWireframe, kSlots };
 	int slots[kSlots]; for(int &v : slots) v = -1;
+	int n_color_nodes = 0; BumpList bump;
 	nodes.clear();
 	if(!yi->eparams.empty())
 	{
@@ -391,15 +415,17 @@ bool make_shinydiffuse(yafaray_interface *yi, const ParamMap &p, yafgpu_material
 			                                    "sigma_oren_shader", "diffuse_refl_shader", "IOR_shader", "bump_shader", "wireframe_shader"};
 			std::string node;
 			for(int k = 0; k < kSlots; ++k) if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
-			if(slots[kBump] >= 0) return fail(yi, "shinydiffusemat: bump_shader (bump / normal mapping) is not supported by the GPU path");
 			if(slots[kWireframe] >= 0) return fail(yi, "shinydiffusemat: wireframe_shader is not supported by the GPU path");
+			const int bump_slot = slots[kBump]; slots[kBump] = -1;
 			if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
+			n_color_nodes = (int)nodes.size();
+			if(!append_bump_nodes(yi, ld, bump_slot, nodes, bump)) return false;
 		}
 		else std::fprintf(stderr, "WARNING: ShinyDiffuse: Loading shader nodes failed! (the material is built without them, as the reference does)\n");
 	}
 	std::memset(&m, 0, sizeof m);
 	clear_shader_slots(m);
-	m.n_nodes = (int32_t)nodes.size();
+	m.n_nodes = (int32_t)n_color_nodes; m.bump_first = bump.first; m.n_bump = bump.count; m.sh_bump = bump.slot;
 	m.sh_diffuse = slots[kDiffuse]; m.sh_mirror_color = slots[kMirrorColor]; m.sh_mirror = slots[kMirror]; m.sh_transparency = slots[kTransparency];
 	m.sh_translucency = slots[kTranslucency]; m.sh_sigma_oren = slots[kSigmaOren]; m.sh_diffuse_refl = slots[kDiffuseRefl]; m.sh_ior = slots[kIor];
 	m.ior_base = ior; m.emit_strength = emit;
@@ -474,10 +500,13 @@ bool glossy_nodes(yafaray_interface *yi, const ParamMap &p, const char *what, bo
 		if(!coated && (k == kIor || k == kMirror || k == kMirrorColor)) continue;       // glossy has no such slots
 		if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
 	}
-	if(slots[kBump] >= 0) return fail(yi, std::string(what) + ": bump_shader (bump / normal mapping) is not supported by the GPU path");
 	if(slots[kWireframe] >= 0) return fail(yi, std::string(what) + ": wireframe_shader is not supported by the GPU path");
+	const int bump_slot = slots[kBump]; slots[kBump] = -1;
 	if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
 	m.n_nodes = (int32_t)nodes.size();
+	BumpList bump;
+	if(!append_bump_nodes(yi, ld, bump_slot, nodes, bump)) return false;
+	m.bump_first = bump.first; m.n_bump = bump.count; m.sh_bump = bump.slot;
 	m.sh_diffuse = slots[kDiffuse]; m.sh_glossy = slots[kGlossy]; m.sh_glossy_reflect = slots[kGlossyReflect]; m.sh_sigma_oren = slots[kSigmaOren];
 	m.sh_exponent = slots[kExponent]; m.sh_diffuse_refl = slots[kDiffuseRefl]; m.sh_ior = slots[kIor]; m.sh_mirror = slots[kMirror]; m.sh_mirror_color = slots[kMirrorColor];
 	return true;
@@ -590,7 +619,7 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, st
 	clear_shader_slots(m);
 	nodes.clear();
 	if(!yi->eparams.empty())
-	{	// material_glass.cc:402-441: mirror_color_shader, filter_color_shader, IOR_shader (bump / wireframe refused)
+	{	// material_glass.cc:402-441: mirror_color_shader, filter_color_shader, IOR_shader, bump_shader (wireframe refused)
 		enum { kMirrorColor, kFilterColor, kIor, kBump, kWireframe, kSlots };
 		static const char *names[kSlots] = {"mirror_color_shader", "filter_color_shader", "IOR_shader", "bump_shader", "wireframe_shader"};
 		int slots[kSlots]; for(int &v : slots) v = -1;
@@ -601,10 +630,13 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, st
 		{
 			std::string node;
 			for(int k = 0; k < kSlots; ++k) if(p.get(names[k], node)) { auto it = ld.by_name.find(node); if(it != ld.by_name.end()) slots[k] = it->second; }
-			if(slots[kBump] >= 0) return fail(yi, "glass: bump_shader (bump / normal mapping) is not supported by the GPU path");
 			if(slots[kWireframe] >= 0) return fail(yi, "glass: wireframe_shader is not supported by the GPU path");
+			const int bump_slot = slots[kBump]; slots[kBump] = -1;
 			if(!sort_nodes(yi, ld, slots, kSlots, nodes)) return false;
 			m.n_nodes = (int32_t)nodes.size();
+			BumpList bump;
+			if(!append_bump_nodes(yi, ld, bump_slot, nodes, bump)) return false;
+			m.bump_first = bump.first; m.n_bump = bump.count; m.sh_bump = bump.slot;
 			m.sh_mirror_color = slots[kMirrorColor]; m.sh_filter_color = slots[kFilterColor]; m.sh_ior = slots[kIor];
 		}
 		else std::fprintf(stderr, "WARNING: Glass: Loading shader nodes failed! (the material is built without them, as the reference does)\n");
@@ -1425,7 +1457,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 					const size_t vi = (size_t)m.tri[3 * t + (size_t)c];
 					if(m.has_uv && m.tri_uv.size() >= 3 * (t + 1))
 					{ const size_t ui = (size_t)m.tri_uv[3 * t + (size_t)c]; tri_uv.push_back(m.uv[2 * ui]); tri_uv.push_back(m.uv[2 * ui + 1]); }
-					else { tri_uv.push_back(0.f); tri_uv.push_back(0.f); }            // sp.u_ = sp.v_ = 0, triangle.cc:103-111
+					else { tri_uv.push_back(c == 0 ? kNoOrco : 0.f); tri_uv.push_back(0.f); }            // has_uv_ false (NaN marker): sp.u_ = sp.v_ = 0, implicit dPdU / dPdV, triangle.cc:103-111
 					if(m.has_orco && m.orco.size() >= 3 * (vi + 1))
 					{ tri_orco.push_back(m.orco[3 * vi]); tri_orco.push_back(m.orco[3 * vi + 1]); tri_orco.push_back(m.orco[3 * vi + 2]); }
 					else { tri_orco.push_back(c == 0 ? kNoOrco : 0.f); tri_orco.push_back(0.f); tri_orco.push_back(0.f); }   // has_orco_ false: orco = the hit point
@@ -1438,7 +1470,8 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	for(auto *m : yi->material_order)
 	{
 		yafgpu_material rec = m->m;
-		rec.node_first = (int32_t)nodes.size(); rec.n_nodes = (int32_t)m->nodes.size();
+		rec.node_first = (int32_t)nodes.size();           // rec.n_nodes colour nodes, then the bump shader's list
+		rec.bump_first += rec.node_first;
 		nodes.insert(nodes.end(), m->nodes.begin(), m->nodes.end());
 		mats.push_back(rec);
 	}

@@ -1040,6 +1040,28 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			for(int k = 0; k < cnt && 5 * k + 4 < n_out; ++k) { o[5 * k] = stack[k].col.r; o[5 * k + 1] = stack[k].col.g; o[5 * k + 2] = stack[k].col.b; o[5 * k + 3] = stack[k].col.a; o[5 * k + 4] = stack[k].f; }
 			break;
 		}
+		case 15:
+		{	// bump mapping: evalDerivative of a node range at a surface point — op 14's 20 words with x[17] = the scale applied to the last
+			// node's derivative, then ds_du, ds_dv, nu, nv, has_uv: n_nodes x (du, dv, 0, alpha, f), then (out + 5 * cnt) n, nu, nv after applyBump
+			if(sc.tex.nodes == nullptr || n_in < 33) break;
+			TexPoint tp;
+			tp.p = mk(x[0], x[1], x[2]); tp.n = mk(x[3], x[4], x[5]); tp.ng = mk(x[6], x[7], x[8]);
+			tp.orco_p = mk(x[9], x[10], x[11]); tp.orco_ng = mk(x[12], x[13], x[14]); tp.u = x[15]; tp.v = x[16];
+			tp.ds_du = mk(x[20], x[21], x[22]); tp.ds_dv = mk(x[23], x[24], x[25]); tp.nu = mk(x[26], x[27], x[28]); tp.nv = mk(x[29], x[30], x[31]);
+			tp.has_uv = x[32] != 0.f;
+			const int first = (int)__float_as_uint(x[18]), cnt = min((int)__float_as_uint(x[19]), kMaxNodes);
+			NodeResult stack[kMaxNodes];
+			nodes_eval_derivative(sc.tex, sc.tex.nodes + first, cnt, sc.cam, tp, stack);
+			for(int k = 0; k < cnt && 5 * k + 4 < n_out; ++k) { o[5 * k] = stack[k].col.r; o[5 * k + 1] = stack[k].col.g; o[5 * k + 2] = stack[k].col.b; o[5 * k + 3] = stack[k].col.a; o[5 * k + 4] = stack[k].f; }
+			if(cnt > 0 && 5 * cnt + 9 <= n_out)
+			{
+				V3 n = tp.n, nu = tp.nu, nv = tp.nv;
+				apply_bump(n, nu, nv, stack[cnt - 1].col.r * x[17], stack[cnt - 1].col.g * x[17]);
+				float *q = o + 5 * cnt;
+				q[0] = n.x; q[1] = n.y; q[2] = n.z; q[3] = nu.x; q[4] = nu.y; q[5] = nu.z; q[6] = nv.x; q[7] = nv.y; q[8] = nv.z;
+			}
+			break;
+		}
 		default: break;
 	}
 }
@@ -1094,6 +1116,7 @@ struct yafgpu_scene
 	int max_add_depth = 0;               // the largest Material::additional_depth_ of the scene: recursion frames beyond raydepth
 	bool has_glossy = false;             // some material has a glossy lobe that recursiveRaytrace samples (glossy / coated_glossy with as_diffuse off): 12-record frames
 	bool has_aniso = false;              // some material has the anisotropic glossy lobe: the general shading kernel
+	bool has_bump = false;               // some material has a bump shader: the shading frame is parked per vertex (records 24 / 25, frame record 12)
 	bool has_textures = false;           // some material in use has shader nodes: the general shading kernel, texture coordinates parked per path
 	bool has_specular = false, has_transparent = false; int wf_frames = 0; float4 *wf_filt = nullptr; uint32_t wf_filt_cap = 0;      // recursiveRaytrace frames allocated behind the working records
 	float *d_filter_table = nullptr;
@@ -1326,6 +1349,9 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			if(m.n_nodes < 0 || m.n_nodes > kMaxNodes || m.node_first < 0 || m.node_first + m.n_nodes > d->n_nodes)
 			{ yafgpu_scene_destroy(s); return fail(-24, "a material's shader nodes: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
 			if(m.n_nodes > 0) s->has_textures = true;
+			if(m.n_bump < 0 || m.n_bump > kMaxNodes || (m.n_bump > 0 && (m.bump_first < 0 || m.bump_first + m.n_bump > d->n_nodes || m.sh_bump < 0 || m.sh_bump >= m.n_bump)))
+			{ yafgpu_scene_destroy(s); return fail(-24, "a material's bump shader: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
+			if(m.n_bump > 0) { s->has_textures = true; s->has_bump = true; }
 		}
 		for(int i = 0; i < d->n_nodes; ++i)
 		{
@@ -1344,6 +1370,13 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		dv.tex.texels = texels; dv.tex.n_textures = d->n_textures;
 		if(d->tri_uv && (rc = upload(s, d->tri_uv, nt * 6, &dv.tex.tri_uv))) { yafgpu_scene_destroy(s); return rc; }
 		if(d->tri_orco && (rc = upload(s, d->tri_orco, nt * 9, &dv.tex.tri_orco))) { yafgpu_scene_destroy(s); return rc; }
+		if(s->has_bump)
+		{	// the third edge of Triangle::getSurface's dPdU / dPdV (triangle.cc:80-111): c - b, rounded once like e1 and e2 of the record
+			std::vector<float> e3(nt * 3);
+			for(size_t i = 0; i < nt; ++i) for(int k = 0; k < 3; ++k) e3[3 * i + k] = d->verts[9 * i + 6 + k] - d->verts[9 * i + 3 + k];
+			if((rc = upload(s, e3.data(), e3.size(), &dv.tex.tri_e3))) { yafgpu_scene_destroy(s); return rc; }
+			dv.tex.has_bump = 1;
+		}
 	}
 	if((rc = upload(s, faure.data(), faure.size(), &dv.faure))) { yafgpu_scene_destroy(s); return rc; }
 	dv.n_faure = (int)faure.size();
@@ -1588,7 +1621,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
 	const int frames = ((s->has_specular || s->has_glossy) && rp.raydepth + s->max_add_depth > 0) ? rp.raydepth + s->max_add_depth : 0;
-	const int frame_recs = s->has_glossy ? 12 : 5;
+	const int frame_recs = s->has_glossy ? (s->has_bump ? 13 : 12) : 5;
 	if(frames > 7) return fail(-17, "raydepth + additionaldepth > 7 with mirror / transparent / glossy-recursive materials: the device path keeps at most 7 recursion frames per sample");
 	// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
 	// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice

@@ -20,8 +20,9 @@ namespace yafgpu {
 struct TexScene
 {
 	const yafgpu_texture *textures; const float4 *texels; const yafgpu_node *nodes;
-	const float *tri_uv, *tri_orco;      // per triangle: u, v of the three corners (6 floats; zeros for a mesh without UVs) / orco of the three corners (9 floats; first word NaN for a mesh without orco), or nullptr
-	int n_textures;
+	const float *tri_uv, *tri_orco;      // per triangle: u, v of the three corners (6 floats; first word NaN for a mesh without UVs) / orco of the three corners (9 floats; first word NaN for a mesh without orco), or nullptr
+	const float *tri_e3;                 // bump mapping: vertex c - vertex b per triangle (3 floats), or nullptr
+	int n_textures, has_bump;
 };
 
 struct Rgba4 { float r, g, b, a; };
@@ -290,7 +291,7 @@ YG_DEV V3 mapper_do_mapping(const yafgpu_node &n, V3 p, V3 ng)
 }
 
 struct NodeResult { Rgba4 col; float f; };
-struct TexPoint { V3 p, n, ng, orco_p, orco_ng; float u, v; };      // what the nodes read of a SurfacePoint
+struct TexPoint { V3 p, n, ng, orco_p, orco_ng; float u, v; bool has_uv; V3 nu, nv, ds_du, ds_dv; };      // what the nodes read of a SurfacePoint (nu .. ds_dv: bump mapping only)
 
 constexpr int kMaxNodes = 16;       // nodes per material on the device (a layer stack of 8 textures; the host refuses more)
 
@@ -465,13 +466,126 @@ YG_DEV void tex_point(const TexScene &ts, int tri, float bu, float bv, V3 p, V3 
 		tp.orco_ng = normalize(cross(p_1 - p_0, p_2 - p_0));
 	}
 	else { tp.orco_p = p; tp.orco_ng = ng; }
-	if(ts.tri_uv != nullptr)
+	const float *q_uv = ts.tri_uv != nullptr ? ts.tri_uv + 6 * (size_t)tri : nullptr;
+	tp.has_uv = q_uv != nullptr && q_uv[0] == q_uv[0];     // a NaN first word: the triangle's mesh has no UVs (has_uv_ is per mesh)
+	if(tp.has_uv)
 	{
-		const float *q = ts.tri_uv + 6 * (size_t)tri;
+		const float *q = q_uv;
 		tp.u = u * q[0] + v * q[2] + w * q[4];
 		tp.v = u * q[1] + v * q[3] + w * q[5];
 	}
 	else { tp.u = 0.f; tp.v = 0.f; }
+}
+
+// dPdU / dPdV in shading space, Triangle::getSurface (triangle.cc:80-130): only bump mapping reads them.  a, e1 = b - a, e2 = c - a from the
+// triangle record, e3 = c - b from its own array (the differences the reference forms, each rounded once)
+YG_DEV void tex_point_derivatives(const TexScene &ts, int tri, V3 e1, V3 e2, V3 n, V3 nu, V3 nv, TexPoint &tp)
+{
+	const float *q3 = ts.tri_e3 + 3 * (size_t)tri;
+	const V3 e3 = mk(q3[0], q3[1], q3[2]);
+	V3 dp_du = e1, dp_dv = e3;                               // implicit mapping: p_1 - p_0, p_2 - p_1
+	if(tp.has_uv)
+	{
+		const float *q = ts.tri_uv + 6 * (size_t)tri;
+		const float du_1 = q[0] - q[4], du_2 = q[2] - q[4], dv_1 = q[1] - q[5], dv_2 = q[3] - q[5];
+		const float det = du_1 * dv_2 - dv_1 * du_2;
+		if(fabsf(det) > 1e-30f)
+		{
+			const float invdet = 1.f / det;
+			const V3 dp_1 = -e2, dp_2 = -e3;                 // p_0 - p_2, p_1 - p_2
+			dp_du = (dp_1 * dv_2 - dp_2 * dv_1) * invdet;
+			dp_dv = (dp_2 * du_1 - dp_1 * du_2) * invdet;
+		}
+	}
+	dp_du = normalize(dp_du); dp_dv = normalize(dp_dv);
+	tp.nu = nu; tp.nv = nv;
+	tp.ds_du = mk(dot(nu, dp_du), dot(nv, dp_du), dot(n, dp_du));
+	tp.ds_dv = mk(dot(nu, dp_dv), dot(nv, dp_dv), dot(n, dp_dv));
+}
+
+// NodeMaterial::evalBump's node pass (material_node.cc:132-139): evalDerivative of every node in order — TextureMapperNode :232-343
+// (image textures: discrete, no normal maps), LayerNode :122-152, the base class's zero for the others (shader_node.h:87-88)
+YG_DEV V3 mapper_get_coords(const yafgpu_node &n, const yafgpu_camera &cam, const TexPoint &sp, V3 &ng)
+{
+	V3 texpt;
+	if(n.texco == kTcUv) { texpt = mk(sp.u, sp.v, 0.f); ng = sp.ng; }
+	else if(n.texco == kTcOrco) { texpt = sp.orco_p; ng = sp.orco_ng; }
+	else if(n.texco == kTcTran)
+	{
+		const float *m = n.mtx;
+		texpt = mk(m[0] * sp.p.x + m[1] * sp.p.y + m[2] * sp.p.z + m[3], m[4] * sp.p.x + m[5] * sp.p.y + m[6] * sp.p.z + m[7], m[8] * sp.p.x + m[9] * sp.p.y + m[10] * sp.p.z + m[11]);
+		ng = mk(m[0] * sp.ng.x + m[1] * sp.ng.y + m[2] * sp.ng.z, m[4] * sp.ng.x + m[5] * sp.ng.y + m[6] * sp.ng.z, m[8] * sp.ng.x + m[9] * sp.ng.y + m[10] * sp.ng.z);
+	}
+	else if(n.texco == kTcWin)
+	{
+		const V3 dir = sp.p - vec3(cam.position);
+		const float dx = dot(dir, vec3(cam.cam_x)), dy = dot(dir, vec3(cam.cam_y)), dz = dot(dir, vec3(cam.cam_z));
+		texpt = mk(2.0f * dx * cam.focal_distance / dz, -2.0f * dy * cam.focal_distance / (dz * cam.aspect_ratio), 0.f);
+		ng = sp.ng;
+	}
+	else if(n.texco == kTcNor) { texpt = mk(dot(sp.n, vec3(cam.cam_x)), -dot(sp.n, vec3(cam.cam_y)), 0.f); ng = sp.ng; }
+	else { texpt = sp.p; ng = sp.ng; }
+	return texpt;
+}
+YG_DEV void nodes_eval_derivative(const TexScene &ts, const yafgpu_node *nodes, int n_nodes, const yafgpu_camera &cam, const TexPoint &sp, NodeResult *stack)
+{
+	for(int k = 0; k < n_nodes; ++k)
+	{
+		const yafgpu_node &n = nodes[k];
+		NodeResult res; res.col = ra4(0.f, 0.f, 0.f, 0.f); res.f = 0.f;
+		if(n.type == YAFGPU_NODE_TEXTURE_MAPPER && n.texture >= 0 && n.texture < ts.n_textures)
+		{
+			const yafgpu_texture &t = ts.textures[n.texture];
+			V3 ng;
+			V3 texpt = mapper_get_coords(n, cam, sp, ng);
+			float du = 0.0f, dv = 0.0f;
+			if(sp.has_uv && n.texco == kTcUv)
+			{
+				texpt = mapper_do_mapping(n, texpt, ng);
+				const V3 i_0 = mk(texpt.x - n.d_u, texpt.y - 0.f, texpt.z - 0.f), i_1 = mk(texpt.x + n.d_u, texpt.y + 0.f, texpt.z + 0.f);
+				const V3 j_0 = mk(texpt.x - 0.f, texpt.y - n.d_v, texpt.z - 0.f), j_1 = mk(texpt.x + 0.f, texpt.y + n.d_v, texpt.z + 0.f);
+				const float dfdu = (tex_get_float(ts, t, i_0) - tex_get_float(ts, t, i_1)) / n.d_u;
+				const float dfdv = (tex_get_float(ts, t, j_0) - tex_get_float(ts, t, j_1)) / n.d_v;
+				V3 vec_u = sp.ds_du, vec_v = sp.ds_dv;
+				vec_u.z = dfdu; vec_v.z = dfdv;
+				const V3 norm = normalize(cross(vec_u, vec_v));
+				if(fabsf(norm.z) > 1e-30f)
+				{
+					const float nf = (float)(1.0 / (double)norm.z * (double)n.bump_str);
+					du = norm.x * nf; dv = norm.y * nf;
+				}
+			}
+			else
+			{
+				const V3 i_0 = mapper_do_mapping(n, texpt - sp.nu * n.d_u, ng), i_1 = mapper_do_mapping(n, texpt + sp.nu * n.d_u, ng);
+				const V3 j_0 = mapper_do_mapping(n, texpt - sp.nv * n.d_v, ng), j_1 = mapper_do_mapping(n, texpt + sp.nv * n.d_v, ng);
+				du = (tex_get_float(ts, t, i_0) - tex_get_float(ts, t, i_1)) / n.d_u;
+				dv = (tex_get_float(ts, t, j_0) - tex_get_float(ts, t, j_1)) / n.d_v;
+				du *= n.bump_str; dv *= n.bump_str;
+				if(n.texco != kTcUv) { du = -du; dv = -dv; }
+			}
+			res.col = ra4(du, dv, 0.f, 0.f);
+		}
+		else if(n.type == YAFGPU_NODE_LAYER)
+		{
+			float rdu = 0.f, rdv = 0.f, stencil_tin = 1.f;
+			if(n.upper >= 0) { rdu = stack[n.upper].col.r; rdv = stack[n.upper].col.g; stencil_tin = stack[n.upper].col.a; }
+			float tdu = stack[n.input].col.r, tdv = stack[n.input].col.g;
+			if(n.texflag & kTxfNegative) { tdu = -tdu; tdv = -tdv; }
+			rdu += tdu; rdv += tdv;
+			res.col = ra4(rdu, rdv, 0.f, stencil_tin);
+		}
+		stack[k] = res;
+	}
+}
+// Material::applyBump, material.cc:77-84
+YG_DEV void apply_bump(V3 &n, V3 &nu, V3 &nv, float df_dnu, float df_dnv)
+{
+	nu = nu + n * df_dnu;
+	nv = nv + n * df_dnv;
+	n = normalize(cross(nu, nv));
+	nu = normalize(nu);
+	nv = normalize(cross(n, nu));
 }
 
 // the material record as its functions see it at this surface point (see the header comment)

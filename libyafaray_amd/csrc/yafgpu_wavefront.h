@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 24;   // float4 records of parked state per path (384 B; 22 and 23 are only touched in textured scenes)
+constexpr int kWfRecs = 26;   // float4 records of parked state per path (416 B; 22 and 23 are only touched in textured scenes, 24 and 25 only with bump mapping)
 
 struct WfArgs
 {
@@ -195,6 +195,39 @@ YG_DEV const yafgpu_material &wf_mat_hit(const DevScene &sc, const SurfPt &sp, i
 #endif
 	return m;
 }
+// Bump mapping (NodeMaterial::evalBump + Material::applyBump at the head of every initBsdf, material_shiny_diffuse.cc:171-175,
+// material_glossy.cc:56, material_coated_glossy.cc:73, material_glass.cc:62): the shading frame the rest of the vertex sees.
+// Record 24 / 25 parks nu of the path's two vertices with .w = 1 for a bumped frame (nv = n x nu then), 0 for create_cs's.
+YG_DEV bool wf_bump_hit(const DevScene &sc, SurfPt &sp, int tri, float bu, float bv)
+{
+#if YAFGPU_FEAT_TEXTURE
+	const yafgpu_material &m = sc.mats[sp.mat];
+	if(m.n_bump <= 0 || !sc.tex.has_bump) return false;
+	TexPoint tp; tex_point(sc.tex, tri, bu, bv, sp.p, sp.n, sp.ng, tp);
+	const float4 r1 = sc.tri[3 * tri + 1], r2 = sc.tri[3 * tri + 2];
+	tex_point_derivatives(sc.tex, tri, mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), sp.n, sp.nu, sp.nv, tp);
+	NodeResult stack[kMaxNodes];
+	nodes_eval_derivative(sc.tex, sc.tex.nodes + m.bump_first, min(m.n_bump, kMaxNodes), sc.cam, tp, stack);
+	apply_bump(sp.n, sp.nu, sp.nv, stack[m.sh_bump].col.r, stack[m.sh_bump].col.g);
+	return true;
+#else
+	(void)sc; (void)sp; (void)tri; (void)bu; (void)bv;
+	return false;
+#endif
+}
+// the parked frame of vertex 0 / 1 back onto a surface point rebuilt from its records
+YG_DEV void wf_frame_set(SurfPt &sp, const float4 nu)
+{
+	if(nu.w != 0.f) { sp.nu = v3(nu); sp.nv = normalize(cross(sp.n, sp.nu)); }
+}
+YG_DEV void wf_frame_parked(const WfArgs &a, uint32_t slot, int vertex, SurfPt &sp)
+{
+#if YAFGPU_FEAT_TEXTURE
+	if(a.ra.sc.tex.has_bump) wf_frame_set(sp, REC(24 + vertex));
+#else
+	(void)a; (void)slot; (void)vertex; (void)sp;
+#endif
+}
 YG_DEV const yafgpu_material &wf_mat_parked(const WfArgs &a, uint32_t slot, int vertex, const SurfPt &sp, yafgpu_material &tmp)
 {
 	const yafgpu_material &m = a.ra.sc.mats[sp.mat];
@@ -324,6 +357,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		const V3 dir = v3(r1);
 		SurfPt sp0;
 		get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, sp0);
+		if(YAFGPU_FEAT_TEXTURE && sc.tex.has_bump) { const bool bumped = wf_bump_hit(sc, sp0, tri, ans.z, ans.w); REC(24) = f4(sp0.nu, bumped ? 1.f : 0.f); }
 		yafgpu_material m_tmp;
 		const yafgpu_material &m = wf_mat_hit(sc, sp0, tri, ans.z, ans.w, m_tmp);
 		if(YAFGPU_FEAT_TEXTURE && sc.tex.nodes != nullptr) REC(22) = make_float4(fbits((uint32_t)tri), ans.z, ans.w, 0.f);
@@ -360,6 +394,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	const V3 dir = v3(r1);
 	SurfPt hit;
 	get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, hit);
+	if(YAFGPU_FEAT_TEXTURE && sc.tex.has_bump) { const bool bumped = wf_bump_hit(sc, hit, tri, ans.z, ans.w); REC(25) = f4(hit.nu, bumped ? 1.f : 0.f); }
 	yafgpu_material pm_tmp;
 	const yafgpu_material &pm = wf_mat_hit(sc, hit, tri, ans.z, ans.w, pm_tmp);
 	if(YAFGPU_FEAT_TEXTURE && sc.tex.nodes != nullptr) REC(23) = make_float4(fbits((uint32_t)tri), ans.z, ans.w, 0.f);
@@ -480,6 +515,7 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 	SurfPt sp; V3 wo;
 	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
 	else { const float4 p = REC(7); make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), sp); wo = v3(REC(10)); }
+	wf_frame_parked(a, slot, c.dl_on_sp0 ? 0 : 1, sp);
 	yafgpu_material mat_tmp;
 	const yafgpu_material &mat = wf_mat_parked(a, slot, c.dl_on_sp0 ? 0 : 1, sp, mat_tmp);
 	BsdfDat dat; mat_init_bsdf(mat, dat);
@@ -603,6 +639,7 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
 	const float4 p = REC(7);
 	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
+	wf_frame_parked(a, slot, 1, hit);
 	const float4 r10 = REC(10);
 	const V3 pwo = v3(r10);
 	yafgpu_material pm_tmp;
@@ -639,6 +676,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	c.incl = 0;                                                                                   // :211 state.include_lights_ = false
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
+	wf_frame_parked(a, slot, 0, sp0);
 	const V3 wo0 = v3(REC(6));
 	yafgpu_material m_tmp;
 	const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
@@ -693,6 +731,7 @@ YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 	if(!(ubits(r5.w) & (kSpecular | kFilter))) return W_RETURN;
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(r5), (int)ubits(p.w), sp0);
+	wf_frame_parked(a, slot, 0, sp0);
 	const V3 wo0 = v3(REC(6));
 	yafgpu_material m_tmp;
 	const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
@@ -725,7 +764,7 @@ YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 // recursiveRaytrace's glossy branch (:861-972) for materials that reflect only (:897-918): gsam trajectories through the glossy
 // lobe, each a full integrate() one level down under the trajectory-splitting state of frame record 5.  The loop lives in the
 // frame (flag 16 in F2.w): F6 normal | ns, gsam   F7 geometric normal | bsdf flags   F8 wo | integrate()'s w   F9 gcol | material
-// F10 the sample's colour | weight   F11 texture coordinates of the hit (tri, bu, bv)
+// F10 the sample's colour | weight   F11 texture coordinates of the hit (tri, bu, bv)   F12 (bump mapping) the hit's nu | bumped
 YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
 {
 	const int L = c.level;
@@ -739,6 +778,7 @@ YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
 	FREC(L, 8) = REC(6);
 	FREC(L, 9) = make_float4(0.f, 0.f, 0.f, r3.w);
 	if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) FREC(L, 11) = REC(22);
+	if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.has_bump) FREC(L, 12) = REC(24);
 	c.incl = 1;            // :863 state.include_lights_ = true, once: a later trajectory starts with what the one before left (its path samples clear it, :211)
 	return W_GLOSSY_NEXT;
 }
@@ -749,6 +789,7 @@ YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel
 	const float4 f2 = FREC(L, 2), f6 = FREC(L, 6), f7 = FREC(L, 7);
 	const int ns = (int)(ubits(f6.w) & 0xffu), gsam = (int)(ubits(f6.w) >> 8);
 	SurfPt sp0; make_sp(v3(f2), v3(f6), v3(f7), (int)ubits(FREC(L, 9).w), sp0);
+	if(YAFGPU_FEAT_TEXTURE && sc.tex.has_bump) wf_frame_set(sp0, FREC(L, 12));
 	const V3 wo0 = v3(FREC(L, 8));
 	yafgpu_material m_tmp;
 	const yafgpu_material *mp = &sc.mats[sp0.mat];
@@ -816,6 +857,7 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
 			// the level's hit again, for the specular branch that follows
 			REC(3) = f4(v3(f2), f9.w); REC(4) = f4(v3(f6), 0.f); REC(5) = FREC(P, 7); REC(6) = FREC(P, 8);
 			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) REC(22) = FREC(P, 11);
+			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.has_bump) REC(24) = FREC(P, 12);
 			REC(19) = make_float4(0.f, 0.f, 0.f, f0.w);
 			return W_RECURSE_SPEC;
 		}

@@ -39,7 +39,8 @@ class MaterialDesc(C.Structure):
         ("pad2", C.c_int32), ("nodes", C.c_void_p),
         ("exp_u", C.c_float), ("exp_v", C.c_float),
         ("sh_glossy", C.c_int32), ("sh_glossy_reflect", C.c_int32), ("sh_exponent", C.c_int32), ("sh_filter_color", C.c_int32),
-        ("additional_depth", C.c_int32), ("transp_bias_factor", C.c_float), ("transp_bias_mult", C.c_int32), ("pad4", C.c_int32),
+        ("additional_depth", C.c_int32), ("transp_bias_factor", C.c_float), ("transp_bias_mult", C.c_int32),
+        ("n_bump_nodes", C.c_int32), ("sh_bump", C.c_int32), ("pad5", C.c_int32), ("bump_nodes", C.c_void_p),
     ]
 
 
@@ -70,6 +71,7 @@ class NodeDesc(C.Structure):
         ("no_rgb", C.c_int32), ("stencil", C.c_int32), ("negative", C.c_int32), ("use_alpha", C.c_int32), ("do_color", C.c_int32),
         ("do_scalar_l", C.c_int32), ("color_input", C.c_int32),
         ("colfac", C.c_float), ("valfac", C.c_float), ("def_val", C.c_float), ("def_col", f3), ("upper_col", f4), ("upper_val", C.c_float),
+        ("bump_strength", C.c_float),
     ]
 
 
@@ -142,6 +144,7 @@ def node_descs(nodes, texture_index):
             d.scale = f3(*n.get("scale", (1, 1, 1))); d.offset = f3(*n.get("offset", (0, 0, 0)))
             d.mtx = (C.c_float * 16)(*np.asarray(n.get("transform", np.eye(4)), np.float32).reshape(16))
             d.do_scalar = int(n.get("do_scalar", True))
+            d.bump_strength = n.get("bump_strength", 1.0)
         elif t == "value":
             d.type = 1
             col = n.get("color", (1, 1, 1))
@@ -498,6 +501,24 @@ class OracleScene:
                 for pname, field in SHADER_SLOTS.items():
                     if pname in m and m[pname] in index:
                         setattr(d, field, index[m[pname]])
+                if m.get("bump_shader") in index:
+                    # bump_nodes_: what the bump shader reaches, in evaluation order (NodeMaterial::getNodeList)
+                    by_name = {n["name"]: n for n in m["nodes"]}
+                    order, seen = [], set()
+
+                    def visit(n):
+                        if n["name"] in seen:
+                            return
+                        seen.add(n["name"])
+                        for k in ("input1", "input2", "factor", "input", "upper_layer"):
+                            if k in n and n[k] in by_name:
+                                visit(by_name[n[k]])
+                        order.append(n)
+                    visit(by_name[m["bump_shader"]])
+                    barr, bindex = node_descs(order, tex_index)
+                    assert [bindex[n["name"]] for n in order] == list(range(len(order)))
+                    self._node_arrays.append(barr)
+                    d.n_bump_nodes = len(order); d.sh_bump = len(order) - 1; d.bump_nodes = C.cast(barr, C.c_void_p)
             mdescs.append(d)
         mats = (MaterialDesc * len(scene["materials"]))(*mdescs)
         lights = (LightDesc * max(1, len(scene["lights"])))(*[light_desc(l) for l in scene["lights"]])

@@ -46,6 +46,7 @@
 #include "shader/shader_node.h"
 #include "shader/shader_node_basic.h"
 #include "shader/shader_node_layer.h"
+#include "material/material_shiny_diffuse.h"
 #undef private
 #undef protected
 
@@ -317,6 +318,37 @@ static void sec_nodes(Json &j)
 	}
 	j.arr_u32("nodes_in", in);
 	j.arr_u32("nodes_out", out);
+
+	// bump mapping: evalDerivative of every node (TextureMapperNode :232-343 — the UV branch on a discrete texture, the branch for
+	// every other coordinate kind —, LayerNode :122-152, the base class's zero for value / mix) and Material::applyBump with the last
+	// layer's derivative (material.cc:77-84).  Surface points as above plus the shading-space UV derivatives getSurface leaves.
+	std::vector<uint32_t> bin, bout, bsp;
+	ParamMap mp; mp["type"] = std::string("shinydiffusemat");
+	std::list<ParamMap> no_nodes;
+	Material *any_mat = ShinyDiffuseMaterial::factory(mp, no_nodes, fake_env());
+	for(int k = 0; k < 40; ++k)
+	{
+		SurfacePoint sp; make_sp(sp);
+		sp.has_uv_ = (k % 4) != 3;
+		Vec3 a(srand11(), srand11(), srand11()), b(srand11(), srand11(), srand11());
+		a.normalize(); b.normalize();
+		sp.ds_du_ = a; sp.ds_dv_ = b;
+		push_sp(bin, sp);
+		const float extra[13] = {sp.ds_du_.x_, sp.ds_du_.y_, sp.ds_du_.z_, sp.ds_dv_.x_, sp.ds_dv_.y_, sp.ds_dv_.z_, sp.nu_.x_, sp.nu_.y_, sp.nu_.z_, sp.nv_.x_, sp.nv_.y_, sp.nv_.z_,
+		                         sp.has_uv_ ? 1.f : 0.f};
+		for(float f : extra) bin.push_back(f2u(f));
+		NodeStack stack(stack_mem.data());
+		for(ShaderNode *n : nodes) n->evalDerivative(stack, state, sp);
+		for(size_t i = 0; i < nodes.size(); ++i) { push_rgba(bout, stack_mem[i].col_); bout.push_back(f2u(stack_mem[i].f_)); }
+		float du, dv;
+		nodes.back()->getDerivative(stack, du, dv);
+		any_mat->applyBump(sp, du * 40.f, dv * 40.f);             // (scaled up: the harness's bump strengths are those of a 1 % bump)
+		const float res[9] = {sp.n_.x_, sp.n_.y_, sp.n_.z_, sp.nu_.x_, sp.nu_.y_, sp.nu_.z_, sp.nv_.x_, sp.nv_.y_, sp.nv_.z_};
+		for(float f : res) bsp.push_back(f2u(f));
+	}
+	j.arr_u32("bump_in", bin);
+	j.arr_u32("bump_out", bout);
+	j.arr_u32("bump_applied", bsp);
 }
 
 int main(int argc, char **argv)

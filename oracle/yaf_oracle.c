@@ -452,6 +452,7 @@ typedef struct
 	rgb ref_col;
 	/* shader nodes: the list in evaluation order and the node each slot reads (-1: none) */
 	int n_nodes; struct node_s *nodes;
+	int n_bump, sh_bump; struct node_s *bump_nodes;      /* bump_nodes_ in evaluation order and the bump shader's place in it (NodeMaterial::evalBump) */
 	int sh_diffuse, sh_mirror_color, sh_mirror, sh_transparency, sh_translucency, sh_sigma_oren, sh_diffuse_refl, sh_ior;
 	int sh_glossy, sh_glossy_reflect, sh_exponent;      /* glossy / coated_glossy: glossy_shader, glossy_reflect_shader, exponent_shader */
 	int additional_depth; float transp_bias_factor; int transp_bias_mult;      /* Material::additional_depth_, transparent_bias_* (material.h) */
@@ -920,7 +921,7 @@ static int brute_intersect_s(const yor_scene *s, v3 from, v3 dir, float dist)
 
 /* ------------------------------------------------------------------ surface point
  * the subset of SurfacePoint (surface.h:58-100) the path uses */
-typedef struct { v3 p, n, ng, nu, nv; int mat; int tri; float u, v; v3 orco_p, orco_ng; int has_uv, has_orco; } sp_t;
+typedef struct { v3 p, n, ng, nu, nv; int mat; int tri; float u, v; v3 orco_p, orco_ng; int has_uv, has_orco; v3 ds_du, ds_dv; } sp_t;   /* ds_du / ds_dv: dPdU / dPdV in shading space (triangle.cc:112-130), filled for bump mapping only */
 
 /* Triangle::getSurface, triangle.cc:30-133 (dPdU / dPdV are only used by bump mapping: not restated) */
 static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, sp_t *sp)
@@ -945,17 +946,32 @@ static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, 
 		sp->has_orco = 1;
 	}
 	else { sp->orco_p = hit; sp->has_orco = 0; sp->orco_ng = sp->ng; }      /* :58-63 */
-	if(s->tri_uv)
-	{	/* :69-79 */
+	v3 dp_du, dp_dv;
+	const v3 p_0 = tr->a, p_1 = tr->b, p_2 = tr->c;
+	if(s->tri_uv && s->tri_uv[6 * (size_t)ti] == s->tri_uv[6 * (size_t)ti])   /* has_uv_ is per mesh: a NaN first word = "this triangle's mesh has none" */
+	{	/* :69-101 */
 		const float *q = s->tri_uv + 6 * (size_t)ti;
 		sp->u = u * q[0] + v * q[2] + w * q[4];
 		sp->v = u * q[1] + v * q[3] + w * q[5];
 		sp->has_uv = 1;
+		float du_1 = q[0] - q[4], du_2 = q[2] - q[4], dv_1 = q[1] - q[5], dv_2 = q[3] - q[5];
+		float det = du_1 * dv_2 - dv_1 * du_2;
+		if(fabsf(det) > 1e-30f)
+		{
+			float invdet = 1.f / det;
+			v3 dp_1 = vsub(p_0, p_2), dp_2 = vsub(p_1, p_2);
+			dp_du = vmul(vsub(vmul(dp_1, dv_2), vmul(dp_2, dv_1)), invdet);
+			dp_dv = vmul(vsub(vmul(dp_2, du_1), vmul(dp_1, du_2)), invdet);
+		}
+		else { dp_du = vsub(p_1, p_0); dp_dv = vsub(p_2, p_1); }
 	}
-	else { sp->u = 0.f; sp->v = 0.f; sp->has_uv = 0; }                      /* :103-111 */
+	else { sp->u = 0.f; sp->v = 0.f; sp->has_uv = 0; dp_du = vsub(p_1, p_0); dp_dv = vsub(p_2, p_1); }                      /* :103-111 */
+	dp_du = vnormalize(dp_du); dp_dv = vnormalize(dp_dv);                    /* :116-117 */
 	sp->mat = tr->mat;
 	sp->p = hit;
 	create_cs(sp->n, &sp->nu, &sp->nv);
+	sp->ds_du = V(vdot(sp->nu, dp_du), vdot(sp->nv, dp_du), vdot(sp->n, dp_du));      /* :124-130 */
+	sp->ds_dv = V(vdot(sp->nu, dp_dv), vdot(sp->nv, dp_dv), vdot(sp->n, dp_dv));
 }
 
 /* Scene::intersect, scene.cc:896-927 */
@@ -1280,6 +1296,7 @@ typedef struct node_s
 	int mode; float cfactor; int input1, input2, factor; rgba_t col1, col2;
 	int input, upper; unsigned texflag; float colfac, valfac, def_val; rgba_t def_col, upper_col; float upper_val;
 	int do_color, do_scalar_l, color_input, use_alpha;
+	float bump_strength;      /* texture_mapper "bump_strength" as given; setup() (:34-59) turns it into bump_str_ once the texture's size is known */
 } node_t;
 typedef struct { rgba_t col; float f; } node_result_t;
 enum { TXF_RGBTOINT = 1, TXF_STENCIL = 2, TXF_NEGATIVE = 4, TXF_ALPHAMIX = 8 };
@@ -1307,6 +1324,7 @@ static void node_configure(node_t *n, const yor_node_desc *d)
 	n->def_col = RA(d->def_col[0], d->def_col[1], d->def_col[2], 1.f);
 	n->upper_col = RA(d->upper_col[0], d->upper_col[1], d->upper_col[2], d->upper_col[3]); n->upper_val = d->upper_val;
 	n->do_color = d->do_color; n->do_scalar_l = d->do_scalar_l; n->color_input = d->color_input; n->use_alpha = d->use_alpha;
+	n->bump_strength = d->bump_strength;
 }
 
 /* fAcos__ util_math_optimizations.h:255-261 */
@@ -1366,6 +1384,95 @@ static v3 mtx_point(const float *m, v3 p)      /* Matrix4 * Point3: with transla
 static v3 mtx_vec(const float *m, v3 v)        /* Matrix4 * Vec3: without */
 {
 	return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+/* the texture coordinates a mapper starts from: TextureMapperNode::getCoords :163-190 */
+static void mapper_get_coords(const node_t *n, const camera_t *cam, const sp_t *sp, v3 *texpt, v3 *ng)
+{
+	switch(n->texco)
+	{
+		case TC_UV: *texpt = V(sp->u, sp->v, 0.f); *ng = sp->ng; break;
+		case TC_ORCO: *texpt = sp->orco_p; *ng = sp->orco_ng; break;
+		case TC_TRAN: *texpt = mtx_point(n->mtx, sp->p); *ng = mtx_vec(n->mtx, sp->ng); break;
+		case TC_WIN:
+		{
+			v3 dir = vsub(sp->p, cam->position);
+			float dx = vdot(dir, cam->cam_x), dy = vdot(dir, cam->cam_y), dz = vdot(dir, cam->cam_z);
+			*texpt = V(2.0f * dx * cam->focal / dz, -2.0f * dy * cam->focal / (dz * cam->aspect_ratio), 0.f);
+			*ng = sp->ng; break;
+		}
+		case TC_NOR: *texpt = V(vdot(sp->n, cam->cam_x), -vdot(sp->n, cam->cam_y), 0.f); *ng = sp->ng; break;
+		default: *texpt = sp->p; *ng = sp->ng; break;
+	}
+}
+/* NodeMaterial::evalBump's node pass (material_node.cc:132-139): evalDerivative of every node in order — TextureMapperNode
+ * :232-343 (image textures: discrete, never normal maps here), LayerNode :122-152, the base class's zero for the others
+ * (shader_node.h:87-88).  stack[k].col = (du, dv, 0, stencil alpha). */
+static void nodes_eval_derivative(const node_t *nodes, int n_nodes, const tex_t *tex, int n_tex, const camera_t *cam, const sp_t *sp, node_result_t *stack)
+{
+	for(int k = 0; k < n_nodes; ++k)
+	{
+		const node_t *n = &nodes[k];
+		node_result_t res; res.col = RA(0.f, 0.f, 0.f, 0.f); res.f = 0.f;
+		if(n->type == YOR_NODE_TEXTURE_MAPPER && n->tex >= 0 && n->tex < n_tex)
+		{
+			const tex_t *t = &tex[n->tex];
+			/* setup() :34-59 */
+			const float d_u = 1.f / (float)t->w, d_v = 1.f / (float)t->h;
+			float bump_str = n->bump_strength;
+			bump_str /= vlength(n->scale);
+			bump_str /= 100.0f;
+			v3 texpt, ng;
+			float du = 0.0f, dv = 0.0f;
+			mapper_get_coords(n, cam, sp, &texpt, &ng);
+			if(sp->has_uv && n->texco == TC_UV)
+			{
+				texpt = mapper_do_mapping(n, texpt, ng);
+				v3 i_0 = V(texpt.x - d_u, texpt.y - 0.f, texpt.z - 0.f), i_1 = V(texpt.x + d_u, texpt.y + 0.f, texpt.z + 0.f);
+				v3 j_0 = V(texpt.x - 0.f, texpt.y - d_v, texpt.z - 0.f), j_1 = V(texpt.x + 0.f, texpt.y + d_v, texpt.z + 0.f);
+				float dfdu = (tex_get_float(t, i_0) - tex_get_float(t, i_1)) / d_u;
+				float dfdv = (tex_get_float(t, j_0) - tex_get_float(t, j_1)) / d_v;
+				v3 vec_u = sp->ds_du, vec_v = sp->ds_dv;
+				vec_u.z = dfdu; vec_v.z = dfdv;
+				v3 norm = vnormalize(vcross(vec_u, vec_v));
+				if(fabsf(norm.z) > 1e-30f)
+				{
+					float nf = (float)(1.0 / (double)norm.z * (double)bump_str);
+					du = norm.x * nf; dv = norm.y * nf;
+				}
+				else du = dv = 0.f;
+			}
+			else
+			{
+				v3 i_0 = mapper_do_mapping(n, vsub(texpt, vmul(sp->nu, d_u)), ng), i_1 = mapper_do_mapping(n, vadd(texpt, vmul(sp->nu, d_u)), ng);
+				v3 j_0 = mapper_do_mapping(n, vsub(texpt, vmul(sp->nv, d_v)), ng), j_1 = mapper_do_mapping(n, vadd(texpt, vmul(sp->nv, d_v)), ng);
+				du = (tex_get_float(t, i_0) - tex_get_float(t, i_1)) / d_u;
+				dv = (tex_get_float(t, j_0) - tex_get_float(t, j_1)) / d_v;
+				du *= bump_str; dv *= bump_str;
+				if(n->texco != TC_UV) { du = -du; dv = -dv; }
+			}
+			res.col = RA(du, dv, 0.f, 0.f);
+		}
+		else if(n->type == YOR_NODE_LAYER)
+		{
+			float rdu = 0.f, rdv = 0.f, stencil_tin = 1.f;
+			if(n->upper >= 0) { rdu = stack[n->upper].col.r; rdv = stack[n->upper].col.g; stencil_tin = stack[n->upper].col.a; }
+			float tdu = stack[n->input].col.r, tdv = stack[n->input].col.g;
+			if(n->texflag & TXF_NEGATIVE) { tdu = -tdu; tdv = -tdv; }
+			rdu += tdu; rdv += tdv;
+			res.col = RA(rdu, rdv, 0.f, stencil_tin);
+		}
+		stack[k] = res;
+	}
+}
+/* Material::applyBump, material.cc:77-84 */
+static void apply_bump(sp_t *sp, float df_dnu, float df_dnv)
+{
+	sp->nu = vadd(sp->nu, vmul(sp->n, df_dnu));
+	sp->nv = vadd(sp->nv, vmul(sp->n, df_dnv));
+	sp->n = vnormalize(vcross(sp->nu, sp->nv));
+	sp->nu = vnormalize(sp->nu);
+	sp->nv = vnormalize(vcross(sp->n, sp->nu));
 }
 
 /* one pass over a material's nodes in evaluation order (NodeMaterial::evalNodes, material_node.cc:83-86) */
@@ -1568,6 +1675,13 @@ static void mat_configure_(mat_t *m, const yor_material_desc *d);
 static void mat_configure(mat_t *m, const yor_material_desc *d)
 {
 	mat_configure_(m, d);
+	m->n_bump = 0; m->sh_bump = -1; m->bump_nodes = NULL;
+	if(d->n_bump_nodes > 0 && d->bump_nodes && d->sh_bump >= 0 && d->sh_bump < d->n_bump_nodes)
+	{
+		m->n_bump = d->n_bump_nodes; m->sh_bump = d->sh_bump;
+		m->bump_nodes = (node_t *)calloc((size_t)d->n_bump_nodes, sizeof(node_t));
+		for(int k = 0; k < d->n_bump_nodes; ++k) node_configure(&m->bump_nodes[k], &d->bump_nodes[k]);
+	}
 	m->additional_depth = d->additional_depth; m->transp_bias_factor = d->transp_bias_factor; m->transp_bias_mult = d->transp_bias_mult;
 }
 static void mat_configure_(mat_t *m, const yor_material_desc *d)
@@ -1899,6 +2013,21 @@ static const mat_t *mat_resolve(const yor_scene *s, const sp_t *sp, mat_t *out)
 	if(m->sh_diffuse_refl >= 0) { out->has_diffuse_refl = 1; out->diffuse_refl = stack[m->sh_diffuse_refl].f; }
 	if(m->sh_ior >= 0) { float cur = m->ior_base + stack[m->sh_ior].f; out->ior_squared = cur * cur; }     /* :258-262 */
 	return out;
+}
+
+/* initBsdf's first act on a material with a bump shader (material_shiny_diffuse.cc:171-175, material_glossy.cc:56, ...): evalBump moves
+ * the surface point's shading frame; everything after it at this vertex — the colour nodes, the light estimate, the samplers — sees that */
+static const mat_t *mat_at(const yor_scene *s, sp_t *sp, mat_t *out)
+{
+	const mat_t *m = &s->mats[sp->mat];
+	if(m->n_bump > 0)
+	{
+		node_result_t stack[YOR_MAX_NODES];
+		const int nb = m->n_bump < YOR_MAX_NODES ? m->n_bump : YOR_MAX_NODES;
+		nodes_eval_derivative(m->bump_nodes, nb, s->tex, s->n_tex, &s->cam, sp, stack);
+		apply_bump(sp, stack[m->sh_bump].col.r, stack[m->sh_bump].col.g);
+	}
+	return mat_resolve(s, sp, out);
 }
 
 static void mat_init_bsdf(const mat_t *m, bsdf_dat *dat, unsigned *bsdf_types)
@@ -2923,7 +3052,7 @@ yor_scene *yor_scene_create(int32_t n_tris, const float *verts, const int32_t *t
 void yor_scene_destroy(yor_scene *s)
 {
 	if(!s) return;
-	for(int i = 0; i < s->n_mats; ++i) free(s->mats[i].nodes);
+	for(int i = 0; i < s->n_mats; ++i) { free(s->mats[i].nodes); free(s->mats[i].bump_nodes); }
 	for(int i = 0; i < s->n_tex; ++i) free(s->tex[i].px);
 	free(s->tex); free(s->tri_uv); free(s->tri_orco);
 	free(s->tris); free(s->mats); free(s->lights); free(s->nodes); free(s->leaf_refs); free(s);
@@ -2949,6 +3078,35 @@ void yor_texture_probe(const yor_texture_desc *d, const float p[3], float out5[5
 	rgba_t c = tex_get_color(&t, V(p[0], p[1], p[2]));
 	out5[0] = c.r; out5[1] = c.g; out5[2] = c.b; out5[3] = c.a; out5[4] = tex_get_float(&t, V(p[0], p[1], p[2]));
 	free(t.px);
+}
+/* evalDerivative of every node at a surface point given as 31 floats: the 18 of yor_nodes_probe, ds_du (3), ds_dv (3), nu (3), nv (3),
+ * has_uv; out = n_nodes x (du, dv, 0, alpha, f).  bump9 (may be NULL): n, nu, nv after Material::applyBump with the LAST node's
+ * derivative times `bump_scale`. */
+void yor_nodes_probe_derivative(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
+                                const float sp31[31], float bump_scale, float *out, float *bump9)
+{
+	node_t nd[YOR_MAX_NODES]; node_result_t stack[YOR_MAX_NODES];
+	if(n_nodes > YOR_MAX_NODES) n_nodes = YOR_MAX_NODES;
+	for(int k = 0; k < n_nodes; ++k) node_configure(&nd[k], &nodes[k]);
+	tex_t *tx = (tex_t *)calloc((size_t)(n_textures > 0 ? n_textures : 1), sizeof(tex_t));
+	for(int i = 0; i < n_textures; ++i) tex_configure(&tx[i], &textures[i]);
+	camera_t c; memset(&c, 0, sizeof c);
+	if(cam) camera_configure(&c, cam);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.p = V(sp31[0], sp31[1], sp31[2]); sp.n = V(sp31[3], sp31[4], sp31[5]); sp.ng = V(sp31[6], sp31[7], sp31[8]);
+	sp.orco_p = V(sp31[9], sp31[10], sp31[11]); sp.orco_ng = V(sp31[12], sp31[13], sp31[14]); sp.u = sp31[15]; sp.v = sp31[16];
+	sp.ds_du = V(sp31[18], sp31[19], sp31[20]); sp.ds_dv = V(sp31[21], sp31[22], sp31[23]);
+	sp.nu = V(sp31[24], sp31[25], sp31[26]); sp.nv = V(sp31[27], sp31[28], sp31[29]); sp.has_uv = sp31[30] != 0.f;
+	nodes_eval_derivative(nd, n_nodes, tx, n_textures, &c, &sp, stack);
+	for(int k = 0; k < n_nodes; ++k) { out[5 * k] = stack[k].col.r; out[5 * k + 1] = stack[k].col.g; out[5 * k + 2] = stack[k].col.b; out[5 * k + 3] = stack[k].col.a; out[5 * k + 4] = stack[k].f; }
+	if(bump9 && n_nodes > 0)
+	{
+		apply_bump(&sp, stack[n_nodes - 1].col.r * bump_scale, stack[n_nodes - 1].col.g * bump_scale);
+		const float r[9] = {sp.n.x, sp.n.y, sp.n.z, sp.nu.x, sp.nu.y, sp.nu.z, sp.nv.x, sp.nv.y, sp.nv.z};
+		memcpy(bump9, r, sizeof r);
+	}
+	for(int i = 0; i < n_textures; ++i) free(tx[i].px);
+	free(tx);
 }
 void yor_nodes_probe(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
                      const float sp18[18], float *out)
@@ -3162,7 +3320,7 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 		if(raylevel == 0) st->include_lights = 1; /* :129-135 */
 		unsigned bsdfs;
 		bsdf_dat dat0;
-		mat_t mat_here; const mat_t *material = mat_resolve(s, &sp, &mat_here);
+		mat_t mat_here; const mat_t *material = mat_at(s, &sp, &mat_here);
 		mat_init_bsdf(material, &dat0, &bsdfs);
 		if(additional_depth < material->additional_depth) additional_depth = material->additional_depth;     /* :149 */
 		v3 wo = vneg(dir);
@@ -3194,7 +3352,7 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 				p_tmin = st->ray_min_dist;
 				p_tmax = -1.0f;
 				if(!scene_intersect(s, sp.p, p_dir, p_tmin, &p_tmax, hit, &st->cn)) continue;
-				mat_t mat_hit; const mat_t *p_mat = mat_resolve(s, hit, &mat_hit);
+				mat_t mat_hit; const mat_t *p_mat = mat_at(s, hit, &mat_hit);
 				unsigned mat_bsdfs;
 				mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
 				if(sm.sampled_flags != BSDF_NONE) pwo = vneg(p_dir);
@@ -3216,7 +3374,7 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 					p_tmax = -1.0f;
 					if(!scene_intersect(s, hit->p, p_dir, p_tmin, &p_tmax, hit_2, &st->cn)) break;
 					{ sp_t *tmp = hit; hit = hit_2; hit_2 = tmp; }
-					p_mat = mat_resolve(s, hit, &mat_hit);
+					p_mat = mat_at(s, hit, &mat_hit);
 					mat_init_bsdf(p_mat, &dat_n, &mat_bsdfs);
 					pwo = vneg(p_dir);
 					if(mat_bsdfs & BSDF_DIFFUSE) lcol = estimate_one_direct_light(st, hit, p_mat, &dat_n, pwo);

@@ -84,7 +84,10 @@ typedef struct yor_material_desc
 	int32_t sh_glossy, sh_glossy_reflect, sh_exponent, sh_filter_color;      /* glossy / coated_glossy slots: glossy_shader, glossy_reflect_shader, exponent_shader; glass: filter_color_shader */
 	int32_t additional_depth;  /* "additionaldepth": recursiveRaytrace may go this much deeper below this material (integrator_montecarlo.cc:791) */
 	float transp_bias_factor;  /* shinydiffusemat "transparentbias_factor" / "transparentbias_multiply_raydepth" (:1003-1011) */
-	int32_t transp_bias_mult, pad4;
+	int32_t transp_bias_mult;
+	int32_t n_bump_nodes;      /* bump mapping: the nodes the bump shader reaches, in evaluation order, and its index among them (material_node.cc:132-139) */
+	int32_t sh_bump, pad5;
+	const struct yor_node_desc *bump_nodes;
 } yor_material_desc;
 
 /* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has
@@ -133,6 +136,7 @@ typedef struct yor_node_desc
 	float def_col[3];
 	float upper_col[4];
 	float upper_val;
+	float bump_strength;       /* texture_mapper "bump_strength" (factory default 1) */
 } yor_node_desc;
 
 typedef struct yor_light_desc
@@ -241,6 +245,8 @@ void yor_scene_set_textures(yor_scene *s, int32_t n_textures, const yor_texture_
 void yor_scene_set_texcoords(yor_scene *s, const float *uv, const float *orco);
 /* probes for the pins: one image-texture lookup (getColor rgba + getFloat), one material's node stack at a surface point */
 void yor_texture_probe(const yor_texture_desc *t, const float p[3], float out5[5]);
+void yor_nodes_probe_derivative(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
+                                const float sp31[31], float bump_scale, float *out, float *bump9);
 void yor_nodes_probe(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_textures, const yor_texture_desc *textures, const yor_camera_desc *cam,
                      const float sp18[18], float *out /* n_nodes * 5 */);
 

@@ -151,6 +151,132 @@ def test_device_shader_node_graph_matches_the_reference():
     assert not bad_nodes, f"{len(bad_nodes)} of {len(nodes)} nodes differ, first: {bad_nodes[0]}"
 
 
+def test_device_bump_derivatives_match_the_reference():
+    """evalDerivative of every node of the harness's graph on the device (probe op 15; one material per node with that node as its
+    BUMP shader, so the host's bump list — NodeMaterial::bump_nodes_ — is what is evaluated) at the harness's 40 surface points
+    with and without UVs, and Material::applyBump with the last layer's derivative: bit for bit."""
+    g = golden("ieee")
+    nodes = _node_graph(g)
+    c = f32(g["nodes_camera"])
+    cam = {"type": "perspective", "from": tuple(float(x) for x in c[0:3]), "to": tuple(float(x) for x in c[3:6]), "up": tuple(float(x) for x in c[6:9]),
+           "resx": int(g["nodes_camera"][9]), "resy": int(g["nodes_camera"][10]), "focal": float(c[11])}
+    yi = Interface()
+    yi.startScene(0)
+    yi.paramsClearAll()
+    yi.paramsSet({"type": "image", "interpolate": "bilinear", "clipping": "repeat", "color_space": "sRGB"})
+    yi.createTextureFromMemory("t", f32(g["nodes_texels"]).reshape(5, 6, 4))
+    first, ranges, mats = 0, [], []
+    for n in nodes:
+        yi.paramsClearAll()
+        yi.paramsSet({"type": "shinydiffusemat", "bump_shader": n["name"]})
+        for nd in nodes:
+            yi.paramsPushList()
+            yi.paramsSetString("element", "shader_node")
+            for k, v in nd.items():
+                if k == "transform":
+                    yi.paramsSetMatrix(k, np.asarray(v, np.float32).reshape(16))
+                elif k in ("color", "color1", "color2", "def_col", "upper_color"):
+                    yi.paramsSetColor(k, *[float(x) for x in v])
+                else:
+                    yi.paramsSet({k: v})
+            yi.paramsEndList()
+        mats.append(yi.createMaterial("m_" + n["name"]))
+        cnt = len(_reachable(nodes, n["name"]))
+        ranges.append((first, cnt))
+        first += cnt
+    _one_triangle_scene(yi, mats[0], cam)
+    sps = f32(g["bump_in"]).reshape(-1, 31)
+    want = f32(g["bump_out"]).reshape(len(sps), len(nodes), 5)
+    want9 = f32(g["bump_applied"]).reshape(len(sps), 9)
+    bad_nodes = []
+    for k, (n, (start, cnt)) in enumerate(zip(nodes, ranges)):
+        inp = np.zeros((len(sps), 33), np.float32)
+        inp[:, :17] = sps[:, :17]
+        inp[:, 17] = 40.0
+        inp[:, 18] = np.array([start], np.uint32).view(np.float32)[0]
+        inp[:, 19] = np.array([cnt], np.uint32).view(np.float32)[0]
+        inp[:, 20:33] = sps[:, 18:31]
+        out = yi.probe(15, inp, 5 * cnt + 9)
+        got = out[:, 5 * (cnt - 1):5 * cnt]           # the slot's own node is the last of its range
+        if (got.view(np.uint32) != want[:, k].view(np.uint32)).any():
+            p = int(np.nonzero((got.view(np.uint32) != want[:, k].view(np.uint32)).any(axis=1))[0][0])
+            bad_nodes.append(f"{n} at point {p} (has_uv {sps[p, 30]}): {got[p]} vs {want[p, k]}")
+        if k == len(nodes) - 1:
+            assert np.array_equal(out[:, 5 * cnt:].view(np.uint32), want9.view(np.uint32)), "applyBump differs"
+    assert not bad_nodes, f"{len(bad_nodes)} of {len(nodes)} nodes differ, first: {bad_nodes[0]}"
+
+
+def _bumpy(sc):
+    """bump shaders on the textured box: a UV-mapped bump layer on the walls' material (their triangles have UVs: the derivative's
+    UV branch), an orco / cube one, a two-layer stack over global and window coordinates with a negative layer"""
+    mapper = lambda name, tex, texco, mapping="plain", **kw: dict(name=name, type="texture_mapper", texture=tex, texco=texco, mapping=mapping, **kw)
+    bump = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, valfac=1.0, def_val=1.0, do_color=False, do_scalar=True, color_input=False,
+                                             upper_value=0.0), **kw)
+    m = sc["materials"]
+    m[0] = dict(m[0], bump_shader="bmp", nodes=m[0]["nodes"] + [bump("bmp", "bmap"), mapper("bmap", "t_adj", "uv", bump_strength=3.0, scale=(1.5, 2.0, 1.0))])
+    m[1] = dict(m[1], bump_shader="bmp", nodes=m[1]["nodes"] + [bump("bmp", "bmap"), mapper("bmap", "t_rgb", "orco", "cube", bump_strength=2.0)])
+    m[2] = dict(m[2], bump_shader="bmp2", nodes=m[2]["nodes"] + [bump("bmp2", "bmapw", upper_layer="bmp1", negative=True), bump("bmp1", "bmapg"),
+                                                                 mapper("bmapg", "t_chk", "global", "tube", bump_strength=1.5),
+                                                                 mapper("bmapw", "t_rgb", "window", bump_strength=0.7)])
+    return sc
+
+
+@pytest.mark.parametrize("integrator,kw", [("directlighting", dict(transpShad=True, shadowDepth=3, raydepth=2)), ("pathtracing", dict(bounces=3, raydepth=2)),
+                                           ("pathtracing", dict(bounces=4, russian_roulette_min_bounces=1, specular=False))])
+def test_bump_mapped_render_matches_oracle(integrator, kw):
+    """bump mapping (NodeMaterial::evalBump + Material::applyBump at the head of initBsdf): the bumped shading frame steers the
+    light estimate, the samplers, the mirror directions of recursiveRaytrace and the `normal` texture coordinates of the colour nodes"""
+    kw = dict(kw)
+    sc = _bumpy(_textured_box(specular=kw.pop("specular", True)))
+    rd = scenes.render_settings(48, 40, 4, integrator=integrator, **kw)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(48, 40), yi.getRenderStats()
+    seed, skip = yi.getRandState()
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=1, rand_srand=seed, rand_skip=skip))
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"bump-mapped box {integrator} {kw}", exact_weights=True)
+    # the bump must have mattered: the same scene without the bump shaders renders differently
+    flat = _textured_box(specular=sc["materials"][1].get("specular_reflect") is not None)
+    y2 = Interface()
+    scenes.load_scene(y2, flat, rd)
+    y2.render()
+    assert np.abs(y2.getFilm(48, 40)[..., :3] - film[..., :3]).max() > 0.01
+
+
+def test_bump_mapped_glossy_and_glass_match_oracle():
+    """bump shaders on glossy (through recursiveRaytrace's glossy branch, whose frame keeps the bumped nu), coated_glossy (path-traced)
+    and glass (bumped refraction / reflection directions), on a mesh WITHOUT UVs: a `uv` bump mapper then takes the derivative's
+    other branch and sees u = v = 0 (triangle.cc:103-111)"""
+    sc = _textured_box(specular=False)
+    del sc["uv"]
+    mapper = lambda name, tex, texco, mapping="plain", **kw: dict(name=name, type="texture_mapper", texture=tex, texco=texco, mapping=mapping, **kw)
+    bump = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, valfac=1.0, def_val=1.0, do_color=False, do_scalar=True, color_input=False,
+                                             upper_value=0.0), **kw)
+    m = sc["materials"]
+    m[0] = {"type": "shinydiffusemat", "color": (0.8, 0.8, 0.8), "diffuse_reflect": 0.9, "bump_shader": "bmp",
+            "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_rgb", "uv", bump_strength=2.0)]}
+    m[1] = {"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.4, "glossy_reflect": 0.6, "exponent": 80.0, "as_diffuse": False,
+            "bump_shader": "bmp", "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_rgb", "orco", "cube", bump_strength=2.5)]}
+    m[2] = {"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.5, "glossy_reflect": 0.5, "exponent": 100.0,
+            "specular_reflect": 0.6, "IOR": 1.5, "as_diffuse": True, "anisotropic": True, "exp_u": 40.0, "exp_v": 400.0,
+            "bump_shader": "bmp", "diffuse_shader": "dcol",
+            "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_adj", "global", "sphere", bump_strength=1.5),
+                      dict(name="dcol", type="layer", input="nmap", mode=0, colfac=0.8, def_col=(1.0, 0.0, 1.0, 1.0), do_color=True, do_scalar=False, color_input=True,
+                           upper_color=(0.7, 0.7, 0.7, 1.0), upper_value=0.0), mapper("nmap", "t_rgb", "normal")]}
+    m[4] = {"type": "glass", "IOR": 1.4, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6, "mirror_color": (0.95, 0.9, 1.0),
+            "bump_shader": "bmp", "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_chk", "orco", "tube", bump_strength=2.0)]}
+    rd = scenes.render_settings(48, 40, 3, integrator="pathtracing", bounces=2, raydepth=2, path_samples=2)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    film, st = yi.getFilm(48, 40), yi.getRenderStats()
+    ofilm, ost = po.OracleScene(sc).render(rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, "bump-mapped glossy / coated glossy / glass without UVs", exact_weights=True)
+
+
 def _textured_box(seed=5, n_tris=400, specular=True):
     """the Cornell soup with UVs and orcos on every triangle and a set of materials that drives every shader slot.
     specular=False: without the mirror / transparency lobes (and their shaders), i.e. without recursiveRaytrace — the regime in

@@ -126,3 +126,34 @@ def test_shader_node_graph():
         k = int(np.nonzero(diff[:, bad_nodes[0]])[0][0])
         msg = f"{len(bad_nodes)} nodes differ, first: {nodes[bad_nodes[0]]} at point {k}: {got[k, bad_nodes[0]]} vs {want[k, bad_nodes[0]]}"
     assert not bad_nodes, msg
+
+
+def test_bump_derivatives_and_apply_bump():
+    """evalDerivative of every node of the same graph (TextureMapperNode's UV branch on surface points with UVs, its other
+    branch without them and for every other coordinate kind; LayerNode; the base class's zero for value / mix) and
+    Material::applyBump with the last layer's derivative: bit for bit."""
+    g = golden("ieee")
+    nodes = _node_graph(g)
+    tex = dict(name="t", texels=f32(g["nodes_texels"]).reshape(5, 6, 4), interpolate="bilinear", clipping="repeat", color_space="sRGB")
+    arr, index = po.node_descs(nodes, {"t": 0})
+    td = po.texture_desc(tex)
+    c = f32(g["nodes_camera"])
+    cam = po.camera_desc({"from": c[0:3], "to": c[3:6], "up": c[6:9], "resx": int(g["nodes_camera"][9]), "resy": int(g["nodes_camera"][10]), "focal": float(c[11])})
+    sps = f32(g["bump_in"]).reshape(-1, 31)
+    want = f32(g["bump_out"]).reshape(len(sps), len(nodes), 5)
+    want9 = f32(g["bump_applied"]).reshape(len(sps), 9)
+    L = po.lib()
+    L.yor_nodes_probe_derivative.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.yor_nodes_probe_derivative.restype = None
+    got = np.zeros_like(want); got9 = np.zeros_like(want9)
+    for k in range(len(sps)):
+        L.yor_nodes_probe_derivative(len(nodes), C.cast(arr, C.c_void_p), 1, C.cast(C.pointer(td), C.c_void_p), C.cast(C.pointer(cam), C.c_void_p),
+                                     po.fptr(np.ascontiguousarray(sps[k])), 40.0, po.fptr(got[k]), po.fptr(got9[k]))
+    diff = (got.view(np.uint32) != want.view(np.uint32)).any(axis=2)
+    bad = sorted(set(np.nonzero(diff)[1].tolist()))
+    msg = ""
+    if bad:
+        k = int(np.nonzero(diff[:, bad[0]])[0][0])
+        msg = f"{len(bad)} nodes differ, first: {nodes[bad[0]]} at point {k} (has_uv {sps[k, 30]}): {got[k, bad[0]]} vs {want[k, bad[0]]}"
+    assert not bad, msg
+    assert np.array_equal(got9.view(np.uint32), want9.view(np.uint32)), "applyBump differs"

@@ -1185,6 +1185,30 @@ def _texturize(sc, rng):
         else:
             for key in [key for key in m if key.endswith("_shader")]:
                 m.pop(key)
+    # bump shaders, from a stream of their own (the draws above stay what they were): one layer, sometimes two, over any coordinates
+    rb = np.random.default_rng(int(rng.integers(0, 2 ** 31)))
+    for mi, m in enumerate(sc["materials"]):
+        if m.get("type", "shinydiffusemat") not in ("shinydiffusemat", "glossy", "coated_glossy", "glass") or rb.random() < 0.65:
+            continue
+        nodes = list(m.get("nodes", []))
+        if len(nodes) + 4 > 16:
+            continue
+        def bump_mapper(name):
+            nd = dict(name=name, type="texture_mapper", texture=str(rb.choice([t["name"] for t in sc["textures"]])), texco=str(rb.choice(texcos)),
+                      mapping=str(rb.choice(["plain", "cube", "tube", "sphere"])), scale=tuple(float(x) for x in rb.uniform(0.5, 3.0, 3)),
+                      offset=tuple(float(x) for x in rb.uniform(-0.5, 0.5, 3)), bump_strength=float(rb.uniform(0.2, 4.0)))
+            if nd["texco"] == "transformed":
+                mtx = np.eye(4, dtype=np.float32); mtx[:3, :] = rb.uniform(-1, 1, (3, 4)); nd["transform"] = mtx
+            return nd
+        lay = dict(name="bump_a", type="layer", input="bump_map_a", mode=0, valfac=1.0, def_val=1.0, do_color=False, do_scalar=True, color_input=False, upper_value=0.0,
+                   negative=bool(rb.random() < 0.3))
+        nodes += [lay, bump_mapper("bump_map_a")]
+        m["bump_shader"] = "bump_a"
+        if rb.random() < 0.3:
+            nodes += [dict(lay, name="bump_b", input="bump_map_b", upper_layer="bump_a", negative=bool(rb.random() < 0.3)), bump_mapper("bump_map_b")]
+            nodes[-2].pop("upper_value")
+            m["bump_shader"] = "bump_b"
+        m["nodes"] = nodes
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_FUZZ_FIRST", "0")), int(__import__("os").environ.get("YAFGPU_FUZZ_SEEDS", "16")))))

@@ -171,7 +171,9 @@ void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count)
 /* Multi-pass (adaptive) anti-aliasing on a sharded frame: between passes the noise detection (integrator_tiled.cc:136-258)
  * needs every rank's pixels.  `fn` receives a copy of this rank's splat planes in DEVICE memory and must sum it over all ranks
  * in place (an all-reduce; libyafaray_amd/parallel.py does it with torch.distributed = RCCL) and return 0.  Without it a sharded
- * multi-pass render is refused.  The film a rank returns stays its own share (sum them as for a one-pass render). */
+ * multi-pass render is refused.  The film a rank returns stays its own share (sum them as for a one-pass render).
+ * The same function carries the light counter of the serial replay below across ranks (a small table of per-tile call counts once per
+ * pass): with it a sharded render of a scene with several lights makes the single-GPU render's light choices; without it, its own. */
 typedef int (*yafaray_plane_exchange_t)(void *user, float *d_values, uint64_t n_floats);
 void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user);
 /* Exact replay of the reference's serial render state (on by default): the per-tile Random that Russian roulette draws from

@@ -301,7 +301,10 @@ int yafgpu_scene_set_abort_flag(yafgpu_scene_t *scene, const volatile int32_t *f
  * this rank's four splat planes (device memory, n_floats values) after every pass that is followed by a detection step; the
  * function sums the copies over all ranks in place (an all-reduce: RCCL over xGMI) and returns 0.  Every plane element is
  * written by exactly one rank, so the sums are exact (x + 0) and every rank derives the single-GPU render's resample mask.
- * The rank's own planes, and the film it returns at the end, stay its own share. */
+ * The rank's own planes, and the film it returns at the end, stay its own share.
+ * The same function carries the reference's serial light counter across ranks (path tracing with more than one light,
+ * estimateOneDirectLight's correlative_sample_number_, integrator_montecarlo.cc:62-76): once per pass every rank — with or without
+ * tiles of its own — hands it a table of 2 x (tiles of the frame) floats holding its own tiles' call counts; see DESIGN.md §6. */
 typedef int (*yafgpu_exchange_fn)(void *user, float *d_values, uint64_t n_floats);
 int yafgpu_scene_set_exchange(yafgpu_scene_t *scene, yafgpu_exchange_fn fn, void *user);
 int yafgpu_get_profile(const yafgpu_scene_t *scene, double ms[4], uint64_t launches[4]);

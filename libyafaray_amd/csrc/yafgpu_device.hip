@@ -1122,7 +1122,9 @@ struct yafgpu_scene
 	float *d_filter_table = nullptr;
 	// serial-state replay tables (WfArgs::replay)
 	uint32_t *rp_flags = nullptr; float *rp_p = nullptr; uint8_t *rp_kill = nullptr, *rp_calls = nullptr; uint32_t *rp_base = nullptr; size_t rp_ents = 0; uint32_t rp_prob = 0;
-	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
+	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_seg_base = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
+	uint32_t lc_host_counter = 0;                        // correlative_sample_number_ of a sharded render: the same value on every rank (lc_exchange_counts)
+	std::vector<uint32_t> h_seg_base;
 	std::vector<uint32_t> h_listed;                      // pixels of a masked (adaptive) pass, in tile order
 	std::vector<uint32_t> h_seg_begin, h_seg_seed;       // every chunk's segments of the pass, uploaded once (scene-owned: an async copy may read them late)
 	yafgpu_exchange_fn exchange = nullptr; void *exchange_user = nullptr;     // yafgpu_scene_set_exchange
@@ -1430,7 +1432,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base, (void *)s->rp_seg_begin,
-	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_counter}) if(q) (void)hipFree(q);
+	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter}) if(q) (void)hipFree(q);
 	delete s;
 }
 
@@ -1580,6 +1582,55 @@ static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
 	return nullptr;
 }
 
+// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
+// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
+// (more than one light).  Not with recursiveRaytrace frames (a sample's events are then a tree, not a list: the
+// per-sample streams stand in).  The light counter of a SHARDED frame needs every rank's calls per tile (a tile
+// starts with the sum over all tiles before it): with an exchange function attached the ranks share them (lc_sharded),
+// without one the per-sample ordinals stand in for the counter.
+struct ReplayPlan { int frames; bool need_rr, need_lc, replay, replay_lights, lc_sharded; };
+static ReplayPlan replay_plan(const yafgpu_scene *s, const yafgpu_render_params &rp)
+{
+	ReplayPlan p{};
+	p.frames = ((s->has_specular || s->has_glossy) && rp.raydepth + s->max_add_depth > 0) ? rp.raydepth + s->max_add_depth : 0;
+	const bool path = rp.integrator == YAFGPU_INTEGRATOR_PATH;
+	p.need_rr = path && rp.bounces - 1 > rp.rr_min_bounces;
+	p.need_lc = path && s->n_lights > 1;
+	p.replay = rp.serial_replay != 0 && p.frames == 0 && (p.need_rr || p.need_lc);
+	if(const char *e = std::getenv("YAFGPU_SERIAL_REPLAY")) if(std::atoi(e) == 0) p.replay = false;
+	p.lc_sharded = p.replay && p.need_lc && rp.shard_count > 1 && s->exchange != nullptr;
+	p.replay_lights = p.replay && p.need_lc && (rp.shard_count == 1 || p.lc_sharded);
+	if(p.replay && !p.need_rr && !p.replay_lights) p.replay = false;
+	if(!p.replay) { p.replay_lights = false; p.lc_sharded = false; }
+	return p;
+}
+// The light counter across ranks: every rank contributes the estimateOneDirectLight calls of its own tiles (global tile index,
+// count), the exchange function sums the table over the ranks (each entry has one writer; two 16-bit halves as floats, so the sums
+// are exact), and every rank takes the same exclusive scan in the reference's tile order on top of the counter so far.  Every rank
+// of the render calls this once per pass, with or without tiles of its own.
+static int lc_exchange_counts(yafgpu_scene *s, const yafgpu_render_params &rp, const std::vector<std::pair<int, uint32_t>> &own, std::vector<uint32_t> *base_of_tile)
+{
+	const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size, nty = (rp.height + rp.tile_size - 1) / rp.tile_size;
+	const size_t n = (size_t)ntx * (size_t)nty;
+	std::vector<float> h(2 * n, 0.f);
+	for(const auto &e : own) { h[2 * (size_t)e.first] = (float)(e.second & 0xffffu); h[2 * (size_t)e.first + 1] = (float)(e.second >> 16); }
+	DevMem<float> d;
+	HIP_OK(d.alloc(2 * n));
+	HIP_OK(hipMemcpy(d, h.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice));
+	HIP_OK(hipDeviceSynchronize());
+	if(s->exchange(s->exchange_user, d, (uint64_t)(2 * n))) return fail(-31, "the exchange function reported a failure (light counter)");
+	HIP_OK(hipMemcpy(h.data(), d, 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+	uint32_t run = rp.accumulate ? s->lc_host_counter : 0u;      // zeroed once per render, before its first pass (integrator_tiled.cc:192-194)
+	if(base_of_tile) base_of_tile->resize(n);
+	for(size_t t = 0; t < n; ++t)
+	{
+		if(base_of_tile) (*base_of_tile)[t] = run;
+		run += (uint32_t)h[2 * t] + ((uint32_t)h[2 * t + 1] << 16);
+	}
+	s->lc_host_counter = run;
+	return 0;
+}
+
 static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream, bool stats)
 {
 	const yafgpu_render_params &rp = ra.rp;
@@ -1603,7 +1654,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 					if(rp.resample_mask[(size_t)(y - rp.ystart) * (size_t)rp.width + (size_t)(x - rp.xstart)]) listed.push_back((uint32_t)x | ((uint32_t)y << 16));
 			listed_prefix.push_back((uint32_t)listed.size());
 		}
-		if(listed.empty()) return 0;
+		if(listed.empty()) return replay_plan(s, rp).lc_sharded ? lc_exchange_counts(s, rp, {}, nullptr) : 0;      // (the other ranks wait for this one's counts)
 	}
 	const std::vector<uint32_t> &tile_px = masked ? listed_prefix : pp;      // pixels of the pass before every tile of the shard
 	const uint32_t n_pixels_total = tile_px.back();
@@ -1620,21 +1671,12 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	uint32_t max_paths = kWfMaxPaths;
 	if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) max_paths = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));     // tests chunk tiny frames
 	// recursiveRaytrace: a frame of 5 records per level a camera hit may recurse to
-	const int frames = ((s->has_specular || s->has_glossy) && rp.raydepth + s->max_add_depth > 0) ? rp.raydepth + s->max_add_depth : 0;
+	const ReplayPlan plan = replay_plan(s, rp);
+	const int frames = plan.frames;
 	const int frame_recs = s->has_glossy ? (s->has_bump ? 13 : 12) : 5;
 	if(frames > 7) return fail(-17, "raydepth + additionaldepth > 7 with mirror / transparent / glossy-recursive materials: the device path keeps at most 7 recursion frames per sample");
-	// Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
-	// can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
-	// (more than one light).  Not with recursiveRaytrace frames (a sample's events are then a tree, not a list: the
-	// per-sample streams stand in), and the light counter only on one GPU (a tile's starting value is the sum
-	// over all tiles before it, other ranks' included).
 	const bool path = rp.integrator == YAFGPU_INTEGRATOR_PATH;
-	const bool need_rr = path && rp.bounces - 1 > rp.rr_min_bounces;
-	const bool need_lc = path && s->n_lights > 1;
-	bool replay = rp.serial_replay != 0 && frames == 0 && (need_rr || need_lc);
-	if(const char *e = std::getenv("YAFGPU_SERIAL_REPLAY")) if(std::atoi(e) == 0) replay = false;
-	const bool replay_lights = replay && need_lc && rp.shard_count == 1;
-	if(replay && !need_rr && !replay_lights) replay = false;
+	const bool need_rr = plan.need_rr, replay = plan.replay, replay_lights = plan.replay_lights, lc_sharded = plan.lc_sharded;
 	const uint32_t n_ps = (uint32_t)std::max(rp.path_samples, 1), n_prob = (uint32_t)std::max(rp.bounces - 1, 1);
 	// chunks: runs of pixels whose paths are in flight together.  With the replay a chunk is a run of whole tiles (a tile's
 	// stream is walked in one go); without it any run of at most max_paths / spp pixels.
@@ -1726,11 +1768,12 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(segs > s->rp_segs)
 		{
 			HIP_OK(hipStreamSynchronize(stream));
-			for(void *q : {(void *)s->rp_seg_begin, (void *)s->rp_seg_seed, (void *)s->rp_seg_total}) if(q) (void)hipFree(q);
-			s->rp_seg_begin = nullptr; s->rp_seg_seed = nullptr; s->rp_seg_total = nullptr; s->rp_segs = 0;
+			for(void *q : {(void *)s->rp_seg_begin, (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base}) if(q) (void)hipFree(q);
+			s->rp_seg_begin = nullptr; s->rp_seg_seed = nullptr; s->rp_seg_total = nullptr; s->rp_seg_base = nullptr; s->rp_segs = 0;
 			HIP_OK(hipMalloc((void **)&s->rp_seg_begin, segs * sizeof(uint32_t)));
 			HIP_OK(hipMalloc((void **)&s->rp_seg_seed, segs * sizeof(uint32_t)));
 			HIP_OK(hipMalloc((void **)&s->rp_seg_total, segs * sizeof(uint32_t)));
+			HIP_OK(hipMalloc((void **)&s->rp_seg_base, segs * sizeof(uint32_t)));
 			s->rp_segs = segs;
 		}
 		HIP_OK(hipMemcpyAsync(s->rp_seg_begin, s->h_seg_begin.data(), segs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -1802,8 +1845,11 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		}
 		return 0;
 	};
-	size_t seg_off = 0;
-	for(const Chunk &ch : chunks)
+	// phase 0: the whole program for a chunk.  A sharded light counter (lc_sharded) splits it: phase 1 = record pass + the tiles'
+	// roulette walk and call counts, for every chunk; then the ranks exchange the counts; phase 2 = the rest, from the bases the
+	// exchange gave (a pass of one chunk keeps its events from phase 1, one of several records them again).
+	std::vector<std::pair<int, uint32_t>> own_calls;
+	auto process_chunk = [&](const Chunk &ch, size_t &seg_off, int phase) -> int
 	{
 		if(s->aborted()) return fail(-30, "aborted");
 		WfArgs a{};
@@ -1885,23 +1931,41 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		};
 		if(replay)
 		{
-			// record pass: the paths alone (no light estimates, no roulette kills), rays not counted
-			a.replay = 1;
-			yafgpu_counters *const keep = a.ra.counters;
-			a.ra.counters = nullptr;
-			HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * n_ps * sizeof(uint32_t), stream));
-			if((rc = run(iters_record, true))) return rc;
-			a.ra.counters = keep;
+			const bool have_events = phase == 2 && chunks.size() == 1;
+			if(!have_events)
+			{	// record pass: the paths alone (no light estimates, no roulette kills), rays not counted
+				a.replay = 1;
+				yafgpu_counters *const keep = a.ra.counters;
+				a.ra.counters = nullptr;
+				HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * n_ps * sizeof(uint32_t), stream));
+				if((rc = run(iters_record, true))) return rc;
+				a.ra.counters = keep;
+			}
 			const uint32_t n_seg = ch.tile_end - ch.tile_begin;
 			ReplayArgs r{};
 			r.seg_begin = s->rp_seg_begin + seg_off; r.seg_seed = s->rp_seg_seed + seg_off; r.n_seg = n_seg; r.spp = spp; r.n_paths = n_ps; r.n_prob = n_prob;
 			r.bounces = (uint32_t)std::max(rp.bounces, 1);
 			r.ev_flags = s->rp_flags; r.ev_p = s->rp_p; r.ev_kill = s->rp_kill; r.ev_calls = s->rp_calls; r.lc_base = s->rp_base;
 			r.seg_total = s->rp_seg_total + seg_off; r.lc_counter = s->rp_counter;
+			r.seg_base_in = phase == 2 ? s->rp_seg_base + seg_off : nullptr;
 			if((rc = timed(3, [&] {
-				hipLaunchKernelGGL(wf_replay_tiles, dim3(n_seg), dim3(kWave), 0, stream, r);
-				hipLaunchKernelGGL(wf_replay_bases, dim3(1), dim3(1), 0, stream, r);
-				hipLaunchKernelGGL(wf_replay_samples, dim3(n_seg), dim3(kWave), 0, stream, r); }))) return rc;
+				if(!have_events) hipLaunchKernelGGL(wf_replay_tiles, dim3(n_seg), dim3(kWave), 0, stream, r);
+				if(phase == 0) hipLaunchKernelGGL(wf_replay_bases, dim3(1), dim3(1), 0, stream, r);
+				if(phase != 1) hipLaunchKernelGGL(wf_replay_samples, dim3(n_seg), dim3(kWave), 0, stream, r); }))) return rc;
+			if(phase == 1)
+			{	// this chunk's calls per tile, by global tile index
+				std::vector<uint32_t> totals(n_seg);
+				HIP_OK(hipMemcpyAsync(totals.data(), s->rp_seg_total + seg_off, n_seg * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+				HIP_OK(hipStreamSynchronize(stream));
+				const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size;
+				for(uint32_t k = 0; k < n_seg; ++k)
+				{
+					const int4 &t = s->h_tiles[ch.tile_begin + k];
+					own_calls.emplace_back(((t.y - rp.ystart) / rp.tile_size) * ntx + (t.x - rp.xstart) / rp.tile_size, totals[k]);
+				}
+				seg_off += n_seg + 1;
+				return 0;
+			}
 			if(std::getenv("YAFGPU_VERBOSE"))
 			{
 				uint32_t cnt_now = 0;
@@ -1915,7 +1979,31 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if((rc = run(iters, false))) return rc;
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
+		return 0;
+	};
+	int rc = 0;
+	if(lc_sharded)
+	{
+		size_t seg_off = 0;
+		for(const Chunk &ch : chunks) if((rc = process_chunk(ch, seg_off, 1))) return rc;
+		std::vector<uint32_t> base_of_tile;
+		if((rc = lc_exchange_counts(s, rp, own_calls, &base_of_tile))) return rc;
+		// the bases in the layout of the segment tables (n + 1 entries per chunk)
+		const int ntx = (rp.width + rp.tile_size - 1) / rp.tile_size;
+		s->h_seg_base.clear();
+		for(const Chunk &ch : chunks)
+		{
+			for(uint32_t t = ch.tile_begin; t < ch.tile_end; ++t)
+			{
+				const int4 &r = s->h_tiles[t];
+				s->h_seg_base.push_back(base_of_tile[(size_t)(((r.y - rp.ystart) / rp.tile_size) * ntx + (r.x - rp.xstart) / rp.tile_size)]);
+			}
+			s->h_seg_base.push_back(0u);
+		}
+		HIP_OK(hipMemcpyAsync(s->rp_seg_base, s->h_seg_base.data(), s->h_seg_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 	}
+	size_t seg_off = 0;
+	for(const Chunk &ch : chunks) if((rc = process_chunk(ch, seg_off, lc_sharded ? 2 : 0))) return rc;
 	return 0;
 }
 
@@ -1975,7 +2063,12 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 	ra.n_tiles = (int)s->h_tiles.size();
 	ra.n_units = s->h_prefix.back();
 	if(!rp->accumulate) HIP_OK(hipMemsetAsync(d_planes, 0, yafgpu_planes_bytes(rp->width, rp->height), stream));
-	if(ra.n_tiles == 0) return 0;
+	if(ra.n_tiles == 0)
+	{	// a rank without tiles still owes the others its (empty) share of the light-counter exchange
+		const char *pl = std::getenv("YAFGPU_PIPELINE");
+		const bool mega = pl && std::strcmp(pl, "megakernel") == 0;
+		return (!mega && replay_plan(s, *rp).lc_sharded) ? lc_exchange_counts(s, *rp, {}, nullptr) : 0;
+	}
 	if(!s->d_queue) HIP_OK(hipMalloc((void **)&s->d_queue, kQueues * 32 * sizeof(uint32_t)));
 	if(!same)
 	{

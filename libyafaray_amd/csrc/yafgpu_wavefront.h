@@ -1724,6 +1724,7 @@ struct ReplayArgs
 	const uint32_t *ev_flags; const float *ev_p; uint8_t *ev_kill; uint8_t *ev_calls; uint32_t *lc_base;
 	uint32_t *seg_total;           // n_seg: light calls per segment, then (wf_replay_bases) the counter value the segment starts with
 	uint32_t *lc_counter;          // correlative_sample_number_ so far (carried over chunks and passes)
+	const uint32_t *seg_base_in;   // sharded frames: the counter value every segment starts with, from the ranks' exchange (else nullptr: wf_replay_bases left it in seg_total)
 };
 
 // One wave per tile.  Entries (camera sample x path sample) of a tile are contiguous and already in the reference's
@@ -1805,7 +1806,7 @@ __global__ __launch_bounds__(kWave) void wf_replay_samples(const ReplayArgs r)
 	for(uint32_t seg = blockIdx.x; seg < r.n_seg; seg += gridDim.x)
 	{
 		const uint32_t s0 = r.seg_begin[seg] * r.spp, n_slots = (r.seg_begin[seg + 1u] - r.seg_begin[seg]) * r.spp;
-		uint32_t run = r.seg_total[seg];
+		uint32_t run = r.seg_base_in ? r.seg_base_in[seg] : r.seg_total[seg];
 		for(uint32_t base = 0u; base < n_slots; base += kWave)
 		{
 			const uint32_t slot = s0 + base + (uint32_t)lane;

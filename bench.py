@@ -182,6 +182,11 @@ def main():
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.setShard(rank, world)            # pixel-tile sharding: tile t -> rank t % world
+    if world > 1:
+        # only workloads that consume the reference's serial light counter (several lights: c4) ever call it: a few KB of
+        # per-tile call counts per pass, so that the ranks make the single-GPU render's light choices
+        from libyafaray_amd.parallel import plane_exchange
+        yi.setPlaneExchange(plane_exchange(dev))
     if args.emulate_shard > 1 and world == 1:
         yi.setShard(0, args.emulate_shard)
     t0 = time.time()

@@ -103,6 +103,7 @@ typedef struct yafgpu_texture
 	float adj_int, adj_con, adj_sat, adj_hue, adj_r, adj_g, adj_b;    /* adj_hue already divided by 60 (Texture::setAdjustments) */
 	int32_t color_space;           /* for getRawColor / getFloat: 0 sRGB, 1 XYZ, 2 LinearRGB, 3 RawManualGamma */
 	float gamma;
+	int32_t normalmap;             /* texture_image.cc:705: a normal map (TextureMapperNode::evalDerivative reads the normal from its raw colour) */
 } yafgpu_texture;
 
 enum { YAFGPU_NODE_TEXTURE_MAPPER = 0, YAFGPU_NODE_VALUE = 1, YAFGPU_NODE_MIX = 2, YAFGPU_NODE_LAYER = 3 };

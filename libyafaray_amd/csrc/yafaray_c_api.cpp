@@ -261,7 +261,7 @@ int load_nodes(yafaray_interface *yi, const std::list<ParamMap> &list, LoadedNod
 				const yafgpu_texture &t = tex->second->t;
 				n.d_u = 1.f / (float)t.width; n.d_v = 1.f / (float)t.height;
 				bump_str /= std::sqrt(scale[0] * scale[0] + scale[1] * scale[1] + scale[2] * scale[2]);
-				bump_str /= 100.0f;
+				if(!t.normalmap) bump_str /= 100.0f;
 				n.bump_str = bump_str;
 			}
 		}
@@ -1117,7 +1117,7 @@ static bool texture_params(yafaray_interface *yi, const ParamMap &p, yafgpu_text
 	if(intp == "bicubic" || intp == "mipmap_trilinear" || intp == "mipmap_ewa")
 		return fail(yi, "createTexture: interpolate \"" + intp + "\" is not supported by the GPU path (none and bilinear are)");
 	bool normalmap = false; p.get("normalmap", normalmap);
-	if(normalmap) return fail(yi, "createTexture: normal maps are not supported by the GPU path");
+	t.normalmap = normalmap ? 1 : 0;                 // :563, :705
 	t.interpolate = intp == "none" ? 0 : 1;          // bilinear is the default (:575)
 	bool rot90 = false, even = false, odd = true, mirror_x = false, mirror_y = false, clamp = false;
 	int xrep = 1, yrep = 1; double minx = 0.0, miny = 0.0, maxx = 1.0, maxy = 1.0, cdist = 0.0;

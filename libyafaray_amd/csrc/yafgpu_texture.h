@@ -213,8 +213,9 @@ YG_DEV Rgba4 tex_get_color(const TexScene &ts, const yafgpu_texture &t, V3 p)
 	if(tex_do_mapping(t, p_1)) return ra4(0.f, 0.f, 0.f, 0.f);
 	return tex_apply_adjustments(t, tex_interpolate(ts, t, p_1));
 }
-YG_DEV float tex_get_float(const TexScene &ts, const yafgpu_texture &t, V3 p)
-{	// Texture::getFloat = applyIntensityContrastAdjustments(getRawColor(p).col2Bri()); getRawColor re-encodes into the texture's colour space
+// ImageTexture::getRawColor (texture_image.cc:90-104): getColor re-encoded into the texture's colour space
+YG_DEV Rgba4 tex_get_raw_color(const TexScene &ts, const yafgpu_texture &t, V3 p)
+{
 	Rgba4 c = tex_get_color(ts, t, p);
 	if(t.color_space == 0)
 	{
@@ -236,6 +237,11 @@ YG_DEV float tex_get_float(const TexScene &ts, const yafgpu_texture &t, V3 p)
 		const float inv = 1.f / gamma;
 		c.r = f_pow(c.r, inv); c.g = f_pow(c.g, inv); c.b = f_pow(c.b, inv);
 	}
+	return c;
+}
+YG_DEV float tex_get_float(const TexScene &ts, const yafgpu_texture &t, V3 p)
+{	// Texture::getFloat = applyIntensityContrastAdjustments(getRawColor(p).col2Bri())
+	const Rgba4 c = tex_get_raw_color(ts, t, p);
 	float f = (0.2126f * c.r + 0.7152f * c.g + 0.0722f * c.b);
 	if(!t.adj_set) return f;
 	if(t.adj_int != 1.f || t.adj_con != 1.f) f = (f - 0.5f) * t.adj_con + t.adj_int - 0.5f;
@@ -539,7 +545,18 @@ YG_DEV void nodes_eval_derivative(const TexScene &ts, const yafgpu_node *nodes, 
 			V3 ng;
 			V3 texpt = mapper_get_coords(n, cam, sp, ng);
 			float du = 0.0f, dv = 0.0f;
-			if(sp.has_uv && n.texco == kTcUv)
+			if(t.normalmap)
+			{	// :245-258 / :287-312: both branches read the normal from the texture's raw colour
+				texpt = mapper_do_mapping(n, texpt, ng);
+				const Rgba4 color = tex_get_raw_color(ts, t, texpt);
+				const V3 norm = normalize(mk(2.f * color.r - 1.f, 2.f * color.g - 1.f, 2.f * color.b - 1.f));
+				if(fabsf(norm.z) > 1e-30f)
+				{
+					const float nf = (float)(1.0 / (double)norm.z * (double)n.bump_str);
+					du = norm.x * nf; dv = norm.y * nf;
+				}
+			}
+			else if(sp.has_uv && n.texco == kTcUv)
 			{
 				texpt = mapper_do_mapping(n, texpt, ng);
 				const V3 i_0 = mk(texpt.x - n.d_u, texpt.y - 0.f, texpt.z - 0.f), i_1 = mk(texpt.x + n.d_u, texpt.y + 0.f, texpt.z + 0.f);

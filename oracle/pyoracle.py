@@ -56,7 +56,7 @@ class TextureDesc(C.Structure):
         ("cropmin_x", C.c_float), ("cropmin_y", C.c_float), ("cropmax_x", C.c_float), ("cropmax_y", C.c_float),
         ("adj_intensity", C.c_float), ("adj_contrast", C.c_float), ("adj_saturation", C.c_float), ("adj_hue", C.c_float),
         ("adj_red", C.c_float), ("adj_green", C.c_float), ("adj_blue", C.c_float), ("adj_clamp", C.c_int32),
-        ("color_space", C.c_int32), ("gamma", C.c_float),
+        ("color_space", C.c_int32), ("gamma", C.c_float), ("normalmap", C.c_int32),
     ]
 
 
@@ -105,6 +105,7 @@ def texture_desc(t):
     d.adj_clamp = int(t.get("adj_clamp", False))
     d.color_space = COLOR_SPACE.get(t.get("color_space", "Raw_Manual_Gamma"), 0)   # the factory's default (:552); unknown names read as sRGB (:613)
     d.gamma = t.get("gamma", 1.0)
+    d.normalmap = int(t.get("normalmap", False))
     return d
 
 

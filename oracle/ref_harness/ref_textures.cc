@@ -234,6 +234,7 @@ static void sec_nodes(Json &j)
 	//   0..N-1 mappers | value | mix of (mapper k, value) by every mode | layer over (mapper k) for every blend mode and flag set
 	const int texcos[] = {TextureMapperNode::Uv, TextureMapperNode::Glob, TextureMapperNode::Orco, TextureMapperNode::Tran, TextureMapperNode::Win, TextureMapperNode::Nor};
 	std::vector<ShaderNode *> nodes;
+	std::vector<TextureMapperNode *> mappers;
 	std::vector<uint32_t> desc;       // per node: type and its parameters, as the test rebuilds them (see tests/test_oracle_golden.py)
 	for(int tc : texcos)
 		for(int proj = 0; proj < 4; ++proj)
@@ -251,6 +252,7 @@ static void sec_nodes(Json &j)
 			tm->setup();
 			tm->id_ = (unsigned)nodes.size();
 			nodes.push_back(tm);
+			mappers.push_back(tm);
 			desc.push_back(0u); desc.push_back((uint32_t)tc); desc.push_back((uint32_t)proj);
 			desc.push_back((uint32_t)tm->map_x_); desc.push_back((uint32_t)tm->map_y_); desc.push_back((uint32_t)tm->map_z_);
 			for(float f : sc) desc.push_back(f2u(f));
@@ -322,7 +324,7 @@ static void sec_nodes(Json &j)
 	// bump mapping: evalDerivative of every node (TextureMapperNode :232-343 — the UV branch on a discrete texture, the branch for
 	// every other coordinate kind —, LayerNode :122-152, the base class's zero for value / mix) and Material::applyBump with the last
 	// layer's derivative (material.cc:77-84).  Surface points as above plus the shading-space UV derivatives getSurface leaves.
-	std::vector<uint32_t> bin, bout, bsp;
+	std::vector<uint32_t> bin, bout, bsp, bnout;
 	ParamMap mp; mp["type"] = std::string("shinydiffusemat");
 	std::list<ParamMap> no_nodes;
 	Material *any_mat = ShinyDiffuseMaterial::factory(mp, no_nodes, fake_env());
@@ -338,6 +340,13 @@ static void sec_nodes(Json &j)
 		                         sp.has_uv_ ? 1.f : 0.f};
 		for(float f : extra) bin.push_back(f2u(f));
 		NodeStack stack(stack_mem.data());
+		// the same texture as a NORMAL MAP (texture_image.cc:705 normalmap_; evalDerivative's other two branches, setup() without the / 100)
+		tex->normalmap_ = true;
+		for(TextureMapperNode *tm : mappers) { tm->bump_str_ = 1.f; tm->setup(); }
+		for(ShaderNode *n : nodes) n->evalDerivative(stack, state, sp);
+		for(size_t i = 0; i < nodes.size(); ++i) { push_rgba(bnout, stack_mem[i].col_); bnout.push_back(f2u(stack_mem[i].f_)); }
+		tex->normalmap_ = false;
+		for(TextureMapperNode *tm : mappers) { tm->bump_str_ = 1.f; tm->setup(); }
 		for(ShaderNode *n : nodes) n->evalDerivative(stack, state, sp);
 		for(size_t i = 0; i < nodes.size(); ++i) { push_rgba(bout, stack_mem[i].col_); bout.push_back(f2u(stack_mem[i].f_)); }
 		float du, dv;
@@ -349,6 +358,7 @@ static void sec_nodes(Json &j)
 	j.arr_u32("bump_in", bin);
 	j.arr_u32("bump_out", bout);
 	j.arr_u32("bump_applied", bsp);
+	j.arr_u32("bump_normalmap_out", bnout);
 }
 
 int main(int argc, char **argv)

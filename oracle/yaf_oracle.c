@@ -1032,6 +1032,7 @@ typedef struct tex_s
 	int cropx, cropy; float cropminx, cropmaxx, cropminy, cropmaxy;
 	int adj_set, adj_clamp; float adj_int, adj_con, adj_sat, adj_hue, adj_r, adj_g, adj_b;
 	int color_space; float gamma;
+	int normalmap;
 } tex_t;
 typedef struct { float r, g, b, a; } rgba_t;
 static inline rgba_t RA(float r, float g, float b, float a) { rgba_t c = {r, g, b, a}; return c; }
@@ -1056,7 +1057,7 @@ static void tex_configure(tex_t *t, const yor_texture_desc *d)
 	t->adj_clamp = d->adj_clamp; t->adj_r = d->adj_red; t->adj_g = d->adj_green; t->adj_b = d->adj_blue;
 	t->adj_set = d->adj_intensity != 1.f || d->adj_contrast != 1.f || d->adj_saturation != 1.f || d->adj_hue != 0.f ||
 	             d->adj_red != 1.f || d->adj_green != 1.f || d->adj_blue != 1.f || d->adj_clamp;
-	t->color_space = d->color_space; t->gamma = d->gamma;
+	t->color_space = d->color_space; t->gamma = d->gamma; t->normalmap = d->normalmap;
 }
 
 static inline rgba_t tex_pixel(const tex_t *t, int x, int y)
@@ -1421,11 +1422,24 @@ static void nodes_eval_derivative(const node_t *nodes, int n_nodes, const tex_t 
 			const float d_u = 1.f / (float)t->w, d_v = 1.f / (float)t->h;
 			float bump_str = n->bump_strength;
 			bump_str /= vlength(n->scale);
-			bump_str /= 100.0f;
+			if(!t->normalmap) bump_str /= 100.0f;
 			v3 texpt, ng;
 			float du = 0.0f, dv = 0.0f;
 			mapper_get_coords(n, cam, sp, &texpt, &ng);
-			if(sp->has_uv && n->texco == TC_UV)
+			if(t->normalmap)
+			{	/* :245-258 / :287-312: both branches read the normal from the texture's raw colour */
+				texpt = mapper_do_mapping(n, texpt, ng);
+				rgba_t color = color_space_from_linear(tex_get_color(t, texpt), t->color_space, t->gamma);      /* getRawColor */
+				v3 norm = V(2.f * color.r - 1.f, 2.f * color.g - 1.f, 2.f * color.b - 1.f);
+				norm = vnormalize(norm);
+				if(fabsf(norm.z) > 1e-30f)
+				{
+					float nf = (float)(1.0 / (double)norm.z * (double)bump_str);
+					du = norm.x * nf; dv = norm.y * nf;
+				}
+				else du = dv = 0.f;
+			}
+			else if(sp->has_uv && n->texco == TC_UV)
 			{
 				texpt = mapper_do_mapping(n, texpt, ng);
 				v3 i_0 = V(texpt.x - d_u, texpt.y - 0.f, texpt.z - 0.f), i_1 = V(texpt.x + d_u, texpt.y + 0.f, texpt.z + 0.f);

@@ -105,6 +105,7 @@ typedef struct yor_texture_desc
 	int32_t adj_clamp;
 	int32_t color_space;       /* for getRawColor (texture_image.cc:90-104): 0 sRGB, 1 XYZ, 2 LinearRGB, 3 RawManualGamma */
 	float gamma;
+	int32_t normalmap;         /* texture_image.cc:705: the texture is a normal map (changes TextureMapperNode::evalDerivative and setup()) */
 } yor_texture_desc;
 
 enum { YOR_NODE_TEXTURE_MAPPER = 0, YOR_NODE_VALUE = 1, YOR_NODE_MIX = 2, YOR_NODE_LAYER = 3 };

@@ -1187,6 +1187,9 @@ def _texturize(sc, rng):
                 m.pop(key)
     # bump shaders, from a stream of their own (the draws above stay what they were): one layer, sometimes two, over any coordinates
     rb = np.random.default_rng(int(rng.integers(0, 2 ** 31)))
+    for t in sc["textures"]:
+        if rb.random() < 0.25:
+            t["normalmap"] = True      # only a bump shader's mapper reads the flag
     for mi, m in enumerate(sc["materials"]):
         if m.get("type", "shinydiffusemat") not in ("shinydiffusemat", "glossy", "coated_glossy", "glass") or rb.random() < 0.65:
             continue

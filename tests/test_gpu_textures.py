@@ -151,10 +151,12 @@ def test_device_shader_node_graph_matches_the_reference():
     assert not bad_nodes, f"{len(bad_nodes)} of {len(nodes)} nodes differ, first: {bad_nodes[0]}"
 
 
-def test_device_bump_derivatives_match_the_reference():
+@pytest.mark.parametrize("normalmap", [False, True])
+def test_device_bump_derivatives_match_the_reference(normalmap):
     """evalDerivative of every node of the harness's graph on the device (probe op 15; one material per node with that node as its
     BUMP shader, so the host's bump list — NodeMaterial::bump_nodes_ — is what is evaluated) at the harness's 40 surface points
-    with and without UVs, and Material::applyBump with the last layer's derivative: bit for bit."""
+    with and without UVs, and Material::applyBump with the last layer's derivative: bit for bit.  normalmap: the same texture flagged
+    as a normal map (evalDerivative's two other branches, setup() without the / 100)."""
     g = golden("ieee")
     nodes = _node_graph(g)
     c = f32(g["nodes_camera"])
@@ -163,7 +165,7 @@ def test_device_bump_derivatives_match_the_reference():
     yi = Interface()
     yi.startScene(0)
     yi.paramsClearAll()
-    yi.paramsSet({"type": "image", "interpolate": "bilinear", "clipping": "repeat", "color_space": "sRGB"})
+    yi.paramsSet({"type": "image", "interpolate": "bilinear", "clipping": "repeat", "color_space": "sRGB", "normalmap": normalmap})
     yi.createTextureFromMemory("t", f32(g["nodes_texels"]).reshape(5, 6, 4))
     first, ranges, mats = 0, [], []
     for n in nodes:
@@ -186,7 +188,7 @@ def test_device_bump_derivatives_match_the_reference():
         first += cnt
     _one_triangle_scene(yi, mats[0], cam)
     sps = f32(g["bump_in"]).reshape(-1, 31)
-    want = f32(g["bump_out"]).reshape(len(sps), len(nodes), 5)
+    want = f32(g["bump_normalmap_out" if normalmap else "bump_out"]).reshape(len(sps), len(nodes), 5)
     want9 = f32(g["bump_applied"]).reshape(len(sps), 9)
     bad_nodes = []
     for k, (n, (start, cnt)) in enumerate(zip(nodes, ranges)):
@@ -201,7 +203,7 @@ def test_device_bump_derivatives_match_the_reference():
         if (got.view(np.uint32) != want[:, k].view(np.uint32)).any():
             p = int(np.nonzero((got.view(np.uint32) != want[:, k].view(np.uint32)).any(axis=1))[0][0])
             bad_nodes.append(f"{n} at point {p} (has_uv {sps[p, 30]}): {got[p]} vs {want[p, k]}")
-        if k == len(nodes) - 1:
+        if k == len(nodes) - 1 and not normalmap:
             assert np.array_equal(out[:, 5 * cnt:].view(np.uint32), want9.view(np.uint32)), "applyBump differs"
     assert not bad_nodes, f"{len(bad_nodes)} of {len(nodes)} nodes differ, first: {bad_nodes[0]}"
 
@@ -255,8 +257,13 @@ def test_bump_mapped_glossy_and_glass_match_oracle():
     bump = lambda name, inp, **kw: dict(dict(name=name, type="layer", input=inp, mode=0, valfac=1.0, def_val=1.0, do_color=False, do_scalar=True, color_input=False,
                                              upper_value=0.0), **kw)
     m = sc["materials"]
-    m[0] = {"type": "shinydiffusemat", "color": (0.8, 0.8, 0.8), "diffuse_reflect": 0.9, "bump_shader": "bmp",
-            "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_rgb", "uv", bump_strength=2.0)]}
+    # the walls: a NORMAL MAP (texels around (0.5, 0.5, 1)) over global coordinates, under a plain bump layer read through `uv`
+    rng = np.random.default_rng(77)
+    nrm = np.concatenate([rng.uniform(0.3, 0.7, (9, 11, 2)), rng.uniform(0.8, 1.0, (9, 11, 1)), np.ones((9, 11, 1))], axis=2).astype(np.float32)
+    sc["textures"].append(dict(name="t_nrm", texels=nrm, interpolate="bilinear", clipping="repeat", color_space="LinearRGB", normalmap=True))
+    m[0] = {"type": "shinydiffusemat", "color": (0.8, 0.8, 0.8), "diffuse_reflect": 0.9, "bump_shader": "bmp2",
+            "nodes": [bump("bmp2", "nmap", upper_layer="bmp"), mapper("nmap", "t_nrm", "global", "cube", bump_strength=0.4, scale=(2.0, 2.0, 2.0)),
+                      bump("bmp", "bmap"), mapper("bmap", "t_rgb", "uv", bump_strength=2.0)]}
     m[1] = {"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.4, "glossy_reflect": 0.6, "exponent": 80.0, "as_diffuse": False,
             "bump_shader": "bmp", "nodes": [bump("bmp", "bmap"), mapper("bmap", "t_rgb", "orco", "cube", bump_strength=2.5)]}
     m[2] = {"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.5, "glossy_reflect": 0.5, "exponent": 100.0,

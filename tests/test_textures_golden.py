@@ -157,3 +157,13 @@ def test_bump_derivatives_and_apply_bump():
         msg = f"{len(bad)} nodes differ, first: {nodes[bad[0]]} at point {k} (has_uv {sps[k, 30]}): {got[k, bad[0]]} vs {want[k, bad[0]]}"
     assert not bad, msg
     assert np.array_equal(got9.view(np.uint32), want9.view(np.uint32)), "applyBump differs"
+    # the same texture flagged as a normal map: evalDerivative's other two branches, setup() without the / 100
+    tdn = po.texture_desc(dict(tex, normalmap=True))
+    wantn = f32(g["bump_normalmap_out"]).reshape(len(sps), len(nodes), 5)
+    gotn = np.zeros_like(wantn)
+    for k in range(len(sps)):
+        L.yor_nodes_probe_derivative(len(nodes), C.cast(arr, C.c_void_p), 1, C.cast(C.pointer(tdn), C.c_void_p), C.cast(C.pointer(cam), C.c_void_p),
+                                     po.fptr(np.ascontiguousarray(sps[k])), 1.0, po.fptr(gotn[k]), None)
+    diff = (gotn.view(np.uint32) != wantn.view(np.uint32)).any(axis=2)
+    bad = sorted(set(np.nonzero(diff)[1].tolist()))
+    assert not bad, f"normal map: {len(bad)} nodes differ, first {nodes[bad[0]]}: {gotn[np.nonzero(diff[:, bad[0]])[0][0], bad[0]]} vs {wantn[np.nonzero(diff[:, bad[0]])[0][0], bad[0]]}"

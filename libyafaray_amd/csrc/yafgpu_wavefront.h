@@ -262,7 +262,16 @@ enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECUR
 #ifndef YAFGPU_HOT_ACC
 #define YAFGPU_HOT_ACC 1      // C2 shade: 0 -> 7.8 ms, 1 -> 6.9 ms per pass (3 waves/SIMD)
 #endif
-struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty; };
+// acc_zero: the light-estimate accumulators 15..17 are all zero and their records in memory are NOT kept up to date — the state
+// between two light estimates, and, with one-sample lights, at every park: the flag travels in bit 18 of the word record 14 keeps
+// (kDlcAccZero), so a resumed shadow answer neither loads three records of zeros nor, having closed its light, writes them back
+// (6 of the ~21 record writes and 3 of the ~22 record reads of a vertex of the benchmark scenes).
+#ifndef YAFGPU_ACC_ZERO_FLAG
+#define YAFGPU_ACC_ZERO_FLAG 1      // 0: the accumulators are always kept in memory (A/B: profiles/r02_ab_acczero.txt)
+#endif
+struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty, acc_zero; };
+constexpr uint32_t kHotAccBits = 0x70u, kHot14 = 0x08u;
+constexpr uint32_t kDlcAccZero = 1u << 18;
 template<int K> constexpr bool hot_cached() { return K == 11 || K == 12 || K == 14 || K == 18 || (YAFGPU_HOT_ACC && K >= 15 && K <= 17); }
 template<int K> YG_DEV float4 &hot_ref(Hot &h)
 {
@@ -287,21 +296,56 @@ template<int K> YG_DEV void hot_set(const WfArgs &a, uint32_t slot, Hot &h, floa
 	else
 	{
 		constexpr uint32_t bit = 1u << (K - 11);
+		if constexpr(YAFGPU_HOT_ACC && K >= 15 && K <= 17)
+		{
+			if(h.acc_zero)
+			{	// no longer all zero: from here on the three records are kept in memory again (the other two as the zeros they hold)
+				h.acc_zero = 0u;
+				if(!(h.valid & kHot14)) { h.r14 = REC(14); h.valid |= kHot14; }
+				h.dirty |= kHotAccBits | kHot14;
+			}
+		}
 		hot_ref<K>(h) = v; h.valid |= bit; h.dirty |= bit;
+	}
+}
+// accumulators := 0 (the start of a light estimate, a light closed)
+YG_DEV void hot_zero_acc(const WfArgs &a, uint32_t slot, Hot &h)
+{
+	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if(!YAFGPU_HOT_ACC) { REC(15) = z4; REC(16) = z4; REC(17) = z4; return; }
+	if(!YAFGPU_ACC_ZERO_FLAG) { hot_set<15>(a, slot, h, z4); hot_set<16>(a, slot, h, z4); hot_set<17>(a, slot, h, z4); return; }
+	h.r15 = z4; h.r16 = z4; h.r17 = z4;
+	h.valid |= kHotAccBits; h.dirty &= ~kHotAccBits;
+	if(!h.acc_zero)
+	{
+		h.acc_zero = 1u;
+		if(!(h.valid & kHot14)) { h.r14 = REC(14); h.valid |= kHot14; }
+		h.dirty |= kHot14;
 	}
 }
 YG_DEV void hot_preload(const WfArgs &a, uint32_t slot, Hot &h)
 {
 	h.r11 = REC(11); h.r12 = REC(12); h.r14 = REC(14); h.r18 = REC(18);
-	h.valid = 0x8bu; h.dirty = 0u;
-	if(YAFGPU_HOT_ACC) { h.r15 = REC(15); h.r16 = REC(16); h.r17 = REC(17); h.valid = 0xfbu; }
+	h.valid = 0x8bu; h.dirty = 0u; h.acc_zero = 0u;
+	if(YAFGPU_HOT_ACC)
+	{
+		h.acc_zero = (YAFGPU_ACC_ZERO_FLAG && (ubits(h.r14.w) & kDlcAccZero)) ? 1u : 0u;
+		if(h.acc_zero) { const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f); h.r15 = z4; h.r16 = z4; h.r17 = z4; }
+		else { h.r15 = REC(15); h.r16 = REC(16); h.r17 = REC(17); }
+		h.valid = 0xfbu;
+	}
 }
 YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 {
 	if(h.dirty & 0x01u) REC(11) = h.r11;
 	if(h.dirty & 0x02u) REC(12) = h.r12;
-	if(h.dirty & 0x08u) REC(14) = h.r14;
-	if(YAFGPU_HOT_ACC)
+	if(h.dirty & 0x08u)
+	{
+		float4 r14 = h.r14;
+		if(YAFGPU_HOT_ACC) r14.w = fbits((ubits(r14.w) & ~kDlcAccZero) | (h.acc_zero ? kDlcAccZero : 0u));
+		REC(14) = r14;
+	}
+	if(YAFGPU_HOT_ACC && !h.acc_zero)
 	{
 		if(h.dirty & 0x10u) REC(15) = h.r15;
 		if(h.dirty & 0x20u) REC(16) = h.r16;
@@ -382,7 +426,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
 		{
 			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0))));
-			HSET(15, z4); HSET(16, z4); HSET(17, z4);
+			hot_zero_acc(a, slot, h);
 			c.dl_on_sp0 = 1;
 			return W_DL_NEXT;
 		}
@@ -435,7 +479,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		misc.z = fbits(calls + 1u);
 		REC(19) = misc;
 		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0))));
-		HSET(15, z4); HSET(16, z4); HSET(17, z4);
+		hot_zero_acc(a, slot, h);
 		c.dl_on_sp0 = 0;
 		return W_DL_NEXT;
 	}
@@ -449,7 +493,7 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict
 	const DevScene &sc = a.ra.sc;
 	float4 r14 = HGET(14);
 	const uint32_t w = ubits(r14.w);
-	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0xfu), is = (int)(w >> 20);
+	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0x3u), is = (int)(w >> 20);
 	const bool dirac = sc.lights[li].type == YAFGPU_LIGHT_POINT;
 	// transparent shadows (integrator_montecarlo.cc:114,182,309): what an unblocked ray picked up on its way scales the
 	// light.  (The reference scales the light colour before forming the contribution, here the parked contribution is
@@ -499,8 +543,7 @@ YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h, int level)
 		if(dirac) col = col + c3(HGET(17));
 		else { col = col + c3(HGET(15)) * inv_ns; col = col + c3(HGET(16)) * inv_ns; }
 		HSET(18, f4(c3(HGET(18)) + col, 0.f));
-		const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-		HSET(15, z4); HSET(16, z4); HSET(17, z4);
+		hot_zero_acc(a, slot, h);
 		is = 0; ++li;
 	}
 	HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(li, l_end, 0, is))));
@@ -900,7 +943,7 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// previous one had just stored), and they are written back once, when the path parks.  (Also forwarding the
 	// vertex st_after_closest writes to st_dl_eval in registers costs more in spills than the round trip it saves:
 	// 6.9 -> 7.7 ms on C2.)
-	Hot h; h.valid = 0u; h.dirty = 0u;
+	Hot h; h.valid = 0u; h.dirty = 0u; h.acc_zero = 0u;
 	uint2 verdict = make_uint2(0u, 0u);
 	if(where == W_AFTER_SHADOW)
 	{	// bit 2*slot + which of the verdict bit array (set by the any-hit kernel for an occluded ray)

@@ -269,9 +269,11 @@ enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECUR
 #ifndef YAFGPU_ACC_ZERO_FLAG
 #define YAFGPU_ACC_ZERO_FLAG 1      // 0: the accumulators are always kept in memory (A/B: profiles/r02_ab_acczero.txt)
 #endif
-struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty, acc_zero; };
-constexpr uint32_t kHotAccBits = 0x70u, kHot14 = 0x08u;
-constexpr uint32_t kDlcAccZero = 1u << 18;
+// tot_zero: the same for record 18, the estimate's sum over the lights closed so far (zero from the start of a vertex's estimate to
+// its first closed light, dead once st_dl_done has taken it): bit 19 (kDlcTotZero).
+struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty, acc_zero, tot_zero; };
+constexpr uint32_t kHotAccBits = 0x70u, kHot14 = 0x08u, kHot18 = 0x80u;
+constexpr uint32_t kDlcAccZero = 1u << 18, kDlcTotZero = 1u << 19;
 template<int K> constexpr bool hot_cached() { return K == 11 || K == 12 || K == 14 || K == 18 || (YAFGPU_HOT_ACC && K >= 15 && K <= 17); }
 template<int K> YG_DEV float4 &hot_ref(Hot &h)
 {
@@ -305,7 +307,29 @@ template<int K> YG_DEV void hot_set(const WfArgs &a, uint32_t slot, Hot &h, floa
 				h.dirty |= kHotAccBits | kHot14;
 			}
 		}
+		if constexpr(YAFGPU_ACC_ZERO_FLAG && K == 18)
+		{
+			if(h.tot_zero)
+			{
+				h.tot_zero = 0u;
+				if(!(h.valid & kHot14)) { h.r14 = REC(14); h.valid |= kHot14; }
+				h.dirty |= kHot14;
+			}
+		}
 		hot_ref<K>(h) = v; h.valid |= bit; h.dirty |= bit;
+	}
+}
+// record 18 := 0 (the start of a vertex's light estimate; its sum taken by st_dl_done)
+YG_DEV void hot_zero_tot(const WfArgs &a, uint32_t slot, Hot &h)
+{
+	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	if(!YAFGPU_ACC_ZERO_FLAG) { hot_set<18>(a, slot, h, z4); return; }
+	h.r18 = z4; h.valid |= kHot18; h.dirty &= ~kHot18;
+	if(!h.tot_zero)
+	{
+		h.tot_zero = 1u;
+		if(!(h.valid & kHot14)) { h.r14 = REC(14); h.valid |= kHot14; }
+		h.dirty |= kHot14;
 	}
 }
 // accumulators := 0 (the start of a light estimate, a light closed)
@@ -323,16 +347,20 @@ YG_DEV void hot_zero_acc(const WfArgs &a, uint32_t slot, Hot &h)
 		h.dirty |= kHot14;
 	}
 }
-YG_DEV void hot_preload(const WfArgs &a, uint32_t slot, Hot &h)
+// with_path: throughput and path colour (11, 12) exist — not during the camera vertex's own estimate (st_start_path sets them up)
+YG_DEV void hot_preload(const WfArgs &a, uint32_t slot, Hot &h, bool with_path)
 {
-	h.r11 = REC(11); h.r12 = REC(12); h.r14 = REC(14); h.r18 = REC(18);
-	h.valid = 0x8bu; h.dirty = 0u; h.acc_zero = 0u;
+	h.r14 = REC(14);
+	h.valid = 0x88u; h.dirty = 0u; h.acc_zero = 0u;
+	if(with_path || !YAFGPU_ACC_ZERO_FLAG) { h.r11 = REC(11); h.r12 = REC(12); h.valid |= 0x03u; }
+	h.tot_zero = (YAFGPU_ACC_ZERO_FLAG && (ubits(h.r14.w) & kDlcTotZero)) ? 1u : 0u;
+	if(h.tot_zero) h.r18 = make_float4(0.f, 0.f, 0.f, 0.f); else h.r18 = REC(18);
 	if(YAFGPU_HOT_ACC)
 	{
 		h.acc_zero = (YAFGPU_ACC_ZERO_FLAG && (ubits(h.r14.w) & kDlcAccZero)) ? 1u : 0u;
 		if(h.acc_zero) { const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f); h.r15 = z4; h.r16 = z4; h.r17 = z4; }
 		else { h.r15 = REC(15); h.r16 = REC(16); h.r17 = REC(17); }
-		h.valid = 0xfbu;
+		h.valid |= kHotAccBits;
 	}
 }
 YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
@@ -342,7 +370,7 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 	if(h.dirty & 0x08u)
 	{
 		float4 r14 = h.r14;
-		if(YAFGPU_HOT_ACC) r14.w = fbits((ubits(r14.w) & ~kDlcAccZero) | (h.acc_zero ? kDlcAccZero : 0u));
+		if(YAFGPU_HOT_ACC) r14.w = fbits((ubits(r14.w) & ~(kDlcAccZero | kDlcTotZero)) | (h.acc_zero ? kDlcAccZero : 0u) | (h.tot_zero ? kDlcTotZero : 0u));
 		REC(14) = r14;
 	}
 	if(YAFGPU_HOT_ACC && !h.acc_zero)
@@ -351,7 +379,7 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
 		if(h.dirty & 0x20u) REC(16) = h.r16;
 		if(h.dirty & 0x40u) REC(17) = h.r17;
 	}
-	if(h.dirty & 0x80u) REC(18) = h.r18;
+	if((h.dirty & 0x80u) && !h.tot_zero) REC(18) = h.r18;
 }
 #define HGET(k) hot_get<k>(a, slot, h)
 #define HSET(k, v) hot_set<k>(a, slot, h, (v))
@@ -417,11 +445,9 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 			alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
 		}
 		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
-		Mwc rr; rr.init(fnv32a(ordinal) + 123u);   // see DESIGN.md: Russian-roulette stream (row N4)
-		HSET(11, make_float4(1.f, 1.f, 1.f, fbits(rr.x)));
-		HSET(12, make_float4(0.f, 0.f, 0.f, fbits(rr.c)));
+		// (throughput, path colour and the roulette stream of this level's path samples: st_start_path, at the first of them)
 		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(0u), alpha);
-		HSET(18, z4);
+		hot_zero_tot(a, slot, h);
 		c.path_i = 0; c.depth = 0;
 		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
 		{
@@ -449,7 +475,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
 	// .w of 8..10: p_ray.dir_ of the segment that ended here — what Material::sample leaves in `wi` when it samples nothing
 	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, dir.x); REC(9) = f4(hit.ng, dir.y); REC(10) = f4(pwo, dir.z);
-	HSET(18, z4);
+	hot_zero_tot(a, slot, h);
 	if(YAFGPU_FEAT_RECURSE && (mb & kVolumetric) && c.stage == kStDepth && pm.has_vol_i && dot(hit.n, pwo) < 0.f)
 	{	// integrator_path_tracer.cc:276-279: the segment ran inside an absorbing material (lcol does not depend on it)
 		const float4 r11 = HGET(11);
@@ -476,8 +502,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 			h2.set_start(rp.base_sampling_offset + counter - 1u);
 			lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
 		}
-		misc.z = fbits(calls + 1u);
-		REC(19) = misc;
+		if(sc.n_lights > 1) { misc.z = fbits(calls + 1u); REC(19) = misc; }      // (only the choice among several lights reads it)
 		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0))));
 		hot_zero_acc(a, slot, h);
 		c.dl_on_sp0 = 0;
@@ -599,6 +624,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const Col total = c3(HGET(18));
 	const int l_end = (int)((ubits(HGET(14).w) >> 8) & 0xffu);
+	hot_zero_tot(a, slot, h);                       // taken: nothing reads it again before the next vertex zeroes it
 	if(c.stage == kStPrimary)
 	{
 		const uint32_t bsdfs0 = ubits(REC(5).w);
@@ -710,7 +736,7 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 }
 
 // first segment of path sample `path_i` from the camera hit, :186-216 — or the end of the sample
-YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs)
+YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const DivState dv = wf_div(a, slot, c.level);
@@ -737,7 +763,13 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
 	REC(6).w = w;
 	REC(10) = f4(wo0, 0.f);                          // pwo = wo
-	HSET(11, f4(scol, HGET(11).w));                   // throughput = scol
+	if(c.path_i == 0)
+	{	// the level's first path sample: path colour 0 and the roulette stream of the per-sample mode start here
+		Mwc rr; rr.init(fnv32a(ordinal) + 123u);
+		HSET(11, f4(scol, fbits(rr.x)));
+		HSET(12, make_float4(0.f, 0.f, 0.f, fbits(rr.c)));
+	}
+	else HSET(11, f4(scol, HGET(11).w));              // throughput = scol
 	float4 misc = REC(19);
 	misc.x = fbits(offs); misc.y = fbits(bs.sampled);
 	REC(19) = misc;
@@ -871,14 +903,14 @@ YG_DEV int st_recurse(const WfArgs &a, uint32_t slot, Ctl &c)
 	return W_RECURSE_SPEC;
 }
 // an integrate() ends with (c.col, alpha): hand it to the level above, which either sends its transmitted ray or ends too
-YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c)
+YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 {
 	const yafgpu_render_params &rp = a.ra.rp;
 	float alpha = REC(19).w;
 	for(;;)
 	{
 		if(rp.bg_transp) alpha = smax(alpha, 0.f);      // EmptyVolumeIntegrator: transmittance 1 (integrator_path_tracer.cc:336-344)
-		if(!YAFGPU_FEAT_RECURSE || c.level == 0) { REC(19) = make_float4(0.f, 0.f, 0.f, alpha); return W_FINISH; }
+		if(!YAFGPU_FEAT_RECURSE || c.level == 0) { alpha_out = alpha; return W_FINISH; }
 		const int P = c.level - 1;
 		const float4 f0 = FREC(P, 0), f2 = FREC(P, 2);
 		const uint32_t flags = ubits(f2.w);
@@ -943,13 +975,14 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// previous one had just stored), and they are written back once, when the path parks.  (Also forwarding the
 	// vertex st_after_closest writes to st_dl_eval in registers costs more in spills than the round trip it saves:
 	// 6.9 -> 7.7 ms on C2.)
-	Hot h; h.valid = 0u; h.dirty = 0u; h.acc_zero = 0u;
+	Hot h; h.valid = 0u; h.dirty = 0u; h.acc_zero = 0u; h.tot_zero = 0u;
+	float alpha = 0.f;
 	uint2 verdict = make_uint2(0u, 0u);
 	if(where == W_AFTER_SHADOW)
 	{	// bit 2*slot + which of the verdict bit array (set by the any-hit kernel for an occluded ray)
 		const uint32_t w = a.verdict[slot >> 4], sh = (slot & 15u) << 1;
 		verdict = make_uint2((w >> sh) & 1u, (w >> (sh + 1u)) & 1u);
-		hot_preload(a, slot, h);
+		hot_preload(a, slot, h, c.stage != kStPrimary);
 	}
 	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
 	// order (a dispatch loop makes the optimizer thread the transitions, duplicate the steps and keep the union
@@ -963,7 +996,7 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	}
 	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
-	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs);
+	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_RECURSE) where = st_recurse(a, slot, c);
 #if YAFGPU_FEAT_RECURSE
 	// recursion: return -> (next glossy trajectory | the specular branch of the level above) -> park or return again
@@ -972,17 +1005,16 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 		if(where == W_GLOSSY_NEXT) where = st_glossy_next(a, slot, c, pixel_sample, sampling_offs);
 		if(where == W_RECURSE_SPEC) where = st_recurse_spec(a, slot, c);
 		if(where != W_RETURN) break;
-		where = st_return(a, slot, c);
+		where = st_return(a, slot, c, alpha);
 		if(where != W_GLOSSY_NEXT && where != W_RECURSE_SPEC) break;
 	}
 #else
-	if(where == W_RETURN) where = st_return(a, slot, c);
+	if(where == W_RETURN) where = st_return(a, slot, c, alpha);
 #endif
 	if(where != W_FINISH) hot_flush(a, slot, h);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
 	// W_FINISH
-	float alpha = REC(19).w;
 	if(a.ra.rp.bg_transp) alpha = smax(alpha, 0.f);   // EmptyVolumeIntegrator: transmittance 1 (integrator_empty_volume.cc:32-38)
 	result[0] = c.col.r; result[1] = c.col.g; result[2] = c.col.b; result[3] = alpha;
 	return kReqDone;
@@ -1000,7 +1032,7 @@ __global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArg
 }
 #define PROBE(name, call) __global__ __launch_bounds__(kBlock, PROBE_WAVES) void name(const WfArgs a, int *out) { \
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
-	Hot h; hot_preload(a, slot, h); const int w = call; hot_flush(a, slot, h); \
+	Hot h; hot_preload(a, slot, h, true); const int w = call; hot_flush(a, slot, h); \
 	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
 PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot]))
 PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))
@@ -1008,7 +1040,7 @@ PROBE(probe_dl_next, st_dl_next(a, slot, h, c.level))
 PROBE(probe_dl_eval, st_dl_eval(a, slot, h, c, slot * 3u, slot * 5u, m))
 PROBE(probe_dl_done, st_dl_done(a, slot, h, c))
 PROBE(probe_extend, st_extend(a, slot, h, c))
-PROBE(probe_start_path, st_start_path(a, slot, h, c, slot * 3u, slot * 5u))
+PROBE(probe_start_path, st_start_path(a, slot, h, c, slot * 3u, slot * 5u, slot * 7u))
 #undef PROBE
 #endif
 

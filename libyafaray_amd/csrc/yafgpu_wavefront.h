@@ -363,10 +363,12 @@ YG_DEV void hot_preload(const WfArgs &a, uint32_t slot, Hot &h, bool with_path)
 		h.valid |= kHotAccBits;
 	}
 }
-YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h)
+// to_closest: the path parks for a closest-hit query — the light estimate's records (14..18) are dead then, st_after_closest starts them afresh
+YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h, bool to_closest)
 {
 	if(h.dirty & 0x01u) REC(11) = h.r11;
 	if(h.dirty & 0x02u) REC(12) = h.r12;
+	if(to_closest && YAFGPU_ACC_ZERO_FLAG) return;
 	if(h.dirty & 0x08u)
 	{
 		float4 r14 = h.r14;
@@ -762,7 +764,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	V3 p_dir = mk(0.f, 0.f, 0.f);
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
 	REC(6).w = w;
-	REC(10) = f4(wo0, 0.f);                          // pwo = wo
+	if(bs.sampled == kNone || !YAFGPU_ACC_ZERO_FLAG) REC(10) = f4(wo0, 0.f);      // pwo = wo: only a segment that sampled nothing keeps it (:224, st_after_closest)
 	if(c.path_i == 0)
 	{	// the level's first path sample: path colour 0 and the roulette stream of the per-sample mode start here
 		Mwc rr; rr.init(fnv32a(ordinal) + 123u);
@@ -1011,7 +1013,7 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 #else
 	if(where == W_RETURN) where = st_return(a, slot, c, alpha);
 #endif
-	if(where != W_FINISH) hot_flush(a, slot, h);      // a path that ends needs none of them again
+	if(where != W_FINISH) hot_flush(a, slot, h, where == W_PARK_CLOSEST);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
 	// W_FINISH
@@ -1032,7 +1034,7 @@ __global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArg
 }
 #define PROBE(name, call) __global__ __launch_bounds__(kBlock, PROBE_WAVES) void name(const WfArgs a, int *out) { \
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
-	Hot h; hot_preload(a, slot, h, true); const int w = call; hot_flush(a, slot, h); \
+	Hot h; hot_preload(a, slot, h, true); const int w = call; hot_flush(a, slot, h, false); \
 	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
 PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot]))
 PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))

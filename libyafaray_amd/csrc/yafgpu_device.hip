@@ -1584,11 +1584,11 @@ static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
 
 // Serial-state replay (WfArgs::replay): wanted when the reference's serial state is consumed at all — a roulette test
 // can happen (some depth in [1, bounces) lies above russian_roulette_min_bounces) or estimateOneDirectLight has a choice
-// (more than one light).  Not with recursiveRaytrace frames (a sample's events are then a tree, not a list: the
-// per-sample streams stand in).  The light counter of a SHARDED frame needs every rank's calls per tile (a tile
+// (more than one light).  With recursiveRaytrace a sample's events are a tree of integrate() calls, kept per call in the depth-first
+// order the reference walks it (up to 255 calls per sample; beyond that the per-sample streams stand in).  The light counter of a SHARDED frame needs every rank's calls per tile (a tile
 // starts with the sum over all tiles before it): with an exchange function attached the ranks share them (lc_sharded),
 // without one the per-sample ordinals stand in for the counter.
-struct ReplayPlan { int frames; bool need_rr, need_lc, replay, replay_lights, lc_sharded; };
+struct ReplayPlan { int frames; bool need_rr, need_lc, replay, replay_lights, lc_sharded; int ev_m; };
 static ReplayPlan replay_plan(const yafgpu_scene *s, const yafgpu_render_params &rp)
 {
 	ReplayPlan p{};
@@ -1596,7 +1596,15 @@ static ReplayPlan replay_plan(const yafgpu_scene *s, const yafgpu_render_params 
 	const bool path = rp.integrator == YAFGPU_INTEGRATOR_PATH;
 	p.need_rr = path && rp.bounces - 1 > rp.rr_min_bounces;
 	p.need_lc = path && s->n_lights > 1;
-	p.replay = rp.serial_replay != 0 && p.frames == 0 && (p.need_rr || p.need_lc);
+	// integrate() calls one camera sample can make (WfArgs::ev_m): without glossy-recursive materials every call sends at most a
+	// reflected and a transmitted ray, frames levels deep; with them a call whose trajectory splitting is still 1 also sends 8 glossy
+	// trajectories, whose calls (division >= 8: one trajectory each) send at most 3.  The ordinal has 8 bits.
+	{
+		long long t = 1, g = 1;
+		for(int k = 0; k < p.frames; ++k) { const long long t2 = s->has_glossy ? 1 + 8 * g + 2 * t : 1 + 2 * t; g = 1 + 3 * g; t = std::min<long long>(t2, 1 << 20); }
+		p.ev_m = (int)t;
+	}
+	p.replay = rp.serial_replay != 0 && p.ev_m <= 255 && (p.need_rr || p.need_lc);
 	if(const char *e = std::getenv("YAFGPU_SERIAL_REPLAY")) if(std::atoi(e) == 0) p.replay = false;
 	p.lc_sharded = p.replay && p.need_lc && rp.shard_count > 1 && s->exchange != nullptr;
 	p.replay_lights = p.replay && p.need_lc && (rp.shard_count == 1 || p.lc_sharded);
@@ -1678,6 +1686,12 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	const bool path = rp.integrator == YAFGPU_INTEGRATOR_PATH;
 	const bool need_rr = plan.need_rr, replay = plan.replay, replay_lights = plan.replay_lights, lc_sharded = plan.lc_sharded;
 	const uint32_t n_ps = (uint32_t)std::max(rp.path_samples, 1), n_prob = (uint32_t)std::max(rp.bounces - 1, 1);
+	const uint32_t ev_m = replay ? (uint32_t)plan.ev_m : 1u;
+	if(replay && ev_m > 1)
+	{	// the event tables grow with the calls a sample can make: keep a chunk's tables within 12 GB
+		const uint64_t per_slot = (uint64_t)ev_m * n_ps * (4 + 4 * n_prob + 2) + 4;
+		max_paths = (uint32_t)std::min<uint64_t>(max_paths, std::max<uint64_t>((12ull << 30) / per_slot, 4096));
+	}
 	// chunks: runs of pixels whose paths are in flight together.  With the replay a chunk is a run of whole tiles (a tile's
 	// stream is walked in one go); without it any run of at most max_paths / spp pixels.
 	struct Chunk { uint32_t pixel_begin, n_pixels, tile_begin, tile_end; };
@@ -1722,7 +1736,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	}
 	if(replay)
 	{	// event tables of the record pass, per path sample; segment tables per tile
-		const size_t ents = (size_t)s->wf_cap * n_ps;
+		const size_t ents = (size_t)s->wf_cap * ev_m * n_ps;
 		if(ents > s->rp_ents || n_prob > s->rp_prob)
 		{
 			HIP_OK(hipStreamSynchronize(stream));
@@ -1859,7 +1873,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		a.pix_prefix = s->d_pix_prefix; a.pix_xy = s->wf_pix_xy; a.pix_listed = masked ? 1 : 0;
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		a.ev_flags = s->rp_flags; a.ev_p = s->rp_p; a.ev_kill = s->rp_kill; a.ev_calls = s->rp_calls; a.lc_base = s->rp_base;
-		a.replay_lights = replay_lights ? 1 : 0;
+		a.replay_lights = replay_lights ? 1 : 0; a.ev_m = (int)ev_m;
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
@@ -1937,13 +1951,13 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				a.replay = 1;
 				yafgpu_counters *const keep = a.ra.counters;
 				a.ra.counters = nullptr;
-				HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * n_ps * sizeof(uint32_t), stream));
+				HIP_OK(hipMemsetAsync(s->rp_flags, 0, (size_t)a.n_paths * ev_m * n_ps * sizeof(uint32_t), stream));
 				if((rc = run(iters_record, true))) return rc;
 				a.ra.counters = keep;
 			}
 			const uint32_t n_seg = ch.tile_end - ch.tile_begin;
 			ReplayArgs r{};
-			r.seg_begin = s->rp_seg_begin + seg_off; r.seg_seed = s->rp_seg_seed + seg_off; r.n_seg = n_seg; r.spp = spp; r.n_paths = n_ps; r.n_prob = n_prob;
+			r.seg_begin = s->rp_seg_begin + seg_off; r.seg_seed = s->rp_seg_seed + seg_off; r.n_seg = n_seg; r.spp = spp; r.n_paths = ev_m * n_ps; r.n_prob = n_prob;
 			r.bounces = (uint32_t)std::max(rp.bounces, 1);
 			r.ev_flags = s->rp_flags; r.ev_p = s->rp_p; r.ev_kill = s->rp_kill; r.ev_calls = s->rp_calls; r.lc_base = s->rp_base;
 			r.seg_total = s->rp_seg_total + seg_off; r.lc_counter = s->rp_counter;

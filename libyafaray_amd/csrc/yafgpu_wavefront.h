@@ -49,7 +49,12 @@ struct WfArgs
 	// and leaves the depth each path is killed at and the counter value each sample starts with; replay 2 = FINAL pass:
 	// the program proper, taking both from those tables.  replay 0: per-sample streams (no serial state).
 	int replay, replay_lights;        // replay_lights: the counter is replayed too (one GPU; else the per-sample ordinal)
-	uint32_t *ev_flags;               // [path * P + path_sample]: bit d = light call at depth d, bit 16 + d = roulette test at depth d
+	// With recursiveRaytrace a camera sample is a TREE of integrate() calls, which the reference (and the frames of this path program)
+	// walks depth first: a sample's events are kept per call, in that order.  ev_m = entries of calls per camera sample (1 without
+	// recursion; else the most a sample can make); the call's ordinal rides in the top byte of record 19's z (the sample's light
+	// calls so far in the low 24 bits), counted up by st_after_closest whenever a level below the camera's starts.
+	int ev_m;
+	uint32_t *ev_flags;               // [(path * ev_m + call) * P + path_sample]: bit d = light call at depth d, bit 16 + d = roulette test at depth d
 	float *ev_p;                      // [(path * P + path_sample) * (bounces - 1) + d - 1]: probability of the test at depth d
 	uint8_t *ev_kill;                 // [path * P + path_sample]: depth of the test that kills it (255: none)
 	uint8_t *ev_calls;                // [path * P + path_sample]: light calls it makes (up to the kill)
@@ -179,6 +184,12 @@ YG_DEV float4 &wf_rec(const WfArgs &a, int k, uint32_t slot)
 	return *(float4 *)((char *)(a.state + (size_t)k * a.cap) + (slot << 4));
 }
 #define REC(k) wf_rec(a, (k), slot)
+// index of (camera sample, integrate() call, path sample) in the event tables of the serial-state replay; z19 = record 19's z
+YG_DEV uint32_t wf_event(const WfArgs &a, uint32_t slot, uint32_t z19, int path_i)
+{
+	const uint32_t call = a.ev_m > 1 ? min(z19 >> 24, (uint32_t)a.ev_m - 1u) : 0u;
+	return (slot * (uint32_t)a.ev_m + call) * (uint32_t)max(a.ra.rp.path_samples, 1) + (uint32_t)path_i;
+}
 
 // The material at a path vertex: the record itself or, for a material with shader nodes, its resolved copy in `tmp`
 // (yafgpu_texture.h mat_resolve).  wf_mat_hit: triangle and barycentrics at hand; wf_mat_parked: from record 22 / 23.
@@ -413,7 +424,6 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int tri = (int)ubits(ans.x);
 	const bool got = tri >= 0;
-	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 	if(c.stage == kStPrimary)
 	{
 		c.col = mkc(0.f, 0.f, 0.f);
@@ -423,7 +433,8 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		if(!got)
 		{
 			if(rp.has_background && !rp.bg_transp_refract) c.col = c.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
-			REC(19) = make_float4(0.f, 0.f, 0.f, alpha);
+			// (z: the sample's call ordinal and light calls so far belong to the whole sample, see WfArgs::ev_m)
+			REC(19) = make_float4(0.f, 0.f, (a.ev_m > 1 && c.level > 0) ? REC(19).z : 0.f, alpha);
 			return W_RETURN;
 		}
 		if(c.level == 0) c.incl = 1;                                                         // integrator_path_tracer.cc:129-135
@@ -448,7 +459,9 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		}
 		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
 		// (throughput, path colour and the roulette stream of this level's path samples: st_start_path, at the first of them)
-		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(0u), alpha);
+		uint32_t z19 = 0u;
+		if(a.ev_m > 1 && c.level > 0) z19 = ubits(REC(19).z) + (1u << 24);      // the next integrate() call of this camera sample
+		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(z19), alpha);
 		hot_zero_tot(a, slot, h);
 		c.path_i = 0; c.depth = 0;
 		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
@@ -486,14 +499,14 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
 	if(want_dl && a.replay == 1)
 	{	// record pass: note the call (its depth: 0 at the first hit), skip the estimate — it does not steer the path
-		const uint32_t e = slot * (uint32_t)max(rp.path_samples, 1) + (uint32_t)c.path_i;
+		const uint32_t e = wf_event(a, slot, ubits(misc.z), c.path_i);
 		a.ev_flags[e] |= 1u << (c.stage == kStFirst ? 0 : c.depth);
 		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
 		return W_DL_DONE;
 	}
 	if(want_dl)
 	{	// estimateOneDirectLight, integrator_montecarlo.cc:62-76
-		const uint32_t calls = ubits(misc.z);
+		const uint32_t calls = ubits(misc.z) & 0xffffffu;
 		int lnum = 0;
 		if(sc.n_lights > 1)
 		{
@@ -504,7 +517,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 			h2.set_start(rp.base_sampling_offset + counter - 1u);
 			lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
 		}
-		if(sc.n_lights > 1) { misc.z = fbits(calls + 1u); REC(19) = misc; }      // (only the choice among several lights reads it)
+		if(sc.n_lights > 1) { misc.z = fbits(ubits(misc.z) + 1u); REC(19) = misc; }      // (only the choice among several lights reads it)
 		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(lnum, lnum + 1, 0, 0))));
 		hot_zero_acc(a, slot, h);
 		c.dl_on_sp0 = 0;
@@ -674,7 +687,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 		const float probability = smax(throughput.r, smax(throughput.g, throughput.b));
 		if(a.replay != 0)
 		{
-			const uint32_t e = slot * (uint32_t)max(rp.path_samples, 1) + (uint32_t)c.path_i;
+			const uint32_t e = wf_event(a, slot, a.ev_m > 1 ? ubits(REC(19).z) : 0u, c.path_i);
 			if(a.replay == 1)
 			{	// record: the test and its probability; the draw is the tile stream's, made by wf_replay_scan in sample order
 				a.ev_p[(size_t)e * (size_t)max(rp.bounces - 1, 1) + (size_t)(c.depth - 1)] = probability;
@@ -935,7 +948,7 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 			REC(3) = f4(v3(f2), f9.w); REC(4) = f4(v3(f6), 0.f); REC(5) = FREC(P, 7); REC(6) = FREC(P, 8);
 			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) REC(22) = FREC(P, 11);
 			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.has_bump) REC(24) = FREC(P, 12);
-			REC(19) = make_float4(0.f, 0.f, 0.f, f0.w);
+			REC(19) = make_float4(0.f, 0.f, a.ev_m > 1 ? REC(19).z : 0.f, f0.w);
 			return W_RECURSE_SPEC;
 		}
 		if(flags & ((flags & 2u) ? 8u : 4u))

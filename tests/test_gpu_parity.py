@@ -375,6 +375,11 @@ def _render_with_rand_state(sc, rd, replay=True, same_tree=False):
     dict(n_lights=2, bounces=4, rr=4, path_samples=1, aa=dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02)),   # ... the counter alone
     dict(n_lights=2, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=2, AA_inc_samples=2, AA_threshold=0.0)),    # every pixel again
     dict(n_lights=2, bounces=4, rr=1, path_samples=1, aa=dict(AA_passes=2, AA_inc_samples=2, AA_threshold=10.0)),   # no pixel again: pass 0 in the multi-pass mode
+    # with recursiveRaytrace a camera sample is a tree of integrate() calls: its events are kept per call, in the reference's depth-first order
+    dict(n_lights=2, bounces=3, rr=0, path_samples=1, raydepth=2, spec=True),
+    dict(n_lights=1, bounces=4, rr=1, path_samples=2, raydepth=3, spec=True),
+    dict(n_lights=2, bounces=3, rr=1, path_samples=2, raydepth=2, spec=True, glossy=0.3, glossy_rec=True),      # the glossy branch: 8 trajectories, split path samples
+    dict(n_lights=2, bounces=3, rr=0, path_samples=1, raydepth=2, spec=True, aa=dict(AA_passes=3, AA_inc_samples=2, AA_threshold=0.02)),
 ])
 def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, monkeypatch):
     """Russian roulette ON (the reference's default, integrator_path_tracer.cc:355) and / or more than one light: the
@@ -385,8 +390,14 @@ def test_serial_state_replay_matches_the_single_threaded_oracle(case, pipeline, 
     if pipeline == "megakernel":
         pytest.skip("the replay belongs to the wavefront pipeline")
     sc = scenes.cornell_soup(1500, seed=41 + case["bounces"], res=(72, 56), n_lights=case["n_lights"], glossy_fraction=case.get("glossy", 0.0))
+    if case.get("spec"):
+        m = sc["materials"]
+        m[1] = {"type": "shinydiffusemat", "color": (0.8, 0.3, 0.3), "diffuse_reflect": 0.6, "specular_reflect": 0.35, "transparency": 0.25, "transmit_filter": 0.8}
+        m[2] = {"type": "glass", "IOR": 1.45, "filter_color": (0.8, 1.0, 0.8), "transmit_filter": 0.6, "mirror_color": (1.0, 1.0, 1.0)}
+        if case.get("glossy_rec"):
+            m[4] = dict(m[4], as_diffuse=False)
     rd = scenes.render_settings(72, 56, 6, bounces=case["bounces"], path_samples=case["path_samples"], tile_size=16,
-                                russian_roulette_min_bounces=case["rr"], **case.get("aa", {}))
+                                russian_roulette_min_bounces=case["rr"], **({"raydepth": case["raydepth"]} if "raydepth" in case else {}), **case.get("aa", {}))
     multi = "aa" in case
     film, st, ofilm, ost = _render_with_rand_state(sc, rd, same_tree=multi)
     wdiff = int((film[..., 4] != ofilm[..., 4]).sum())
@@ -968,7 +979,9 @@ def _push_to_extremes(m, rng):
     return m
 
 
-def _feature_mix(seed, textures=True):
+def _feature_mix(seed, textures=True, serial=False):
+    """serial: the same mix made to consume the reference's serial state — path tracing with Russian roulette from a random depth on and,
+    mostly, a second light (the light counter) — for the exact replay (test_random_feature_mixes_with_serial_state)"""
     rng = np.random.default_rng(1000 + seed)
     w, h = int(rng.integers(36, 60)), int(rng.integers(28, 48))
     # bounce vertices of the path tracer pick ONE light through a counter that is serial state in the reference
@@ -1060,6 +1073,17 @@ def _feature_mix(seed, textures=True):
         cw, ch = int(rng.integers(8, w - 4)), int(rng.integers(8, h - 4))
         kw.update(xstart=int(rng.integers(0, w - cw)), ystart=int(rng.integers(0, h - ch)))
         w, h = cw, ch
+    if serial:
+        rs = np.random.default_rng(5000 + seed)
+        kw["integrator"] = "pathtracing"
+        kw["bounces"] = max(kw["bounces"], 2)
+        kw["russian_roulette_min_bounces"] = int(rs.integers(0, kw["bounces"]))
+        kw["raydepth"] = min(kw["raydepth"], 3)          # (up to 255 integrate() calls per camera sample are replayed: DESIGN.md, serial state)
+        for m in sc["materials"]:
+            m.pop("additionaldepth", None)
+        if rs.random() < 0.7:
+            sc["lights"] = list(sc["lights"]) + [{"type": "pointlight", "from": tuple(float(x) for x in rs.uniform(-0.6, 0.6, 3)),
+                                                 "color": (1.0, 0.9, 0.8), "power": float(rs.uniform(0.5, 3.0))}]
     if textures and rng.random() < 0.4:
         _texturize(sc, rng)
     rd = scenes.render_settings(w, h, spp, **kw)
@@ -1230,6 +1254,35 @@ def test_random_feature_mixes(seed, pipeline, monkeypatch):
     yi.render()
     film, st = yi.getFilm(w, h), yi.getRenderStats()
     assert_matches_an_oracle_render(sc, rd, film, st, f"feature mix {seed}: {[m['type'] for m in sc['materials'][base:]]} {kw}")
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("YAFGPU_SERIAL_FUZZ_FIRST", "0")), int(__import__("os").environ.get("YAFGPU_SERIAL_FUZZ_SEEDS", "12")))))
+def test_random_feature_mixes_with_serial_state(seed, pipeline):
+    """The random mixes again, consuming the reference's serial state (roulette stream, light counter) — with mirrors, glass and
+    glossy-recursive materials a camera sample is a tree of integrate() calls whose events are replayed in the reference's depth-first
+    order: the device must equal the SINGLE-THREADED oracle started from the same libc rand() state."""
+    if pipeline == "megakernel":
+        pytest.skip("the replay belongs to the wavefront pipeline")
+    sc, rd, w, h, base, kw = _feature_mix(seed, serial=True)
+    what = f"serial feature mix {seed}: {[m['type'] for m in sc['materials'][base:]]} {kw}"
+    firsts = []
+    for same_tree in (True, False):      # (exact-distance ties resolve by tree topology: see assert_matches_an_oracle_render)
+        film, st, ofilm, ost = _render_with_rand_state(sc, rd, same_tree=same_tree)
+        if (st.camera_samples, st.rays_closest, st.rays_shadow) == (ost.camera_samples, ost.rays_closest, ost.rays_shadow):
+            wide = rd.get("filter_type", "box") != "box" or rd.get("AA_pixelwidth", 1.0) > 1.002      # (splats from several tiles: the plane sums round in another order)
+            compare_films(film, ofilm, what, exact_weights=not wide)
+            return
+        # where, in the reference's tile order, the two renders part
+        ys, xs = np.nonzero(~np.isclose(film, ofilm, rtol=1e-4, atol=1e-6).all(axis=-1))
+        ts = rd.get("tile_size", 32)
+        order = np.lexsort((xs, ys, xs // ts, ys // ts))
+        firsts.append((int(xs[order[0]]), int(ys[order[0]])) if len(order) else None)
+    # With serial state ONE sample that resolves an exact-distance tie the other way (a camera ray into the edge two walls share)
+    # shifts the light counter of every sample after it.  Each tree has its own such pixels; a scene that has them in both trees
+    # cannot be checked this way — told apart from a device error by where the renders part: at another pixel per tree.
+    if firsts[0] is not None and firsts[1] is not None and firsts[0] != firsts[1]:
+        pytest.skip(f"{what}: tie artefacts with both trees (the renders part at {firsts[0]} / {firsts[1]})")
+    raise AssertionError(f"{what}: differs from the single-threaded oracle with either tree, from the same pixel on: {firsts}")
 
 
 @pytest.mark.parametrize("seed", [3, 14, 25, 36, 47, 58, 69, 80])

@@ -286,8 +286,7 @@ def test_bump_mapped_glossy_and_glass_match_oracle():
 
 def _textured_box(seed=5, n_tris=400, specular=True):
     """the Cornell soup with UVs and orcos on every triangle and a set of materials that drives every shader slot.
-    specular=False: without the mirror / transparency lobes (and their shaders), i.e. without recursiveRaytrace — the regime in
-    which the device replays the reference's serial state (Russian-roulette stream), DESIGN.md row N4"""
+    specular=False: without the mirror / transparency lobes (and their shaders), i.e. without recursiveRaytrace"""
     rng = np.random.default_rng(seed)
     sc = scenes.cornell_soup(n_tris, seed=seed, sigma=0.12, res=(48, 40))
     n = sc["verts"].shape[0]
@@ -336,7 +335,8 @@ def _textured_box(seed=5, n_tris=400, specular=True):
 
 
 @pytest.mark.parametrize("integrator,kw", [("directlighting", dict(transpShad=True, shadowDepth=3)), ("pathtracing", dict(bounces=3, transpShad=True, shadowDepth=2)),
-                                           ("pathtracing", dict(bounces=4, russian_roulette_min_bounces=1, specular=False))])
+                                           ("pathtracing", dict(bounces=4, russian_roulette_min_bounces=1, specular=False)),
+                                           ("pathtracing", dict(bounces=3, russian_roulette_min_bounces=1, raydepth=2))])      # roulette through recursiveRaytrace's call tree
 def test_textured_render_matches_oracle(integrator, kw):
     """every shader slot of shinydiffusemat driven by node graphs over three image textures, UV / orco / global / transformed /
     window / normal coordinates, plain / cube / tube / sphere mappings: device film against the oracle's on the same scene"""

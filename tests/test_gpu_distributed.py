@@ -34,7 +34,7 @@ def _scene(case):
         # stream decides which paths make further estimates); "lights_aa" carries the counter over adaptive passes as well
         sc = scenes.cornell_soup(900, seed=31, res=(W, H), n_lights=1 if case == "lights_rr_only" else 2)
         rr = {} if case == "lights_lc_only" else dict(russian_roulette_min_bounces=1)
-        rd = scenes.render_settings(W, H, 3, bounces=4, tile_size=T, background=(0.05, 0.1, 0.2), **rr, **(AA if case == "lights_aa" else {}))
+        rd = scenes.render_settings(W, H, 3, bounces=4, tile_size=128 if case == "lights_one_tile" else T, background=(0.05, 0.1, 0.2), **rr, **(AA if case == "lights_aa" else {}))
     return sc, rd
 
 
@@ -67,7 +67,7 @@ def _worker(rank, world, port, out_path, case):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("case", ["aa", "lights_rr_only", "lights_lc_only", "lights", "lights_aa", "lights_chunks"])
+@pytest.mark.parametrize("case", ["aa", "lights_rr_only", "lights_lc_only", "lights", "lights_aa", "lights_chunks", "lights_one_tile"])
 def test_sharded_render_with_cross_rank_state_equals_the_single_gpu_render(tmp_path, monkeypatch, case):
     monkeypatch.setenv("YAFGPU_PIPELINE", "wavefront")
     if case == "lights_chunks":      # several chunks per rank (a tile each): the count pass and the final pass record a chunk's events twice
@@ -102,6 +102,7 @@ def test_sharded_render_with_cross_rank_state_equals_the_single_gpu_render(tmp_p
     assert got["counts"].tolist() == counts
     assert np.array_equal(got["film"][..., 4], full[..., 4]), "the ranks sampled other pixels again than the single GPU"
     interior = np.ones((H, W), bool)
-    interior[::T, :] = False; interior[:, ::T] = False
+    if case != "lights_one_tile":        # (one tile: rank 1 has none — it still joins the exchange — and rank 0's film is the whole frame)
+        interior[::T, :] = False; interior[:, ::T] = False
     assert np.array_equal(got["film"][interior], full[interior])
     np.testing.assert_allclose(got["film"], full, rtol=2.5e-7, atol=1e-7)

@@ -1123,6 +1123,7 @@ struct yafgpu_scene
 	// serial-state replay tables (WfArgs::replay)
 	uint32_t *rp_flags = nullptr; float *rp_p = nullptr; uint8_t *rp_kill = nullptr, *rp_calls = nullptr; uint32_t *rp_base = nullptr; size_t rp_ents = 0; uint32_t rp_prob = 0;
 	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_seg_base = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
+	float4 *rp_hits = nullptr; size_t rp_hits_cap = 0;       // closest-hit answers of the record pass (WfArgs::hit_cache)
 	uint32_t lc_host_counter = 0;                        // correlative_sample_number_ of a sharded render: the same value on every rank (lc_exchange_counts)
 	std::vector<uint32_t> h_seg_base;
 	std::vector<uint32_t> h_listed;                      // pixels of a masked (adaptive) pass, in tile order
@@ -1432,7 +1433,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base, (void *)s->rp_seg_begin,
-	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter}) if(q) (void)hipFree(q);
+	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter, (void *)s->rp_hits}) if(q) (void)hipFree(q);
 	delete s;
 }
 
@@ -1734,6 +1735,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
 	}
+	uint32_t hit_k = 0; bool use_hits = false;
 	if(replay)
 	{	// event tables of the record pass, per path sample; segment tables per tile
 		const size_t ents = (size_t)s->wf_cap * ev_m * n_ps;
@@ -1748,6 +1750,20 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			HIP_OK(hipMalloc((void **)&s->rp_calls, ents));
 			HIP_OK(hipMalloc((void **)&s->rp_base, (size_t)s->wf_cap * sizeof(uint32_t)));
 			s->rp_ents = ents; s->rp_prob = n_prob;
+		}
+		// the record pass's closest-hit answers, one per (call, path sample, segment): kept when a camera sample's fit in 1 KB (the
+		// final pass then looks its closest hits up instead of tracing them again); never in a stats pass, whose per-ray traversal
+		// counts are the point
+		hit_k = ev_m * n_ps * ((uint32_t)std::max(rp.bounces, 1) + 1u);
+		use_hits = !stats && (size_t)hit_k * sizeof(float4) <= 1024;
+		if(const char *e = std::getenv("YAFGPU_HIT_CACHE")) use_hits = use_hits && std::atoi(e) != 0;
+		if(use_hits && (size_t)s->wf_cap * hit_k > s->rp_hits_cap)
+		{
+			HIP_OK(hipStreamSynchronize(stream));
+			if(s->rp_hits) (void)hipFree(s->rp_hits);
+			s->rp_hits = nullptr; s->rp_hits_cap = 0;
+			HIP_OK(hipMalloc((void **)&s->rp_hits, (size_t)s->wf_cap * hit_k * sizeof(float4)));
+			s->rp_hits_cap = (size_t)s->wf_cap * hit_k;
 		}
 		// every chunk's tiles as segments — first pixel of each (chunk-local) and the seed of its Random:
 		// rand() + offset * (resx * tile.y + tile.x) + 123 (integrator_tiled.cc:319), offset = pass offset + base sampling
@@ -1874,6 +1890,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		a.ev_flags = s->rp_flags; a.ev_p = s->rp_p; a.ev_kill = s->rp_kill; a.ev_calls = s->rp_calls; a.lc_base = s->rp_base;
 		a.replay_lights = replay_lights ? 1 : 0; a.ev_m = (int)ev_m;
+		a.hit_cache = use_hits ? s->rp_hits : nullptr; a.hit_k = (int)hit_k;
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
 		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
@@ -1909,7 +1926,11 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 					HIP_OK(hipEventRecord(s->ev_fork, stream));
 					HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
 				}
-				if((rc = timed(0, [&] {
+				if(!record && a.replay == 2 && a.hit_cache != nullptr)
+				{	// the record pass answered these queries already
+					if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_cached_closest, dim3((uint32_t)cus * 8u), dim3(kBlock), 0, stream, a); }))) return rc;
+				}
+				else if((rc = timed(0, [&] {
 					if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);
 					else hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, stream, a); }))) return rc;
 				// The two traversal launches of an iteration are independent (each drains its own queue, writes its own

@@ -54,6 +54,10 @@ struct WfArgs
 	// recursion; else the most a sample can make); the call's ordinal rides in the top byte of record 19's z (the sample's light
 	// calls so far in the low 24 bits), counted up by st_after_closest whenever a level below the camera's starts.
 	int ev_m;
+	// The record pass has already answered every closest-hit query the final pass will ask (the same paths, cut short by the roulette
+	// kills): it keeps the answers — one per (call, path sample, segment), hit_k per camera sample — and the final pass's closest-hit
+	// launches become look-ups (wf_cached_closest).  nullptr: not kept (too many per sample, or a stats pass), the rays are traced again.
+	float4 *hit_cache; int hit_k;
 	uint32_t *ev_flags;               // [(path * ev_m + call) * P + path_sample]: bit d = light call at depth d, bit 16 + d = roulette test at depth d
 	float *ev_p;                      // [(path * P + path_sample) * (bounces - 1) + d - 1]: probability of the test at depth d
 	uint8_t *ev_kill;                 // [path * P + path_sample]: depth of the test that kills it (255: none)
@@ -418,12 +422,27 @@ YG_DEV DivState wf_div(const WfArgs &a, uint32_t slot, int level)
 }
 YG_DEV float add_mod_1(float x, float y) { const float t = x + y; return t > 1 ? t - 1.f : t; }      // util_sample.h:183-187
 
+// where the answer of the closest-hit query a path is parked on lives in the record pass's cache: from what its control word and
+// record 19 hold at the park — (call, path sample, segment); a level's own ray (segment 0) belongs to the call about to start
+YG_DEV uint32_t wf_hit_key(const WfArgs &a, uint32_t slot, uint32_t ctl, uint32_t z19)
+{
+	const int stage = (int)((ctl >> 2) & 3u), level = (int)((ctl >> 5) & 7u), depth = (int)((ctl >> 8) & 0xfu), path_i = (int)(ctl >> 17);
+	const uint32_t n_ps = (uint32_t)max(a.ra.rp.path_samples, 1), per_path = (uint32_t)max(a.ra.rp.bounces, 1) + 1u;
+	uint32_t call = a.ev_m > 1 ? (z19 >> 24) : 0u, seg = 0u, ps = 0u;
+	if(stage == kStPrimary) call = level > 0 ? call + 1u : 0u;      // (the camera ray: record 19 is not set up yet)
+	else { ps = (uint32_t)path_i; seg = stage == kStFirst ? 1u : 1u + (uint32_t)depth; }
+	call = min(call, (uint32_t)a.ev_m - 1u); seg = min(seg, per_path - 1u); ps = min(ps, n_ps - 1u);
+	return slot * (uint32_t)a.hit_k + (call * n_ps + ps) * per_path + seg;
+}
+
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
 YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal, const float4 ans)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int tri = (int)ubits(ans.x);
 	const bool got = tri >= 0;
+	if(a.replay == 1 && a.hit_cache != nullptr)      // record pass: keep the answer for the final pass (the control word is still the park's)
+		a.hit_cache[wf_hit_key(a, slot, pack_ctl(c), a.ev_m > 1 ? ubits(REC(19).z) : 0u)] = ans;
 	if(c.stage == kStPrimary)
 	{
 		c.col = mkc(0.f, 0.f, 0.f);
@@ -434,7 +453,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		{
 			if(rp.has_background && !rp.bg_transp_refract) c.col = c.col + mkc(rp.background[0], rp.background[1], rp.background[2]);
 			// (z: the sample's call ordinal and light calls so far belong to the whole sample, see WfArgs::ev_m)
-			REC(19) = make_float4(0.f, 0.f, (a.ev_m > 1 && c.level > 0) ? REC(19).z : 0.f, alpha);
+			REC(19) = make_float4(0.f, 0.f, (a.ev_m > 1 && c.level > 0) ? fbits(ubits(REC(19).z) + (1u << 24)) : 0.f, alpha);      // (a call that ends here is a call too: its ordinal is its own)
 			return W_RETURN;
 		}
 		if(c.level == 0) c.incl = 1;                                                         // integrator_path_tracer.cc:129-135
@@ -1534,6 +1553,24 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 
 // Scene::isShadowed with transparent shadows (scene.cc:996-1035) over the shadow queue: one lane per ray, no refill —
 // the feature path for scenes with transparent materials and transpShad, not the benchmark path.
+// The final pass of a serial-state replay whose record pass kept its closest-hit answers (WfArgs::hit_cache): every ray of the
+// closest-hit queue gets its answer by look-up, at its queue position like wf_trace's.
+__global__ __launch_bounds__(kBlock) void wf_cached_closest(const WfArgs a)
+{
+	const uint32_t n = a.cnt_in[0];
+	const uint32_t *q = a.q_closest_in;
+	const size_t c = a.cap;
+	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t slot = q ? q[i] : i;
+		const uint32_t ctl = ubits(a.state[13 * c + slot].w);
+		const uint32_t z19 = a.ev_m > 1 ? ubits(a.state[19 * c + slot].z) : 0u;
+		a.state[2 * c + i] = a.hit_cache[wf_hit_key(a, slot, ctl, z19)];
+	}
+	if(a.ra.counters != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && n)
+		atomicAdd((unsigned long long *)&a.ra.counters->rays_closest, (unsigned long long)n);
+}
+
 __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 {
 	__shared__ uint2 s_stack[kWavesPerBlock][kStack][kWave];

@@ -110,6 +110,8 @@ struct yafaray_interface
 	yafgpu_aa_schedule aa{};
 	std::vector<int32_t> resampled;      // pixels sampled by each pass of the last render
 	bool prepared = false;
+	bool scene_dirty = true;            // something the device scene is made of changed since it was built (Scene::update's state_.changes_, scene.cc:784-790)
+	yafgpu_camera scene_cam{}; int scene_threads = 0;
 	int shard_index = 0, shard_count = 1;
 	std::vector<float> film;
 	yafaray_render_stats_t stats{};
@@ -771,7 +773,7 @@ const char *yafaray_getVersion(void) { return "yafgpu-0.1 (MI355X path-tracing c
 yafaray_bool_t yafaray_startScene(yafaray_interface_t *yi, int type)
 {
 	if(type != 0) return fail(yi, "startScene: only scene type 0 (\"triangle\") is supported (import_xml.cc:339-347)");
-	yi->state = 0; yi->meshes.clear(); yi->cur = nullptr; yi->last = nullptr; yi->geometry_changed = true; yi->prepared = false;
+	yi->state = 0; yi->meshes.clear(); yi->cur = nullptr; yi->last = nullptr; yi->geometry_changed = true; yi->prepared = false; yi->scene_dirty = true;
 	return 1;
 }
 yafaray_bool_t yafaray_startGeometry(yafaray_interface_t *yi) { if(yi->state != 0) return fail(yi, "startGeometry: wrong state"); yi->state = 1; return 1; }
@@ -788,7 +790,7 @@ yafaray_bool_t yafaray_startTriMesh(yafaray_interface_t *yi, unsigned int id, in
 	m.visible = !(type & 0x0100); m.base = (type & 0x0200) != 0;
 	m.has_orco = has_orco != 0; m.has_uv = has_uv != 0;
 	m.points.reserve((size_t)std::max(vertices, 0) * 3); m.tri.reserve((size_t)std::max(triangles, 0) * 3); m.tri_mat.reserve((size_t)std::max(triangles, 0));
-	yi->cur = &m; yi->last = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false;
+	yi->cur = &m; yi->last = &m; yi->state = 2; yi->geometry_changed = true; yi->prepared = false; yi->scene_dirty = true;
 	return 1;
 }
 yafaray_bool_t yafaray_endTriMesh(yafaray_interface_t *yi)
@@ -925,7 +927,7 @@ yafaray_bool_t yafaray_smoothMesh(yafaray_interface_t *yi, unsigned int id, doub
 	Mesh &m = *mp;
 	const float angle = (float)angle_d;
 	const size_t nv = m.points.size() / 3, nt = m.tri.size() / 3;
-	yi->geometry_changed = true; yi->prepared = false;
+	yi->geometry_changed = true; yi->prepared = false; yi->scene_dirty = true;
 	if(m.normals_exported && m.normals.size() == m.points.size()) { m.smooth = true; return 1; }      // :402-406
 	m.smooth_normals.assign(nt * 9, 0.f);
 	// face normals: Triangle::recNormal, triangle.h:295-302
@@ -1106,7 +1108,7 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	yafaray_material *raw = m.get();
 	yi->material_order.push_back(raw);
 	yi->materials[name] = std::move(m);
-	yi->prepared = false;
+	yi->prepared = false; yi->scene_dirty = true;
 	return raw;
 }
 // ImageTexture::factory's parameters other than the image itself (texture_image.cc:559-563, :657-716)
@@ -1156,7 +1158,7 @@ static yafaray_texture_t *register_texture(yafaray_interface *yi, const char *na
 	yafaray_texture *raw = t.get();
 	yi->texture_order.push_back(raw);
 	yi->textures[name] = std::move(t);
-	yi->prepared = false;
+	yi->prepared = false; yi->scene_dirty = true;
 	return raw;
 }
 
@@ -1234,7 +1236,7 @@ yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name)
 	yafaray_light *raw = l.get();
 	if(enabled) yi->light_order.push_back(raw);   // Scene::addLight only sees enabled lights (environment.cc:230-233)
 	yi->lights[name] = std::move(l);
-	yi->prepared = false;
+	yi->prepared = false; yi->scene_dirty = true;
 	return raw;
 }
 yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name)
@@ -1247,7 +1249,7 @@ yafaray_camera_t *yafaray_createCamera(yafaray_interface_t *yi, const char *name
 	if(!make_camera(yi, yi->params, c->c.cam)) return nullptr;
 	yafaray_camera *raw = c.get();
 	yi->cameras[name] = std::move(c);
-	yi->prepared = false;
+	yi->prepared = false; yi->scene_dirty = true;
 	return raw;
 }
 yafaray_background_t *yafaray_createBackground(yafaray_interface_t *yi, const char *name)
@@ -1304,7 +1306,7 @@ yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const ch
 	}
 	yafaray_integrator *raw = it.get();
 	yi->integrators[name] = std::move(it);
-	yi->prepared = false;
+	yi->prepared = false; yi->scene_dirty = true;
 	return raw;
 }
 
@@ -1314,7 +1316,7 @@ void yafaray_clearAll(yafaray_interface_t *yi)
 	yi->materials.clear(); yi->material_order.clear(); yi->textures.clear(); yi->texture_order.clear(); yi->lights.clear(); yi->light_order.clear();
 	yi->cameras.clear(); yi->backgrounds.clear(); yi->integrators.clear(); yi->meshes.clear();
 	yi->params.dicc.clear(); yi->eparams.clear(); yi->cparams = &yi->params;
-	yi->state = -1; yi->prepared = false; yi->geometry_changed = true; yi->film.clear();
+	yi->state = -1; yi->prepared = false; yi->scene_dirty = true; yi->geometry_changed = true; yi->film.clear();
 }
 
 void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip)
@@ -1421,6 +1423,13 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 
 	// Scene::update: flatten visible non-base meshes in object-id order (scene.cc:797-817)
 	if(yi->state != 0) return fail(yi, "render: scene is not in the ready state (missing endGeometry?)");
+	int threads = -1; p.get("threads", threads);
+	if(yi->gpu && !yi->scene_dirty && std::memcmp(&yi->scene_cam, &cam->second->c.cam, sizeof yi->scene_cam) == 0 && yi->scene_threads == threads)
+	{	// nothing the device scene is made of changed: keep it, tree and all (Scene::update rebuilds only on changes, scene.cc:784-790)
+		yafgpu_scene_set_exchange(yi->gpu, yi->exchange, yi->exchange_user);
+		yi->prepared = true;
+		return 1;
+	}
 	if(yi->gpu) { yafgpu_scene_destroy(yi->gpu); yi->gpu = nullptr; }
 	std::vector<float> verts; std::vector<int32_t> tri_mat; std::vector<float> vnormals; bool any_normals = false;
 	for(auto &kv : yi->meshes) if(kv.second.normals_exported || (kv.second.smooth && !kv.second.smooth_normals.empty())) any_normals = true;
@@ -1500,8 +1509,9 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	}
 	d.camera = cam->second->c.cam;
 	d.build_threads = 0;
-	int threads = -1; p.get("threads", threads); if(threads > 0) d.build_threads = threads;
+	if(threads > 0) d.build_threads = threads;
 	if(yafgpu_scene_create(&d, &yi->gpu)) return fail(yi, std::string("scene upload: ") + yafgpu_last_error());
+	yi->scene_dirty = false; yi->scene_cam = cam->second->c.cam; yi->scene_threads = threads;
 	yafgpu_scene_set_abort_flag(yi->gpu, &yi->abort_flag);
 	yafgpu_scene_set_exchange(yi->gpu, yi->exchange, yi->exchange_user);
 	yafgpu_tree_info ti{};

@@ -1123,6 +1123,9 @@ struct yafgpu_scene
 	// serial-state replay tables (WfArgs::replay)
 	uint32_t *rp_flags = nullptr; float *rp_p = nullptr; uint8_t *rp_kill = nullptr, *rp_calls = nullptr; uint32_t *rp_base = nullptr; size_t rp_ents = 0; uint32_t rp_prob = 0;
 	uint32_t *rp_seg_begin = nullptr, *rp_seg_seed = nullptr, *rp_seg_total = nullptr, *rp_seg_base = nullptr, *rp_counter = nullptr; size_t rp_segs = 0;
+	// render targets of the host-film entry points, kept between calls (allocating and freeing 100 MB per render cost up to half a
+	// second a call on this runtime — ten times the pass itself at 1024x1024)
+	float *rt_planes = nullptr, *rt_film = nullptr; yafgpu_counters *rt_cnt = nullptr; size_t rt_planes_n = 0, rt_film_n = 0;
 	float4 *rp_hits = nullptr; size_t rp_hits_cap = 0;       // closest-hit answers of the record pass (WfArgs::hit_cache)
 	uint32_t lc_host_counter = 0;                        // correlative_sample_number_ of a sharded render: the same value on every rank (lc_exchange_counts)
 	std::vector<uint32_t> h_seg_base;
@@ -1433,7 +1436,8 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base, (void *)s->rp_seg_begin,
-	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter, (void *)s->rp_hits}) if(q) (void)hipFree(q);
+	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter, (void *)s->rp_hits,
+	               (void *)s->rt_planes, (void *)s->rt_film, (void *)s->rt_cnt}) if(q) (void)hipFree(q);
 	delete s;
 }
 
@@ -2165,17 +2169,35 @@ int yafgpu_film_combine(const float *d_planes, float *d_film, int32_t width, int
 	return 0;
 }
 
+// planes, combined film and counters of a w x h frame, owned by the scene and reused while the size stays
+static int render_targets(yafgpu_scene *s, int w, int h, float **planes, float **film, yafgpu_counters **cnt)
+{
+	const size_t planes_n = yafgpu_planes_bytes(w, h) / sizeof(float), film_n = (size_t)w * (size_t)h * YAFGPU_FILM_CHANNELS;
+	if(planes_n > s->rt_planes_n || film_n > s->rt_film_n)
+	{
+		HIP_OK(hipDeviceSynchronize());
+		if(s->rt_planes) (void)hipFree(s->rt_planes);
+		if(s->rt_film) (void)hipFree(s->rt_film);
+		s->rt_planes = nullptr; s->rt_film = nullptr; s->rt_planes_n = 0; s->rt_film_n = 0;
+		HIP_OK(hipMalloc((void **)&s->rt_planes, planes_n * sizeof(float)));
+		HIP_OK(hipMalloc((void **)&s->rt_film, film_n * sizeof(float)));
+		s->rt_planes_n = planes_n; s->rt_film_n = film_n;
+	}
+	if(!s->rt_cnt) HIP_OK(hipMalloc((void **)&s->rt_cnt, sizeof(yafgpu_counters)));
+	*planes = s->rt_planes; *film = s->rt_film; *cnt = s->rt_cnt;
+	return 0;
+}
+
 int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, float *h_film, yafgpu_counters *h_counters)
 {
 	if(!s || !rp || !h_film) return fail(-1, "null argument");
 	if(rp->width <= 0 || rp->height <= 0) return fail(-10, "empty image");
-	DevMem<float> d_planes, d_film; DevMem<yafgpu_counters> d_cnt;
+	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
 	const size_t film_bytes = (size_t)rp->width * (size_t)rp->height * YAFGPU_FILM_CHANNELS * sizeof(float);
-	HIP_OK(d_planes.alloc(yafgpu_planes_bytes(rp->width, rp->height) / sizeof(float)));
-	HIP_OK(d_film.alloc(film_bytes / sizeof(float)));
-	HIP_OK(d_cnt.alloc(1));
+	int rc = render_targets(s, rp->width, rp->height, &d_planes, &d_film, &d_cnt);
+	if(rc) return rc;
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
-	int rc = yafgpu_render_tiles(s, rp, d_planes, d_cnt, nullptr);
+	rc = yafgpu_render_tiles(s, rp, d_planes, d_cnt, nullptr);
 	if(!rc) rc = yafgpu_film_combine(d_planes, d_film, rp->width, rp->height, nullptr);
 	if(!rc)
 	{
@@ -2291,11 +2313,9 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	yafgpu_render_params rp = *rp_in;
 	const int w = rp.width, h = rp.height;
 	if(w <= 0 || h <= 0) return fail(-10, "empty image");
-	DevMem<float> d_planes, d_film; DevMem<yafgpu_counters> d_cnt;
+	float *d_planes = nullptr, *d_film = nullptr; yafgpu_counters *d_cnt = nullptr;
 	const size_t film_bytes = (size_t)w * (size_t)h * YAFGPU_FILM_CHANNELS * sizeof(float);
-	HIP_OK(d_planes.alloc(yafgpu_planes_bytes(w, h) / sizeof(float)));
-	HIP_OK(d_film.alloc(film_bytes / sizeof(float)));
-	HIP_OK(d_cnt.alloc(1));
+	{ const int rc_t = render_targets(s, w, h, &d_planes, &d_film, &d_cnt); if(rc_t) return rc_t; }
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
 	auto film_now = [&]() -> int {
 		int rc = yafgpu_film_combine(d_planes, d_film, w, h, nullptr);

@@ -198,7 +198,13 @@ def load_scene(yi, scene, render):
     if scene.get("smooth_angle") is not None:
         yi.smoothMesh(0, float(scene["smooth_angle"]))      # Interface::smoothMesh on the mesh just closed
     yi.endGeometry()
+    set_render_params(yi, render)
+    return handles
 
+
+def set_render_params(yi, render):
+    """the parameter map Interface::render reads (load_scene's last step; again after anything that cleared the map)"""
+    bg = render.get("background")
     yi.paramsClearAll()
     rs = {"camera_name": "cam", "integrator_name": "default", "volintegrator_name": "volintegr"}
     if bg is not None:
@@ -215,4 +221,3 @@ def load_scene(yi, scene, render):
         if k in render:
             rs[k] = float(render[k])
     yi.paramsSet(rs)
-    return handles

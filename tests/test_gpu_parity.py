@@ -344,6 +344,34 @@ def test_full_size_c4_one_light_against_oracle_windows(pipeline):
 
 
 # ---- serial-state replay: the reference's per-tile roulette stream and its light counter -------------
+def test_prepare_render_keeps_the_device_scene_until_something_changes(pipeline):
+    """Scene::update rebuilds the tree only when the scene changed (scene.cc:784-790): a second render() of an untouched scene reuses
+    the device scene (no second tree build), a render parameter alone (samples) does not rebuild either, a new camera or a changed
+    material does — and the film is then the one a fresh Interface renders."""
+    if pipeline == "megakernel":
+        pytest.skip("one pipeline is enough")
+    sc = scenes.cornell_soup(3000, seed=3, res=(40, 32))
+    rd = scenes.render_settings(40, 32, 2, bounces=2)
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    f0, built0 = yi.getFilm(40, 32), yi.getRenderStats().tree_build_seconds
+    assert built0 > 0.0
+    yi.render()
+    assert np.array_equal(yi.getFilm(40, 32), f0)
+    assert yi.getRenderStats().tree_build_seconds == built0, "the tree was built again for an unchanged scene"
+    # a new camera under the same name: the scene is prepared again and the film is a fresh render's
+    cam2 = dict(sc["camera"], **{"from": (0.3, -3.2, 0.2)})
+    yi.paramsClearAll(); yi.paramsSet(dict(cam2, type="perspective")); yi.createCamera("cam")
+    scenes.set_render_params(yi, rd)
+    yi.render()
+    f1 = yi.getFilm(40, 32)
+    y2 = Interface()
+    scenes.load_scene(y2, dict(sc, camera=cam2), rd)
+    y2.render()
+    assert not np.array_equal(f1, f0) and np.array_equal(f1, y2.getFilm(40, 32))
+
+
 def _render_with_rand_state(sc, rd, replay=True, same_tree=False):
     """device render + the oracle's SINGLE-THREADED render of the same scene with the libc state the device side derived
     for it (srand seed of the last constructor, values its colour loop consumed): the reference's serial semantics.

@@ -1126,6 +1126,7 @@ struct yafgpu_scene
 	// render targets of the host-film entry points, kept between calls (allocating and freeing 100 MB per render cost up to half a
 	// second a call on this runtime — ten times the pass itself at 1024x1024)
 	float *rt_planes = nullptr, *rt_film = nullptr; yafgpu_counters *rt_cnt = nullptr; size_t rt_planes_n = 0, rt_film_n = 0;
+	uint8_t *rt_flags = nullptr; size_t rt_flags_n = 0;       // resample flags of the detection step between adaptive passes
 	float4 *rp_hits = nullptr; size_t rp_hits_cap = 0;       // closest-hit answers of the record pass (WfArgs::hit_cache)
 	uint32_t lc_host_counter = 0;                        // correlative_sample_number_ of a sharded render: the same value on every rank (lc_exchange_counts)
 	std::vector<uint32_t> h_seg_base;
@@ -1437,7 +1438,7 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->d_filter_table) (void)hipFree(s->d_filter_table);
 	for(void *q : {(void *)s->rp_flags, (void *)s->rp_p, (void *)s->rp_kill, (void *)s->rp_calls, (void *)s->rp_base, (void *)s->rp_seg_begin,
 	               (void *)s->rp_seg_seed, (void *)s->rp_seg_total, (void *)s->rp_seg_base, (void *)s->rp_counter, (void *)s->rp_hits,
-	               (void *)s->rt_planes, (void *)s->rt_film, (void *)s->rt_cnt}) if(q) (void)hipFree(q);
+	               (void *)s->rt_planes, (void *)s->rt_film, (void *)s->rt_cnt, (void *)s->rt_flags}) if(q) (void)hipFree(q);
 	delete s;
 }
 
@@ -2214,10 +2215,9 @@ int yafgpu_render_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp, flo
 
 // ---- multi-pass anti-aliasing: TiledIntegrator::render (integrator_tiled.cc:116-258) -----------------------------
 // The noise detection between passes (ImageFilm::nextPass, imagefilm.cc:270-480) is an image-space pass over the
-// film so far; it runs on the host on the downloaded film (a few ms per pass at 1024x1024) — the passes themselves
-// are the hot path.
+// film so far: aa_detect_kernel below; next_pass_mask is the same on the host (YAFGPU_AA_DETECT=host), kept as its checker.
 namespace {
-float dark_threshold_curve(float b)   // ImageFilm::darkThresholdCurveInterpolate, imagefilm.cc:1312-1328
+__host__ __device__ float dark_threshold_curve(float b)   // ImageFilm::darkThresholdCurveInterpolate, imagefilm.cc:1312-1328
 {
 	if(b <= 0.10f) return 0.0001f;
 	else if(b > 0.10f && b <= 0.20f) return (0.0001f + (b - 0.10f) * (0.0010f - 0.0001f) / 0.10f);
@@ -2235,19 +2235,19 @@ float dark_threshold_curve(float b)   // ImageFilm::darkThresholdCurveInterpolat
 	else return 0.1000f;
 }
 struct Px { float c[4]; };
-Px px_normalized(const float *p)   // Pixel::normalized, util_image_buffers.h:39-43; Rgba / float, color.h:310-314
+__host__ __device__ Px px_normalized(const float *p)   // Pixel::normalized, util_image_buffers.h:39-43; Rgba / float, color.h:310-314
 {
 	Px o;
 	if(p[4] != 0.f) { const float f = (float)(1.0 / (double)p[4]); for(int k = 0; k < 4; ++k) o.c[k] = p[k] * f; }
 	else for(int k = 0; k < 4; ++k) o.c[k] = 0.f;
 	return o;
 }
-float px_difference(const Px &a, const Px &b, bool use_rgb)   // Rgba::colorDifference, color.h:447-464
+__host__ __device__ float px_difference(const Px &a, const Px &b, bool use_rgb)   // Rgba::colorDifference, color.h:447-464
 {
 	const float bri_a = 0.2126f * a.c[0] + 0.7152f * a.c[1] + 0.0722f * a.c[2];
 	const float bri_b = 0.2126f * b.c[0] + 0.7152f * b.c[1] + 0.0722f * b.c[2];
-	float d = std::fabs(bri_b - bri_a);
-	if(use_rgb) for(int k = 0; k < 4; ++k) { const float dk = std::fabs(b.c[k] - a.c[k]); if(d < dk) d = dk; }
+	float d = fabsf(bri_b - bri_a);
+	if(use_rgb) for(int k = 0; k < 4; ++k) { const float dk = fabsf(b.c[k] - a.c[k]); if(d < dk) d = dk; }
 	return d;
 }
 // which pixels get more samples; returns their number
@@ -2299,6 +2299,52 @@ int next_pass_mask(const float *film, int w, int h, const yafgpu_aa_schedule &aa
 	for(uint8_t f : flags) n += f;
 	return n;
 }
+// The same on the device, one thread per pixel of the loop above (every store is the same 1: the order does not matter), on the
+// combined film that is on the device anyway — the host version costs 10 ms per pass at 1024 x 1024 plus the film's way down.
+__global__ __launch_bounds__(kBlock) void aa_detect_kernel(const float *film, int w, int h, yafgpu_aa_schedule aa, float aa_thesh, uint8_t *flags)
+{
+	const int n = (w - 1) * (h - 1);
+	const int half = aa.variance_edge_size / 2;
+	const bool rgb = aa.detect_color_noise != 0;
+	for(int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x))
+	{
+		const int x = i % (w - 1), y = i / (w - 1);
+		auto P = [&](int px, int py) { return film + 5 * ((size_t)py * (size_t)w + (size_t)px); };
+		auto set = [&](int px, int py) { flags[(size_t)py * (size_t)w + (size_t)px] = 1; };
+		float scaled = aa_thesh;
+		if(P(x, y)[4] <= 0.f) set(x, y);
+		const Px c = px_normalized(P(x, y));
+		const float bri = 0.2126f * fabsf(c.c[0]) + 0.7152f * fabsf(c.c[1]) + 0.0722f * fabsf(c.c[2]);
+		if(aa.dark_detection_type == 1 && aa.dark_threshold_factor > 0.f) scaled = aa_thesh * ((1.f - aa.dark_threshold_factor) + (bri * aa.dark_threshold_factor));
+		else if(aa.dark_detection_type == 2) scaled = dark_threshold_curve(bri);
+		if(px_difference(c, px_normalized(P(x + 1, y)), rgb) >= scaled) { set(x, y); set(x + 1, y); }
+		if(px_difference(c, px_normalized(P(x, y + 1)), rgb) >= scaled) { set(x, y); set(x, y + 1); }
+		if(px_difference(c, px_normalized(P(x + 1, y + 1)), rgb) >= scaled) { set(x, y); set(x + 1, y + 1); }
+		if(x > 0 && px_difference(c, px_normalized(P(x - 1, y + 1)), rgb) >= scaled) { set(x, y); set(x - 1, y + 1); }
+		if(aa.variance_pixels > 0)
+		{
+			int vx = 0, vy = 0;
+			for(int xd = -half; xd < half - 1; ++xd)
+			{
+				int xi = x + xd; if(xi < 0) xi = 0; else if(xi >= w - 1) xi = w - 2;
+				if(px_difference(px_normalized(P(xi, y)), px_normalized(P(xi + 1, y)), rgb) >= scaled) ++vx;
+			}
+			for(int yd = -half; yd < half - 1; ++yd)
+			{
+				int yi = y + yd; if(yi < 0) yi = 0; else if(yi >= h - 1) yi = h - 2;
+				if(px_difference(px_normalized(P(x, yi)), px_normalized(P(x, yi + 1)), rgb) >= scaled) ++vy;
+			}
+			if(vx + vy >= aa.variance_pixels)
+				for(int xd = -half; xd < half; ++xd)
+					for(int yd = -half; yd < half; ++yd)
+					{
+						int xi = x + xd; if(xi < 0) xi = 0; else if(xi >= w) xi = w - 1;
+						int yi = y + yd; if(yi < 0) yi = 0; else if(yi >= h) yi = h - 1;
+						set(xi, yi);
+					}
+		}
+	}
+}
 } // namespace
 
 int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *rp_in, const yafgpu_aa_schedule *aa_in,
@@ -2317,23 +2363,48 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 	const size_t film_bytes = (size_t)w * (size_t)h * YAFGPU_FILM_CHANNELS * sizeof(float);
 	{ const int rc_t = render_targets(s, w, h, &d_planes, &d_film, &d_cnt); if(rc_t) return rc_t; }
 	HIP_OK(hipMemset(d_cnt, 0, sizeof(yafgpu_counters)));
-	auto film_now = [&]() -> int {
+	auto film_now = [&](bool download = true) -> int {
 		int rc = yafgpu_film_combine(d_planes, d_film, w, h, nullptr);
-		if(!rc && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
+		if(!rc && download && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
 		return rc;
 	};
 	// the whole frame's film for the detection step of a sharded render: all ranks' planes summed (exactly: one writer per
 	// element), then combined in the single-GPU order
 	DevMem<float> d_all;
 	const size_t plane_floats = yafgpu_planes_bytes(w, h) / sizeof(float);
-	auto film_of_all_ranks = [&]() -> int {
+	auto film_of_all_ranks = [&](bool download = true) -> int {
 		if(!d_all.p && d_all.alloc(plane_floats) != hipSuccess) return fail(-3, "out of device memory (plane exchange)");
 		if(hipMemcpy(d_all, d_planes, plane_floats * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return fail(-100, "plane copy failed");
 		if(hipDeviceSynchronize() != hipSuccess) return fail(-100, "render failed before the plane exchange");
 		if(s->exchange(s->exchange_user, d_all, (uint64_t)plane_floats)) return fail(-31, "the plane exchange function reported a failure");
 		int rc = yafgpu_film_combine(d_all, d_film, w, h, nullptr);
-		if(!rc && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
+		if(!rc && download && hipMemcpy(h_film, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(-100, "film download failed");
 		return rc;
+	};
+	// the detection step on the film that d_film holds: flags down (1 byte per pixel), counted here; < 0: error
+	const bool detect_on_host = [] { const char *e = std::getenv("YAFGPU_AA_DETECT"); return e && std::strcmp(e, "host") == 0; }();
+	auto detect = [&](float aa_thesh, std::vector<uint8_t> &flags) -> int {
+		const size_t n_px = (size_t)w * (size_t)h;
+		flags.assign(n_px, 0);
+		if(!(aa_thesh > 0.f)) { std::fill(flags.begin(), flags.end(), (uint8_t)1); return w * h; }   // imagefilm.cc:319,460; doMoreSamples :919
+		if(n_px > s->rt_flags_n)
+		{
+			if(s->rt_flags) (void)hipFree(s->rt_flags);
+			s->rt_flags = nullptr; s->rt_flags_n = 0;
+			if(hipMalloc((void **)&s->rt_flags, n_px) != hipSuccess) return fail(-3, "out of device memory (resample flags)");
+			s->rt_flags_n = n_px;
+		}
+		if(hipMemsetAsync(s->rt_flags, 0, n_px, nullptr) != hipSuccess) return fail(-100, "flag reset failed");
+		if(w > 1 && h > 1)
+		{
+			const uint32_t grid = (uint32_t)std::min<size_t>(((size_t)(w - 1) * (size_t)(h - 1) + kBlock - 1) / kBlock, 4096);
+			hipLaunchKernelGGL(aa_detect_kernel, dim3(grid), dim3(kBlock), 0, nullptr, (const float *)d_film, w, h, aa, aa_thesh, s->rt_flags);
+			if(hipGetLastError() != hipSuccess) return fail(-100, "detection kernel launch failed");
+		}
+		if(hipMemcpy(flags.data(), s->rt_flags, n_px, hipMemcpyDeviceToHost) != hipSuccess) return fail(-100, "flag download failed");
+		int n = 0;
+		for(uint8_t f : flags) n += f;
+		return n;
 	};
 	// integrator_tiled.cc:136-258
 	const int aa_samples = std::max(1, rp.aa_minsamples);
@@ -2364,8 +2435,9 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *s, const yafgpu_render_params *
 		light_mult *= aa.light_sample_multiplier_factor;
 		if(!(resampled <= 0 && !threshold_changed))
 		{
-			if((rc = exchange ? film_of_all_ranks() : film_now())) break;
-			resampled = next_pass_mask(h_film, w, h, aa, threshold, mask);
+			if((rc = exchange ? film_of_all_ranks(detect_on_host) : film_now(detect_on_host))) break;
+			if(detect_on_host) resampled = next_pass_mask(h_film, w, h, aa, threshold, mask);
+			else if((resampled = detect(threshold, mask)) < 0) { rc = resampled; break; }
 			threshold_changed = false;
 		}
 		const int n = (int)std::ceil((float)aa_inc * sample_mult);

@@ -344,6 +344,26 @@ def test_full_size_c4_one_light_against_oracle_windows(pipeline):
 
 
 # ---- serial-state replay: the reference's per-tile roulette stream and its light counter -------------
+@pytest.mark.parametrize("aa", [dict(AA_threshold=0.02), dict(AA_threshold=0.03, AA_detect_color_noise=True, AA_dark_detection_type="linear", AA_dark_threshold_factor=0.6),
+                                dict(AA_threshold=0.5, AA_dark_detection_type="curve", AA_variance_pixels=3, AA_variance_edge_size=8)])
+def test_noise_detection_on_the_device_equals_the_host_version(aa, pipeline, monkeypatch):
+    """ImageFilm::nextPass's detection (imagefilm.cc:270-480) runs on the device between adaptive passes; the host restatement it
+    replaced (YAFGPU_AA_DETECT=host) must flag the same pixels: same resampled counts per pass, same film."""
+    if pipeline == "megakernel":
+        pytest.skip("multi-pass renders belong to the wavefront pipeline")
+    sc = scenes.cornell_soup(2000, seed=17, res=(71, 53))
+    rd = scenes.render_settings(71, 53, 2, bounces=2, AA_passes=4, AA_inc_samples=2, **aa)
+    out = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("YAFGPU_AA_DETECT", mode)
+        yi = Interface()
+        scenes.load_scene(yi, sc, rd)
+        yi.render()
+        out.append((yi.getFilm(71, 53), yi.getRenderStats().camera_samples))
+    assert out[0][1] == out[1][1] and out[0][1] > 71 * 53 * 2, "other pixels were flagged (or none at all)"
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_prepare_render_keeps_the_device_scene_until_something_changes(pipeline):
     """Scene::update rebuilds the tree only when the scene changed (scene.cc:784-790): a second render() of an untouched scene reuses
     the device scene (no second tree build), a render parameter alone (samples) does not rebuild either, a new camera or a changed

@@ -1827,7 +1827,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		HIP_OK(hipMalloc((void **)&s->wf_filt, (size_t)2 * s->wf_cap * sizeof(float4)));
 		s->wf_filt_cap = s->wf_cap;
 	}
-	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 64 * sizeof(uint32_t)));
+	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 128 * sizeof(uint32_t)));      // two sets of 2 x 32 (chunk pipelining)
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev));
 	HIP_OK(hipGetDeviceProperties(&prop, dev));
@@ -1945,7 +1945,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 				hipStream_t any_stream = fork ? s->side_stream : stream;
 				if(it > 0 && !record)      // (a record pass has no shadow rays)
 				{
-					HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * s->wf_cap + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
+					HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * a.n_paths + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
 					if((rc = timed(1, [&] {
 						if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
 						else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);
@@ -2022,6 +2022,102 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		return 0;
 	};
 	int rc = 0;
+	// Chunk pipelining.  The launches of a pass form a chain (trace -> shade -> trace ...), and a persistent traversal launch ends in a
+	// tail as long as one ray's walk (~0.3 ms at 1 M triangles) during which the GPU drains: four exposed tails per pass, 5 % of the
+	// metric pass and a third of an eighth-of-the-frame shard's.  Two halves of the pass's pixels, each with its own state, queues
+	// and stream, run the same chain side by side: one's tail is filled by the other's launches.  The film planes are added to by
+	// one accumulate launch at a time, after both.  (Not with the serial-state replay, recursion polling, a resample mask or per-kernel
+	// profiling, which keep the sequential path below.)
+	// MEASURED, OFF (opt in with YAFGPU_CHUNK_PIPELINE=1): the two streams' persistent launches mostly take turns instead of filling
+	// each other's tails, and every half pays the full tail — 25.5 / 13.8 / 8.0 / 5.5 ms per pass at 1, 1/2, 1/4, 1/8 of the metric frame
+	// against 25.5 / 13.9 / 7.9 / 4.75 ms with the closest-hit / any-hit overlap alone.
+	bool pipelined = false;
+	if(const char *e = std::getenv("YAFGPU_CHUNK_PIPELINE"))
+		pipelined = std::atoi(e) != 0 && !replay && frames == 0 && !masked && !s->profiling && !stats && (uint64_t)n_pixels_total * spp >= (1u << 16);
+	if(pipelined)
+	{
+		if(!s->side_stream)
+		{
+			HIP_OK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+			HIP_OK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+			HIP_OK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+		}
+		struct Ctx { WfArgs a; uint32_t *qset[2][3]; uint32_t *cnt[2]; hipStream_t st; uint32_t g_gen; int cur; };
+		// halves of every chunk, two at a time (a chunk already fits the allocated capacity: its halves fit side by side)
+		for(const Chunk &ch : chunks)
+		{
+			if(s->aborted()) return fail(-30, "aborted");
+			const uint32_t px_a = (ch.n_pixels + 1u) / 2u, px_b = ch.n_pixels - px_a;
+			Ctx cx[2];
+			const int n_ctx = px_b > 0 ? 2 : 1;
+			size_t slot_off = 0;
+			for(int k = 0; k < n_ctx; ++k)
+			{
+				Ctx &c = cx[k];
+				const uint32_t px = k == 0 ? px_a : px_b, px_begin = ch.pixel_begin + (k == 0 ? 0u : px_a);
+				const size_t np = (size_t)px * spp;
+				c.a = WfArgs{};
+				c.a.ra = ra;
+				c.a.state = s->wf_state + slot_off; c.a.cap = s->wf_cap; c.a.results = s->wf_results + slot_off;
+				c.a.frames = 0; c.a.frame_recs = frame_recs; c.a.has_glossy = s->has_glossy ? 1 : 0;
+				c.a.pixel_begin = px_begin; c.a.n_pixels = px; c.a.n_paths = (uint32_t)np;
+				c.a.pix_prefix = s->d_pix_prefix; c.a.pix_xy = s->wf_pix_xy + (k == 0 ? 0u : px_a); c.a.pix_listed = 0;
+				c.a.ev_m = 1;
+				uint32_t *qb = s->wf_queues + 8 * slot_off;
+				c.qset[0][0] = qb; c.qset[0][1] = qb + np; c.qset[0][2] = qb + 3 * np;
+				c.qset[1][0] = qb + 4 * np; c.qset[1][1] = qb + 5 * np; c.qset[1][2] = qb + 7 * np;
+				c.cnt[0] = s->wf_counts + 64 * k; c.cnt[1] = s->wf_counts + 64 * k + 32;
+				c.a.verdict = s->wf_verdict + (2 * slot_off + 31) / 32 + (k ? 1 : 0);
+				c.a.shadow_filt = transp ? s->wf_filt + 2 * slot_off : nullptr;
+				c.st = k == 0 ? stream : s->side_stream;
+				c.g_gen = std::min<uint32_t>((uint32_t)((np + kBlock - 1) / kBlock), (uint32_t)cus * 8u);
+				c.cur = 0;
+				slot_off += np;
+			}
+			// fork: what the caller's stream holds so far (the previous pass, the prefix upload) precedes both halves
+			HIP_OK(hipEventRecord(s->ev_fork, stream));
+			HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
+			for(int k = 0; k < n_ctx; ++k)
+			{
+				Ctx &c = cx[k];
+				c.a.cnt_in = c.cnt[0]; c.a.cnt_out = c.cnt[1];
+				c.a.q_closest_in = nullptr; c.a.q_shadow_in = c.qset[0][1]; c.a.q_resume_in = c.qset[0][2];
+				c.a.q_closest_out = c.qset[1][0]; c.a.q_shadow_out = c.qset[1][1]; c.a.q_resume_out = c.qset[1][2];
+				hipLaunchKernelGGL(wf_generate, dim3(c.g_gen), dim3(kBlock), 0, c.st, c.a);
+			}
+			HIP_OK(hipGetLastError());
+			for(int it = 0; it < iters; ++it)
+				for(int k = 0; k < n_ctx; ++k)
+				{
+					Ctx &c = cx[k];
+					HIP_OK(hipMemsetAsync(c.a.cnt_out, 0, 8 * sizeof(uint32_t), c.st));
+					hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, c.st, c.a);
+					if(it > 0)
+					{
+						HIP_OK(hipMemsetAsync(c.a.verdict, 0, ((size_t)2 * c.a.n_paths + 31) / 32 * sizeof(uint32_t), c.st));
+						if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, c.st, c.a);
+						else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, c.st, c.a);
+					}
+					if(shade_variant) { if(shade_variant->launch(&c.a, sizeof c.a, g_shade, c.st)) return fail(-21, "shading kernel variant and main unit disagree on the argument layout"); }
+					else hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, c.st, c.a);
+					HIP_OK(hipGetLastError());
+					c.cur ^= 1;
+					c.a.cnt_in = c.cnt[c.cur]; c.a.cnt_out = c.cnt[c.cur ^ 1];
+					c.a.q_closest_in = c.qset[c.cur][0]; c.a.q_shadow_in = c.qset[c.cur][1]; c.a.q_resume_in = c.qset[c.cur][2];
+					c.a.q_closest_out = c.qset[c.cur ^ 1][0]; c.a.q_shadow_out = c.qset[c.cur ^ 1][1]; c.a.q_resume_out = c.qset[c.cur ^ 1][2];
+				}
+			// join, then the film: one accumulate launch at a time
+			HIP_OK(hipEventRecord(s->ev_join, s->side_stream));
+			HIP_OK(hipStreamWaitEvent(stream, s->ev_join, 0));
+			for(int k = 0; k < n_ctx; ++k)
+			{
+				const uint32_t g_acc = std::min<uint32_t>((cx[k].a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
+				hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, cx[k].a);
+			}
+			HIP_OK(hipGetLastError());
+		}
+		return 0;
+	}
 	if(lc_sharded)
 	{
 		size_t seg_off = 0;

@@ -58,6 +58,9 @@ struct DevScene
 {
 	const uint2 *nodes;          // 8-byte kd nodes (kdtree_build.h)
 	const uint4 *nodes2;         // (node i, a copy of its right child): the pair layout of the traversal kernels (YAFGPU_TRACE_PAIR), or nullptr
+	const uint2 *nodes_blk;      // the same tree in 64-B blocks of three levels (YAFGPU_TRACE_BLOCKS): node id = block * 8 + slot, slot s < 3 has its
+	                             // children in slots 2s + 1, 2s + 2; a node in slots 3..6 keeps (in the child field) the block of its left child, the right
+	                             // child's block is the next one; both children sit in their blocks' slot 0.  Or nullptr.
 	const uint32_t *refs;        // leaf references
 	const float4 *tri;           // 3 x float4 per triangle: (a, eps) (e1, mat|vis<<30) (e2, 0)
 	const float4 *tri_ng;        // geometric normal + smooth flag
@@ -1338,6 +1341,44 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		const uint4 *d_pairs = nullptr;
 		if((rc = upload(s, pairs.data(), pairs.size(), &d_pairs))) { yafgpu_scene_destroy(s); return rc; }
 		dv.nodes2 = d_pairs;
+	}
+#endif
+	dv.nodes_blk = nullptr;
+#if YAFGPU_TRACE_BLOCKS
+	if(!s->tree.nodes.empty())
+	{	// the depth-first array (left child = next node, right child in the node) laid out again in blocks of three levels
+		const std::vector<KdNode> &tn = s->tree.nodes;
+		std::vector<uint2> blk(8, make_uint2(0u, 3u));
+		std::vector<std::pair<uint32_t, uint32_t>> todo;      // (depth-first index of a subtree's root, its block)
+		todo.emplace_back(0u, 0u);
+		while(!todo.empty())
+		{
+			const auto [root, b] = todo.back(); todo.pop_back();
+			uint32_t at[7]; bool have[7] = {true, false, false, false, false, false, false};
+			at[0] = root;
+			for(int sl = 0; sl < 7; ++sl)
+			{
+				if(!have[sl]) continue;
+				const uint2 nd = *(const uint2 *)&tn[at[sl]];
+				uint2 out = nd;
+				if((nd.y & 3u) != 3u)
+				{
+					const uint32_t left = at[sl] + 1u, right = nd.y >> 2;
+					if(sl < 3) { at[2 * sl + 1] = left; at[2 * sl + 2] = right; have[2 * sl + 1] = have[2 * sl + 2] = true; out.y = nd.y & 3u; }
+					else
+					{
+						const uint32_t bl = (uint32_t)(blk.size() / 8);
+						blk.resize(blk.size() + 16, make_uint2(0u, 3u));
+						out.y = (nd.y & 3u) | (bl << 2);
+						todo.emplace_back(right, bl + 1u);
+						todo.emplace_back(left, bl);
+					}
+				}
+				blk[(size_t)b * 8 + (size_t)sl] = out;
+			}
+		}
+		if(blk.size() / 8 >= (1u << 27)) { yafgpu_scene_destroy(s); return fail(-2, "kd-tree too large for the block layout"); }
+		if((rc = upload(s, blk.data(), blk.size(), &dv.nodes_blk))) { yafgpu_scene_destroy(s); return rc; }
 	}
 #endif
 	if((rc = upload(s, s->tree.refs.data(), s->tree.refs.size(), &dv.refs))) { yafgpu_scene_destroy(s); return rc; }

@@ -1211,6 +1211,9 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_PAIR
 #define YAFGPU_TRACE_PAIR 1      // closest-hit launches -6.5 % on the 1 M-triangle scenes, -4.5 % on the 100 k one (pair4 in profiles/r02_ab_pair.txt)
 #endif
+#ifndef YAFGPU_TRACE_BLOCKS
+#define YAFGPU_TRACE_BLOCKS 0    // measured, off: 1 = the any-hit launches walk the block layout of the tree (DevScene::nodes_blk): +4 %; 2 = the closest-hit ones too, instead of the pair array: +10 % (profiles/r02_ab_blocks.txt)
+#endif
 #ifndef YAFGPU_TRACE_WAVES
 #define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
 #endif
@@ -1250,6 +1253,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 	// the walk: at a node | at a non-empty leaf, waiting for the pending slot | no node left | no ray
 	enum : uint32_t { kWalk = 0u, kBlocked = 1u, kWalkEnd = 2u, kNoRay = 3u };
 	constexpr int kVoteNum = YAFGPU_VOTE_NUM, kVoteDen = YAFGPU_VOTE_DEN, kNodeBurst = YAFGPU_NODE_BURST;
+	constexpr bool kBlk = (YAFGPU_TRACE_BLOCKS == 2) || (YAFGPU_TRACE_BLOCKS == 1 && kAny);
 	uint32_t ws = kNoRay;
 	uint32_t p_cur = 0u, p_end = 0u, ti = 0u;       // pending leaf: references [p_cur, p_end) still to test, ti = refs[p_cur] (in flight)
 	float p_tmax = 0.f;                              // exit distance of the pending leaf's cell
@@ -1407,7 +1411,14 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 #else
 				const bool below = dn ? (o <= split) : (o < split);
 #endif
-				const uint32_t left = node + 1u, right = nd.y >> 2;
+				uint32_t left = node + 1u, right = nd.y >> 2;
+				if(kBlk)
+				{	// block layout: children inside the block for slots 0..2, the roots of the two child blocks for slots 3..6
+					const uint32_t sl = node & 7u;
+					const bool inside = sl < 3u;
+					left = inside ? node + sl + 1u : (nd.y >> 2) << 3;
+					right = inside ? left + 1u : left + 8u;
+				}
 				const uint32_t near_c = below ? left : right, far_c = below ? right : left;
 				if(kStats) { ++cn.interior; if(p_cur < p_end) ++spec; }
 				const bool near_only = !(tplane <= tmax) || tplane <= 0.f;        // plane beyond the cell or behind the origin (also NaN)
@@ -1491,7 +1502,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			// Closest-hit rays only: the doubled node footprint costs the any-hit rays (L2 hit rate 75 %) more than the saved
 			// round trips give them (1 M triangles: closest-hit launches -7 %, any-hit launches +8.5 %).
 #pragma unroll 1
-			for(int s = 0; s < (kAny ? 0 : kNodeBurst / 2); ++s)
+			for(int s = 0; s < ((kAny || kBlk) ? 0 : kNodeBurst / 2); ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
 #if YAFGPU_TRACE_TRIPF
@@ -1511,13 +1522,13 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			}
 #endif
 #pragma unroll 1
-			for(int s = 0; s < ((YAFGPU_TRACE_PAIR && !kAny) ? 0 : kNodeBurst); ++s)
+			for(int s = 0; s < ((YAFGPU_TRACE_PAIR && !kAny && !kBlk) ? 0 : kNodeBurst); ++s)
 			{
 				if(kStats && __ballot(ws == kWalk) != 0ull) ++rounds_node;
 #if YAFGPU_TRACE_TRIPF
 				if(p_cur < p_end && !q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; q_ok = true; }
 #endif
-				if(ws == kWalk) node_step(sc.nodes[node]);
+				if(ws == kWalk) node_step(kBlk ? sc.nodes_blk[node] : sc.nodes[node]);
 			}
 		}
 #endif

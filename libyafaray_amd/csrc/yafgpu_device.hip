@@ -28,6 +28,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
 
 #include "../../include/yafgpu.h"
 #include "kdtree_build.h"
@@ -1129,6 +1131,7 @@ struct yafgpu_scene
 	// render targets of the host-film entry points, kept between calls (allocating and freeing 100 MB per render cost up to half a
 	// second a call on this runtime — ten times the pass itself at 1024x1024)
 	float *rt_planes = nullptr, *rt_film = nullptr; yafgpu_counters *rt_cnt = nullptr; size_t rt_planes_n = 0, rt_film_n = 0;
+	int n_cus = 0;                                            // compute units of the device the scene lives on
 	uint8_t *rt_flags = nullptr; size_t rt_flags_n = 0;       // resample flags of the detection step between adaptive passes
 	float4 *rp_hits = nullptr; size_t rp_hits_cap = 0;       // closest-hit answers of the record pass (WfArgs::hit_cache)
 	uint32_t lc_host_counter = 0;                        // correlative_sample_number_ of a sharded render: the same value on every rank (lc_exchange_counts)
@@ -1584,8 +1587,19 @@ static constexpr uint32_t kWfMaxPaths = 32u << 20;   // paths in flight per chun
 
 static int wf_grid(const void *kernel, int cus)
 {
+	// (the occupancy of a kernel does not change between passes: asked once per kernel)
+	static std::mutex mu; static std::map<const void *, int> known;
 	int per_cu = 0;
-	if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		auto it = known.find(kernel);
+		if(it != known.end()) per_cu = it->second;
+		else
+		{
+			if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+			known[kernel] = per_cu;
+		}
+	}
 	int cap = 8;
 	if(const char *e = std::getenv("YAFGPU_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(e));   // occupancy experiments
 	return cus * std::min(per_cu, cap);
@@ -1869,10 +1883,14 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		s->wf_filt_cap = s->wf_cap;
 	}
 	if(!s->wf_counts) HIP_OK(hipMalloc((void **)&s->wf_counts, 128 * sizeof(uint32_t)));      // two sets of 2 x 32 (chunk pipelining)
-	int dev = 0; hipDeviceProp_t prop;
-	HIP_OK(hipGetDevice(&dev));
-	HIP_OK(hipGetDeviceProperties(&prop, dev));
-	const int cus = prop.multiProcessorCount;
+	if(s->n_cus <= 0)
+	{
+		int dev = 0; hipDeviceProp_t prop;
+		HIP_OK(hipGetDevice(&dev));
+		HIP_OK(hipGetDeviceProperties(&prop, dev));
+		s->n_cus = prop.multiProcessorCount;
+	}
+	const int cus = s->n_cus;
 	const int g_trace_c = stats ? wf_grid((const void *)wf_trace<false, true>, cus) : wf_grid((const void *)wf_trace<false, false>, cus);
 	const int g_trace_s = stats ? wf_grid((const void *)wf_trace<true, true>, cus) : wf_grid((const void *)wf_trace<true, false>, cus);
 	const ShadeVariant *shade_variant = pick_shade_variant(s, frames);

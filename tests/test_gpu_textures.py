@@ -453,3 +453,53 @@ def test_test01_with_its_textures_against_the_references_expected_png():
         assert dd[sel].mean() < 2.0 and (dd[sel] <= 2).mean() > 0.80, (name, dd[sel].mean(), (dd[sel] <= 2).mean())
     assert stats["within_2"] >= 0.92 * n, stats
     assert stats["exact"] >= 0.70 * n, stats
+
+
+def test_bump_and_normal_map_through_the_xml_loader(tmp_path):
+    """The shipped test scene with a bump layer added to one textured cube's material and a second cube's texture flagged as a
+    normal map feeding another bump layer — written as scene XML (bump_shader, bump_strength, normalmap), read by the product's
+    loader, rendered on the device, against the oracle fed by an independent reading of the same file."""
+    import shutil
+    from tests import xml_scene
+    src = open(os.path.join(HERE, "golden", "test01_tex.xml")).read()
+    layer = lambda name, inp: (f'\t<list_element>\n\t\t<element sval="shader_node"/>\n\t\t<type sval="layer"/>\n\t\t<name sval="{name}"/>\n\t\t<input sval="{inp}"/>\n'
+                               '\t\t<mode ival="0"/>\n\t\t<do_color bval="false"/>\n\t\t<do_scalar bval="true"/>\n\t\t<color_input bval="false"/>\n\t\t<valfac fval="1"/>\n'
+                               '\t\t<def_val fval="1"/>\n\t\t<upper_value fval="0"/>\n\t</list_element>\n')
+    # the first two textured materials: their diffuse layer's mapper is "map0"; give both a bump layer over it
+    parts = src.split("</material>")
+    done = 0
+    for k, part in enumerate(parts):
+        if '<texture sval="Texture.00' in part and done < 2:
+            strength = ["3.0", "0.5"][done]
+            part = part.replace('<type sval="texture_mapper"/>', f'<type sval="texture_mapper"/>\n\t\t<bump_strength fval="{strength}"/>', 1)
+            part = part.replace('<type sval="shinydiffusemat"/>', '<type sval="shinydiffusemat"/>\n\t<bump_shader sval="bump0"/>', 1)
+            parts[k] = part + layer("bump0", "map0")
+            done += 1
+    assert done == 2
+    out = "</material>".join(parts)
+    # the second of those materials reads its texture as a normal map
+    tex_names = [ln.split('"')[1] for ln in out.splitlines() if ln.startswith("<texture name=")]
+    second = [p for p in parts if "bump0" in p][1]
+    tname = second.split('<texture sval="')[1].split('"')[0]
+    assert tname in tex_names
+    at = out.index(f'<texture name="{tname}">')
+    assert '<normalmap bval="false"/>' in out[at:out.index("</texture>", at)]
+    out = out[:at] + out[at:].replace('<normalmap bval="false"/>', '<normalmap bval="true"/>', 1)
+    for f in ("test01_tex.tga", "test01_tex.png", "test01_tex.hdr"):
+        shutil.copy(os.path.join(HERE, "golden", f), tmp_path / f)
+    path = str(tmp_path / "bumped.xml")
+    open(path, "w").write(out)
+    yi = Interface()
+    yi.loadXml(path)
+    yi.render()
+    film = yi.getFilm(480, 270)
+    sc, rd = xml_scene.load(path, texels=yi.getTextureImage)
+    assert sum(1 for m in sc["materials"] if m.get("bump_shader") == "bump0") == 2 and sum(1 for t in sc["textures"] if t.get("normalmap")) == 1
+    seed, skip = yi.getRandState()
+    ofilm, ost = po.OracleScene(sc).render(dict(rd, oracle_threads=8, rand_srand=seed, rand_skip=skip))
+    compare_films(film, ofilm, "test01 with bump layers through the XML loader", exact_weights=False)
+    # and the bump shows: the plain scene renders differently
+    y2 = Interface()
+    y2.loadXml(os.path.join(HERE, "golden", "test01_tex.xml"))
+    y2.render()
+    assert np.abs(y2.getFilm(480, 270)[..., :3] - film[..., :3]).max() > 0.01

@@ -387,7 +387,7 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h, bool to_clos
 	if(h.dirty & 0x08u)
 	{
 		float4 r14 = h.r14;
-		if(YAFGPU_HOT_ACC) r14.w = fbits((ubits(r14.w) & ~(kDlcAccZero | kDlcTotZero)) | (h.acc_zero ? kDlcAccZero : 0u) | (h.tot_zero ? kDlcTotZero : 0u));
+		if(YAFGPU_ACC_ZERO_FLAG) r14.w = fbits((ubits(r14.w) & ~(kDlcAccZero | kDlcTotZero)) | (h.acc_zero ? kDlcAccZero : 0u) | (h.tot_zero ? kDlcTotZero : 0u));
 		REC(14) = r14;
 	}
 	if(YAFGPU_HOT_ACC && !h.acc_zero)

@@ -184,6 +184,10 @@ void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t 
 void yafaray_setSerialReplay(yafaray_interface_t *yi, yafaray_bool_t on);
 /* srand() seed and values consumed since, of the libc stream the next render's tile seeds continue (-1: nothing created yet) */
 void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip);
+/* An embedder that calls libc srand(seed) itself (and consumes `skip` values) between scene construction and render says so
+ * here — the reference would simply continue from that state at integrator_tiled.cc:319.  Holds until the next material or
+ * object is created (their constructors call srand again).  seed < 0: back to the constructors' state. */
+void yafaray_setRandState(yafaray_interface_t *yi, int srand_seed, int skip);
 /* Two-step render for drivers that own device memory and streams (bench.py, RCCL reduce):
  * prepare = setupScene + Scene::update (tree build, upload); renderPass launches one pass
  * asynchronously on `stream` into caller-owned device memory d_planes (yafgpu_planes_bytes). */

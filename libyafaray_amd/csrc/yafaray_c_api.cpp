@@ -119,6 +119,7 @@ struct yafaray_interface
 	// Material / ObjectGeometric constructor calls srand(its running index) and then draws a random colour
 	// (material.cc:53-66, object_geom.cc:39-51); whichever object was made last leaves the state rand() continues from
 	uint32_t last_srand = 0u; bool have_srand = false;
+	int user_srand = -1, user_skip = 0;  // yafaray_setRandState: the embedder's own srand() after the last constructor
 	bool serial_replay = true;           // yafaray_setSerialReplay
 	std::vector<int32_t> tile_rand0;     // the first pass's value per tile (yafaray_renderPassDevice)
 	yafgpu_exchange_fn exchange = nullptr; void *exchange_user = nullptr;     // yafaray_setPlaneExchange
@@ -166,7 +167,7 @@ float host_fpow(float a, float b) { return host_fexp2(host_flog2(a) * b); }
 // Material::material_index_auto_ / ObjectGeometric::object_index_auto_ (common/material.cc:33, object_geom.cc:29): static,
 // process-wide, never reset — like the reference, one process is assumed to build its scenes one after the other
 unsigned int g_material_index_auto = 0u, g_object_index_auto = 0u;
-void note_srand(yafaray_interface *yi, unsigned int seed) { yi->last_srand = seed; yi->have_srand = true; }
+void note_srand(yafaray_interface *yi, unsigned int seed) { yi->last_srand = seed; yi->have_srand = true; yi->user_srand = -1; yi->user_skip = 0; }
 // values the constructor's colour loop consumed after its srand(): do { r, g, b = rand() % 8 / 8 } while(r + g + b < 0.5)
 int colour_loop_draws(uint32_t seed)
 {
@@ -1321,8 +1322,15 @@ void yafaray_clearAll(yafaray_interface_t *yi)
 
 void yafaray_getRandState(yafaray_interface_t *yi, int *srand_seed, int *skip)
 {
+	if(yi->user_srand >= 0) { if(srand_seed) *srand_seed = yi->user_srand; if(skip) *skip = yi->user_skip; return; }
 	if(srand_seed) *srand_seed = yi->have_srand ? (int)(yi->last_srand & 0x7fffffffu) : -1;
 	if(skip) *skip = yi->have_srand ? colour_loop_draws(yi->last_srand) : 0;
+}
+void yafaray_setRandState(yafaray_interface_t *yi, int srand_seed, int skip)
+{
+	yi->user_srand = srand_seed < 0 ? -1 : srand_seed;
+	yi->user_skip = (srand_seed < 0 || skip < 0) ? 0 : skip;
+	yi->prepared = false;
 }
 void yafaray_setSerialReplay(yafaray_interface_t *yi, yafaray_bool_t on) { yi->serial_replay = on != 0; yi->prepared = false; }
 void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user)
@@ -1386,6 +1394,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 		if(aa_passes < 1) return fail(yi, "render: AA_passes must be at least 1");
 		aa.rand_srand = -1; aa.rand_skip = 0;
 		if(yi->have_srand) { aa.rand_srand = (int32_t)(yi->last_srand & 0x7fffffffu); aa.rand_skip = colour_loop_draws(yi->last_srand); }
+		if(yi->user_srand >= 0) { aa.rand_srand = yi->user_srand; aa.rand_skip = yi->user_skip; }      // yafaray_setRandState
 	}
 	int filter_type = YAFGPU_FILTER_BOX;      // RenderEnvironment::createImageFilm, environment.cc:537-541: unknown names default to box
 	if(filter == "mitchell") filter_type = YAFGPU_FILTER_MITCHELL;

@@ -65,7 +65,7 @@ C_API_SYMBOLS = [
     "yafaray_createTexture", "yafaray_createTextureFromMemory", "yafaray_getTextureImage",
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
-    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setPlaneExchange", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_prepareRender",
+    "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setPlaneExchange", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_setRandState", "yafaray_prepareRender",
     "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
 ]
 GPU_ABI_SYMBOLS = [
@@ -128,7 +128,7 @@ def load():
         "yafaray_getFilm": (ci, [vp, C.POINTER(cf), ci, ci]), "yafaray_getRenderStats": (ci, [vp, C.POINTER(RenderStats)]),
         "yafaray_setShard": (None, [vp, ci, ci]), "yafaray_setPlaneExchange": (None, [vp, EXCHANGE, vp]), "yafaray_setSerialReplay": (None, [vp, ci]), "yafaray_prepareRender": (ci, [vp]),
         "yafaray_renderPassDevice": (ci, [vp, vp, vp, vp]), "yafaray_getRenderSize": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
-        "yafaray_loadXml": (ci, [vp, cp]), "yafaray_getRandState": (None, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "yafaray_loadXml": (ci, [vp, cp]), "yafaray_getRandState": (None, [vp, C.POINTER(ci), C.POINTER(ci)]), "yafaray_setRandState": (None, [vp, ci, ci]),
         "yafaray_intersectRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]),
         "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
         "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
@@ -446,6 +446,10 @@ class Interface:
         a, b = C.c_int(), C.c_int()
         self._L.yafaray_getRandState(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def setRandState(self, srand_seed, skip=0):
+        """the embedder called libc srand(seed) itself after building the scene (and drew `skip` values): tile seeds continue there"""
+        self._L.yafaray_setRandState(self._h, int(srand_seed), int(skip))
 
     def prepareRender(self):
         return self._ok(self._L.yafaray_prepareRender(self._h), "prepareRender")

@@ -976,6 +976,9 @@ static void get_surface(const yor_scene *s, int ti, v3 hit, float bu, float bv, 
 
 /* Scene::intersect, scene.cc:896-927 */
 static FILE *g_ray_log = NULL;
+/* test hook (yor_set_trace): the samples renderTile hands to addSample and the closest-hit queries, in call order (single-threaded renders) */
+static float *g_trace_samples = NULL, *g_trace_rays = NULL;
+static uint64_t g_trace_samples_cap = 0, g_trace_rays_cap = 0, g_trace_n_samples = 0, g_trace_n_rays = 0;
 static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float *tmax, sp_t *sp, counters_t *cn)
 {
 	float dis, z, bu = 0, bv = 0; int ti = -1;
@@ -988,6 +991,16 @@ static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, floa
 		float rec[10] = {from.x, from.y, from.z, dir.x, dir.y, dir.z, tmin, *tmax, got ? z : -1.f, 0.f};
 		int32_t tri = got ? ti : -1; memcpy(&rec[9], &tri, 4);
 		fwrite(rec, sizeof rec, 1, g_ray_log);
+	}
+	if(g_trace_rays)
+	{
+		if(g_trace_n_rays < g_trace_rays_cap)
+		{
+			float *rec = g_trace_rays + 10 * g_trace_n_rays;
+			rec[0] = from.x; rec[1] = from.y; rec[2] = from.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z; rec[6] = tmin; rec[7] = *tmax; rec[8] = got ? z : -1.f;
+			int32_t tri = got ? ti : -1; memcpy(&rec[9], &tri, 4);
+		}
+		++g_trace_n_rays;
 	}
 	if(!got) return 0;
 	v3 h = vadd(from, vmul(dir, z)); /* ray.from_ + z * ray.dir_ */
@@ -3707,6 +3720,15 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 				integrate(st, from, dir, tmin, tmax, 0, c, NULL);
 				if(c[3] > 1.f) c[3] = 1.f;                 /* :459 */
 				c[0] *= wt; c[1] *= wt; c[2] *= wt; c[3] *= wt; /* :512 */
+				if(g_trace_samples)
+				{
+					if(g_trace_n_samples < g_trace_samples_cap)
+					{
+						float *rec = g_trace_samples + 8 * g_trace_n_samples;
+						rec[0] = (float)j; rec[1] = (float)i; rec[2] = dx; rec[3] = dy; rec[4] = c[0]; rec[5] = c[1]; rec[6] = c[2]; rec[7] = c[3];
+					}
+					++g_trace_n_samples;
+				}
 				film_add_sample(wk->film, c, j, i, dx, dy, wk->n_threads > 1 ? &wk->deferred : NULL);
 			}
 		}
@@ -3992,6 +4014,16 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 	free(wk); free(th); free(tile_rand);
 	return 0;
 }
+
+/* test hook: record what renderTile hands to ImageFilm::addSample (8 floats per sample: x, y, dx, dy, r, g, b, a) and every closest-hit
+ * query (10 floats: from, dir, tmin, tmax, t or -1, triangle index as int bits), in call order.  Only meaningful for n_threads = 1.
+ * NULL pointers switch it off.  yor_trace_counts reports how many of each the last renders produced (may exceed the capacities). */
+void yor_set_trace(float *samples8, uint64_t cap_samples, float *rays10, uint64_t cap_rays)
+{
+	g_trace_samples = samples8; g_trace_samples_cap = cap_samples; g_trace_n_samples = 0;
+	g_trace_rays = rays10; g_trace_rays_cap = cap_rays; g_trace_n_rays = 0;
+}
+void yor_trace_counts(uint64_t *n_samples, uint64_t *n_rays) { if(n_samples) *n_samples = g_trace_n_samples; if(n_rays) *n_rays = g_trace_n_rays; }
 
 /* ------------------------------------------------------------------ ray-level entry points */
 int yor_intersect(const yor_scene *s, int use_tree, const float from[3], const float dir[3], float tmin, float tmax,

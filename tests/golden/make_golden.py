@@ -24,7 +24,7 @@ def main():
     if not os.path.isdir("/root/reference"):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, timeout=900)
-    which = sys.argv[1:] or ["components", "textures"]
+    which = sys.argv[1:] or ["components", "textures", "integrator"]
     for name in which:          # textures: image textures + shader nodes, oracle/ref_harness/ref_textures.cc
         for variant in ("fast", "ieee"):
             exe = os.path.join(ROOT, "oracle", "_ref", f"ref_{name}_{variant}")

@@ -1,0 +1,69 @@
+"""Reader of tests/golden/ref_integrator_{ieee,fast}.json.gz — what the reference's own TiledIntegrator::render /
+renderTile / PathIntegrator::integrate / doLightEstimation / recursiveRaytrace (compiled from /root/reference by
+oracle/Makefile, driver oracle/ref_harness/ref_integrator.cc) produced on the harness's scenes: every sample handed to
+ImageFilm::addSample in call order, the first closest-hit queries, the ray counts.  The geometry query and the film are
+the harness's (its header says which member functions it provides); everything else ran the reference's code."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def u2f(a):
+    return np.asarray(a, dtype=np.uint32).view(np.float32)
+
+
+def load(variant):
+    with gzip.open(os.path.join(HERE, "golden", f"ref_integrator_{variant}.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def case_scene(doc, cs):
+    """-> (scene description, render description) in the dict form libyafaray_amd.scenes.load_scene and
+    oracle.pyoracle.OracleScene take (reference parameter names)"""
+    verts = u2f(doc["verts"]).reshape(-1, 3, 3)
+    sc = {"verts": verts, "tri_mat": np.asarray(cs["tri_mat"], dtype=np.int32), "vnormals": None,
+          "materials": doc["materials"], "lights": cs["lights"], "camera": cs["camera"]}
+    integ = dict(cs["integrator"])
+    rd = {"integrator": integ.pop("type"), "width": doc["width"], "height": doc["height"], "tile_size": doc["tile_size"],
+          "AA_pixelwidth": 1.0, "filter_type": "box", "background": cs["background"], "rand_srand": cs["srand"], "rand_skip": 0}
+    for k in ("caustic_type", "caustics", "do_AO"):
+        integ.pop(k, None)
+    rd.update(integ)
+    rd.update(cs["render"])
+    return sc, rd
+
+
+def samples(cs):
+    """-> xy (n, 2) int, dxdy (n, 2) f32, rgba (n, 4) f32 in addSample order"""
+    xy = np.asarray(cs["sample_xy"], dtype=np.int64).reshape(-1, 2)
+    v = u2f(cs["sample_dxdy_rgba"]).reshape(-1, 6)
+    return xy, v[:, :2], v[:, 2:]
+
+
+def closest_rays(cs):
+    return u2f(cs["closest_rays9"]).reshape(-1, 9), np.asarray(cs["closest_tri"], dtype=np.int32)
+
+
+def film_from_samples(doc, cs):
+    """ImageFilm::addSample (imagefilm.cc:925-1015) for the box filter of width 1 the cases use: filterw = 0.501, every
+    table entry 1; a sample lands on its pixel and on the right / lower neighbour when dx / dy >= 0.999.
+    float32 accumulation in call order -> film (h, w, 5)"""
+    w, h = doc["width"], doc["height"]
+    xy, dxdy, rgba = samples(cs)
+    film = np.zeros((h, w, 5), dtype=np.float32)
+    filterw = np.float64(np.float32(0.501))
+
+    def r2i(v):
+        return int(v + (0.5 - 1.4e-11))
+    for (x, y), (dx, dy), c in zip(xy, dxdy, rgba):
+        dx0 = max(0 - x, r2i(float(dx) - filterw)); dx1 = min(w - x - 1, r2i(float(dx) + filterw - 1.0))
+        dy0 = max(0 - y, r2i(float(dy) - filterw)); dy1 = min(h - y - 1, r2i(float(dy) + filterw - 1.0))
+        for j in range(y + dy0, y + dy1 + 1):
+            for i in range(x + dx0, x + dx1 + 1):
+                film[j, i, :4] += c
+                film[j, i, 4] += np.float32(1.0)
+    return film

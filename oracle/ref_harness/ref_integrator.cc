@@ -392,7 +392,10 @@ static std::string json_params(const Params &ps_)
 		{
 			case P::I: snprintf(b, sizeof b, "%d", p.i); s += b; break;
 			case P::B: s += p.b ? "true" : "false"; break;
-			case P::F: snprintf(b, sizeof b, "%.17g", p.f); s += b; break;
+			case P::F:      // always with a decimal point: the ParamMap is strictly typed (param.cc:49-53) and a JSON reader makes "14" an int
+				snprintf(b, sizeof b, "%.17g", p.f); s += b;
+				if(!strpbrk(b, ".eEn")) s += ".0";
+				break;
 			case P::S: s += "\"" + p.s + "\""; break;
 			case P::V3: snprintf(b, sizeof b, "[%.17g, %.17g, %.17g]", p.v[0], p.v[1], p.v[2]); s += b; break;
 		}

@@ -23,8 +23,12 @@ oracle — a port of the reference's algorithm — timed single-threaded and on 
 CPU share on a bounded sample of the same scene).
 """
 import argparse
+import hashlib
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,6 +50,54 @@ WORKLOADS = {
     "c4": dict(desc="1M-tri soup 50% glossy + 2 area lights (MIS) 1024x1024 64spp 2 bounces", n_tris=1_000_000, res=1024, spp=64,
                bounces=2, glossy=0.5, lights=2, sigma=0.01, seed=1),
 }
+
+
+KERNEL_SOURCES = ("yafgpu_wavefront.h", "yafgpu_device.hip", "yafgpu_shading.h", "yafgpu_math.h", "yafgpu_texture.h", "yafgpu_shade_variant.hip", "build.sh")
+
+
+def kernel_key():
+    """identifies the kernels a PMC summary was taken on: a hash over the device sources and the build flags (the GPU box has no .git)"""
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "libyafaray_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    h.update(os.environ.get("YAFGPU_EXTRA_FLAGS", "").encode())
+    return h.hexdigest()[:16]
+
+
+def find_traffic(workload):
+    """the committed rocprofv3 PMC summary of this workload (profiles/<round>_<workload>_traffic.json, written by tools/pmc.sh):
+    -> (doc, stale).  A summary whose `kernel_key` is not the built kernels' is stale: its byte counts are not quoted."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_traffic.json")))
+    if not cands:
+        return None, False
+    key = kernel_key()
+    docs = []
+    for c in cands:
+        try:
+            d = json.load(open(c))
+            d["_file"] = os.path.basename(c)
+            docs.append(d)
+        except Exception:
+            pass
+    for d in reversed(docs):
+        if d.get("kernel_key") == key and d.get("workload", workload) == workload:
+            return d, False
+    return (docs[-1], True) if docs else (None, False)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` on its own: start the N ranks (one process per GPU) with torch.distributed.run as a CHILD, before
+    anything in this process touches the GPU, hand its output through and leave with its exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def make_workload(name, res=None, spp=None, lights=None):
@@ -153,7 +205,13 @@ def main():
                          "(host staging). Exercises sharding + reduce + combine with the real kernels; not a measurement.")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="debug: render shard 0 of K on this one GPU (what one rank of a K-GPU run does per pass); not a measurement of K GPUs")
+    ap.add_argument("--reduce", default="auto", choices=["auto", "rccl", "torch"],
+                    help="film reduce of an N-rank run: 'rccl' = the C ABI's ncclReduce (yafaray_reduceFilm), 'torch' = torch.distributed.reduce, "
+                         "'auto' = rccl, falling back to torch (and saying so) if the communicator cannot be created")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -164,7 +222,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without it (bench.py starts its ranks itself)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.rehearse_one_gpu:
@@ -182,11 +240,34 @@ def main():
     yi = Interface()
     scenes.load_scene(yi, sc, rd)
     yi.setShard(rank, world)            # pixel-tile sharding: tile t -> rank t % world
+    comm, reduce_kind = None, "none"
     if world > 1:
-        # only workloads that consume the reference's serial light counter (several lights: c4) ever call it: a few KB of
+        # the frame's collective: the C ABI's RCCL communicator (yafaray_reduceFilm = ncclReduce over xGMI, csrc/yafaray_reduce.cpp);
+        # torch.distributed only carried the 128-byte id and keeps the barrier / timing reductions.  Every rank takes the same branch.
+        reduce_kind = "torch.distributed"
+        if not args.rehearse_one_gpu and args.reduce in ("auto", "rccl"):
+            from libyafaray_amd.parallel import FilmComm
+            ok = torch.ones(1, device=dev)
+            try:
+                comm = FilmComm.from_process_group(local_rank)
+            except Exception as e:      # noqa: BLE001
+                if args.reduce == "rccl":
+                    raise
+                print(f"[bench] rank {rank}: C-ABI RCCL communicator failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() > 0:
+                reduce_kind = "rccl (C ABI yafaray_reduceFilm; " + comm.backend + ")"
+            elif comm is not None:
+                comm.close()
+                comm = None
+        # only workloads that consume the reference's serial light counter (several lights: c4) ever call the exchange: a few KB of
         # per-tile call counts per pass, so that the ranks make the single-GPU render's light choices
-        from libyafaray_amd.parallel import plane_exchange
-        yi.setPlaneExchange(plane_exchange(dev))
+        if comm is not None:
+            yi.setComm(comm)
+        else:
+            from libyafaray_amd.parallel import plane_exchange
+            yi.setPlaneExchange(plane_exchange(dev))
     if args.emulate_shard > 1 and world == 1:
         yi.setShard(0, args.emulate_shard)
     t0 = time.time()
@@ -207,6 +288,8 @@ def main():
             host = film.cpu()
             reduce_film(host, dst=0)
             film.copy_(host)
+        elif comm is not None:
+            comm.reduce_film(film, dst=0, stream=stream)
         else:
             reduce_film(film, dst=0)
 
@@ -278,14 +361,11 @@ def main():
     # HBM-side bytes per launch of the same kernel come from a rocprofv3 PMC run (FETCH_SIZE / WRITE_SIZE in separate
     # passes, tools/pmc.sh); they cannot be read live, so the committed summary of that run of THIS workload is quoted
     # when it exists (profiles/r02_<workload>_traffic.json; it names its own correction of FETCH_SIZE)
-    traffic, pmc = None, None
-    tpath = os.path.join(ROOT, "profiles", f"r02_{args.workload}_traffic.json")
-    if world == 1 and not args.res and not args.spp and os.path.exists(tpath):
-        try:
-            pmc = json.load(open(tpath))
+    traffic, pmc, pmc_stale = None, None, False
+    if world == 1 and not args.res and not args.spp:
+        pmc, pmc_stale = find_traffic(args.workload)
+        if pmc is not None and not pmc_stale:
             traffic = round(pmc["traffic_bytes_per_launch"])
-        except Exception:
-            traffic, pmc = None, None
     avg_launch_s = trace_ms * 1e-3 / max(trace_launches, 1)
     hbm_measured = (traffic / avg_launch_s / 1e9) if traffic else None
 
@@ -295,13 +375,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "triangles": int(stats0.n_triangles), "width": W, "height": H, "spp": w["spp"],
-                       "bounces": w["bounces"], "lights": w["lights"], "parallelism": f"pixel-tile shard x{world}",
+                       "bounces": w["bounces"], "lights": w["lights"], "parallelism": f"pixel-tile shard x{world}", "film_reduce": reduce_kind,
                        "rays_per_step": rays_total // args.steps, "rays_per_camera_sample": round(rays_total / max(int(c[5]), 1), 3),
                        "kd_nodes": int(stats0.kd_nodes), "kd_leaf_refs": int(stats0.kd_leaf_refs), "kd_max_depth": int(stats0.kd_max_depth),
                        "scene_device_MB": round(stats0.scene_device_bytes / 1e6, 1), "setup_s": round(setup_s, 2),
                        "tree_build_s": round(stats0.tree_build_seconds, 2)},
-            "roofline": {"bound": "hbm", "kernel": "wf_trace (closest-hit + any-hit kd traversal)", "achieved": round(achieved, 2),
+            # `bound` names what limits the kernel (PMC: VALU issue slots ~0.8 busy at < 0.5 lane utilisation, working set cache-resident,
+            # counter-side HBM rate 0.2-0.4 of peak); `achieved` / `peak` / `frac` are nevertheless the bench contract's accounting
+            # against the HBM roofline (`accounting`), with the counter-side figure beside them (`hbm_measured_*`)
+            "roofline": {"bound": "valu-issue (cache-resident)", "accounting": "hbm: SURVEY 8(d) algorithmic bytes / measured launch time over the 8 TB/s HBM peak",
+                         "kernel": "wf_trace (closest-hit + any-hit kd traversal)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "pmc_stale": bool(pmc_stale), "kernel_key": kernel_key(),
+                         "pmc_file": None if pmc is None else pmc.get("_file"),
                          # `achieved` / `frac` follow the bench contract: SURVEY 8(d) ALGORITHMIC bytes / measured launch time.
                          # The memory-side figure is beside it: counter bytes (traffic) / the same launch time.  The scene
                          # (~100 MB at 1M triangles) is L2 / Infinity-Cache resident, so the kernel is bound by vector
@@ -310,7 +396,7 @@ def main():
                          "hbm_measured_GBps": None if hbm_measured is None else round(hbm_measured, 2),
                          "hbm_measured_frac": None if hbm_measured is None else round(hbm_measured / HBM_PEAK_GBS, 5),
                          "limiter": "VALU issue under SIMT divergence (working set cache-resident)",
-                         "pmc": None if pmc is None else {k: pmc[k] for k in ("source", "fetch_correction", "fetch_bytes_per_launch_raw",
+                         "pmc": None if (pmc is None or pmc_stale) else {k: pmc[k] for k in ("source", "fetch_correction", "fetch_bytes_per_launch_raw",
                                                                             "write_bytes_per_launch", "lane_utilisation", "salu_per_valu",
                                                                             "shade") if k in pmc},
                          "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_launch / max(trace_launches, 1)),
@@ -331,6 +417,9 @@ def main():
             out["film_checksum"] = {"sum_rgb": float(f[..., :3].astype(np.float64).sum()), "sum_weight": float(f[..., 4].astype(np.float64).sum()),
                                     "crc": int(np.frombuffer(f.tobytes(), dtype=np.uint32).astype(np.uint64).sum() & 0xffffffff)}
         print(json.dumps(out))
+    if comm is not None:
+        yi.setComm(None)
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -176,6 +176,31 @@ void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count)
  * pass): with it a sharded render of a scene with several lights makes the single-GPU render's light choices; without it, its own. */
 typedef int (*yafaray_plane_exchange_t)(void *user, float *d_values, uint64_t n_floats);
 void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user);
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI, no Python on the data path (yafaray_reduce.cpp) -------------------------
+ * The reference's only multi-machine mechanism sums film files (imagefilm.cc:1467-1557: col += , weight +=); here each rank
+ * renders its tile shard into a full-frame [H][W][5] float film and ONE ncclReduce(sum) assembles the frame on `root`.
+ * Sequence for N ranks: rank 0 yafaray_commGetUniqueId -> the host hands the 128 bytes to every rank (file,
+ * environment, MPI, a socket) -> each rank yafaray_commCreate(id, rank, N, device) -> yafaray_setShard(yi, rank, N) ->
+ * yafaray_setComm(yi, comm) -> render into device memory -> yafaray_reduceFilm.  RCCL is loaded at run time; without it these
+ * functions fail with a message in yafaray_commLastError (there is no host-staged fallback). */
+#define YAFARAY_COMM_ID_BYTES 128
+typedef struct yafaray_comm yafaray_comm_t;
+yafaray_bool_t yafaray_commGetUniqueId(char id[YAFARAY_COMM_ID_BYTES]);
+yafaray_comm_t *yafaray_commCreate(const char id[YAFARAY_COMM_ID_BYTES], int rank, int world, int device);
+void yafaray_commDestroy(yafaray_comm_t *comm);
+int yafaray_commRank(const yafaray_comm_t *comm);
+int yafaray_commWorld(const yafaray_comm_t *comm);
+const char *yafaray_commLastError(void);
+const char *yafaray_commBackend(void);      /* which librccl was bound ("" when none) */
+/* sum of the ranks' device films onto `root`, in place, asynchronously on `stream` (ncclReduce); n_floats = height*width*5 */
+yafaray_bool_t yafaray_reduceFilm(yafaray_comm_t *comm, float *d_film, uint64_t n_floats, int root, void *stream);
+/* sum over all ranks, in place on every rank (ncclAllReduce) */
+yafaray_bool_t yafaray_allReduce(yafaray_comm_t *comm, float *d_values, uint64_t n_floats, void *stream);
+/* the communicator as a yafaray_plane_exchange_t (user = the communicator) */
+int yafaray_commExchange(void *user, float *d_values, uint64_t n_floats);
+/* attach a communicator to an interface: yafaray_setPlaneExchange(yi, yafaray_commExchange, comm); NULL detaches */
+void yafaray_setComm(yafaray_interface_t *yi, yafaray_comm_t *comm);
+
 /* Exact replay of the reference's serial render state (on by default): the per-tile Random that Russian roulette draws from
  * (integrator_tiled.cc:319, seeded from libc rand() as the last Material / ObjectGeometric constructor left it;
  * integrator_path_tracer.cc:282-288) and the estimateOneDirectLight counter (integrator_montecarlo.cc:62-76), both as a

@@ -1338,6 +1338,11 @@ void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t 
 	yi->exchange = fn; yi->exchange_user = user;
 	if(yi->gpu) yafgpu_scene_set_exchange(yi->gpu, fn, user);
 }
+void yafaray_setComm(yafaray_interface_t *yi, yafaray_comm_t *comm)
+{
+	if(comm) yafaray_setPlaneExchange(yi, yafaray_commExchange, comm);
+	else yafaray_setPlaneExchange(yi, nullptr, nullptr);
+}
 void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count) { yi->shard_index = shard_index; yi->shard_count = std::max(1, shard_count); }
 
 // RenderEnvironment::setupScene (environment.cc:679-813) + createImageFilm (:456-584) + Scene::update (scene.cc:784-894)

@@ -67,6 +67,8 @@ C_API_SYMBOLS = [
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
     "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setPlaneExchange", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_setRandState", "yafaray_prepareRender",
     "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
+    "yafaray_commGetUniqueId", "yafaray_commCreate", "yafaray_commDestroy", "yafaray_commRank", "yafaray_commWorld", "yafaray_commLastError",
+    "yafaray_commBackend", "yafaray_reduceFilm", "yafaray_allReduce", "yafaray_commExchange", "yafaray_setComm",
 ]
 GPU_ABI_SYMBOLS = [
     "yafgpu_last_error", "yafgpu_device_count", "yafgpu_set_device", "yafgpu_scene_create", "yafgpu_scene_destroy",
@@ -134,6 +136,10 @@ def load():
         "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
         "yafaray_setProfiling": (ci, [vp, ci]),
         "yafaray_getKernelProfile": (ci, [vp, C.POINTER(cd), C.POINTER(C.c_uint64)]),
+        "yafaray_commGetUniqueId": (ci, [C.c_char_p]), "yafaray_commCreate": (vp, [C.c_char_p, ci, ci, ci]), "yafaray_commDestroy": (None, [vp]),
+        "yafaray_commRank": (ci, [vp]), "yafaray_commWorld": (ci, [vp]), "yafaray_commLastError": (cp, []), "yafaray_commBackend": (cp, []),
+        "yafaray_reduceFilm": (ci, [vp, vp, C.c_uint64, ci, vp]), "yafaray_allReduce": (ci, [vp, vp, C.c_uint64, vp]),
+        "yafaray_commExchange": (ci, [vp, vp, C.c_uint64]), "yafaray_setComm": (None, [vp, vp]),
         "yafgpu_last_error": (cp, []), "yafgpu_device_count": (ci, []), "yafgpu_set_device": (ci, [ci]),
         "yafgpu_planes_bytes": (C.c_uint64, [ci, ci]),
         "yafgpu_film_combine": (ci, [vp, vp, ci, ci, vp]),
@@ -436,6 +442,12 @@ class Interface:
                 return 1
         self._exchange = EXCHANGE(thunk)
         self._L.yafaray_setPlaneExchange(self._h, self._exchange, None)
+
+    def setComm(self, comm):
+        """attach a FilmComm (libyafaray_amd.parallel): plane / light-counter exchanges of a sharded render run over its RCCL
+        communicator inside the library; None detaches"""
+        self._comm = comm
+        self._L.yafaray_setComm(self._h, comm.handle if comm is not None else None)
 
     def setSerialReplay(self, on):
         self._L.yafaray_setSerialReplay(self._h, int(bool(on)))

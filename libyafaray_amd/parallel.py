@@ -5,8 +5,65 @@ of that film (20 MB at 1024^2) to rank 0 assembles the frame — the semantics o
 reference's own film merge (sum colour, sum weight, normalise afterwards: imagefilm.cc:1467-1557).
 A reduce(sum) rather than a gather because a sample near a pixel's right/lower edge also lands on
 the neighbouring pixel (imagefilm.cc:933-936), which may belong to another rank's tile."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import interface as _iface
+
+
+class FilmComm:
+    """The C ABI's RCCL communicator (include/yafaray_c_api.h "multi-GPU", csrc/yafaray_reduce.cpp): what a C/C++ host uses
+    to assemble a sharded frame — ncclReduce(sum) of the [H][W][5] film, no torch on the data path.  This wrapper only moves
+    the 128-byte unique id from rank 0 to the others (here through the process group's store; a C host uses a file, MPI ...)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank, world, device_index, unique_id=None, share=None):
+        L = _iface.load()
+        self._L = L
+        if unique_id is None:
+            buf = C.create_string_buffer(self.ID_BYTES)
+            if rank == 0 and not L.yafaray_commGetUniqueId(buf):
+                raise _iface.YafaRayError("commGetUniqueId: " + L.yafaray_commLastError().decode())
+            unique_id = share(buf.raw if rank == 0 else None) if share is not None else buf.raw
+        self.handle = L.yafaray_commCreate(C.c_char_p(unique_id), rank, world, device_index)
+        if not self.handle:
+            raise _iface.YafaRayError("commCreate: " + L.yafaray_commLastError().decode())
+        self.rank, self.world = rank, world
+
+    @classmethod
+    def from_process_group(cls, device_index):
+        """one communicator over the ranks of torch.distributed's default group; the id travels through its store"""
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def share(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls(rank, world, device_index, share=share)
+
+    @property
+    def backend(self):
+        return self._L.yafaray_commBackend().decode()
+
+    def reduce_film(self, film: torch.Tensor, dst=0, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        if not self._L.yafaray_reduceFilm(self.handle, film.data_ptr(), film.numel(), dst, st):
+            raise _iface.YafaRayError("reduceFilm: " + self._L.yafaray_commLastError().decode())
+        return film
+
+    def all_reduce(self, t: torch.Tensor, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        if not self._L.yafaray_allReduce(self.handle, t.data_ptr(), t.numel(), st):
+            raise _iface.YafaRayError("allReduce: " + self._L.yafaray_commLastError().decode())
+        return t
+
+    def close(self):
+        if self.handle:
+            self._L.yafaray_commDestroy(self.handle)
+            self.handle = None
 
 
 def shard_of_tile(tile_index, world_size):

@@ -106,3 +106,92 @@ def test_sharded_render_with_cross_rank_state_equals_the_single_gpu_render(tmp_p
         interior[::T, :] = False; interior[:, ::T] = False
     assert np.array_equal(got["film"][interior], full[interior])
     np.testing.assert_allclose(got["film"], full, rtol=2.5e-7, atol=1e-7)
+
+
+def test_c4_as_stated_in_eight_shards_equals_the_unsharded_frame():
+    """BASELINE.json configs[4] short of RCCL: the 1M-triangle glossy scene with its TWO area lights, 1024x1024 (2 spp), rendered as the
+    eight shards of an 8-GPU node one after the other on this one GPU.  The ranks' only exchange on this scene — the per-tile call
+    counts of the serial light counter, an all-reduce between the record pass and the final pass — is emulated in-process: a first
+    round of renders collects every rank's contribution (a rank's own table depends on its own tiles only), a second round hands
+    every rank the sum, exactly what ncclAllReduce returns to all of them.  The eight films, summed as yafaray_reduceFilm sums them,
+    must be the unsharded device frame — which test_full_size_c4_two_lights_exact_replay pins to the single-threaded oracle:
+    same ray counts, weights exact, interior pixels bit for bit, tile-border pixels to the rounding of one addition."""
+    import torch
+    import bench
+    from libyafaray_amd import Interface, scenes
+    from libyafaray_amd.parallel import _DeviceFloats
+    WORLD = 8
+    w, sc, rd = bench.make_workload("c4", spp=2)
+    Wd, Hd, T = rd["width"], rd["height"], rd["tile_size"]
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    yi.render()
+    full, st_full = yi.getFilm(Wd, Hd).copy(), yi.getRenderStats()
+    contrib = {}          # (rank, k-th exchange of its render) -> this rank's table
+    state = {"rank": 0, "k": 0, "phase": 0}
+
+    def exchange(ptr, n):
+        t = torch.as_tensor(_DeviceFloats(ptr, n), device=torch.device("cuda", 0))
+        key = state["k"]
+        state["k"] += 1
+        if state["phase"] == 0:
+            contrib[(state["rank"], key)] = t.clone()
+        else:
+            total = sum(contrib[(r, key)] for r in range(WORLD))
+            assert torch.equal(contrib[(state["rank"], key)], t), "a rank's own contribution changed between the rounds"
+            t.copy_(total)
+        torch.cuda.synchronize()
+
+    yi.setPlaneExchange(exchange)
+    parts = []
+    for phase in (0, 1):
+        state["phase"] = phase
+        for r in range(WORLD):
+            state["rank"], state["k"] = r, 0
+            yi.setShard(r, WORLD)
+            yi.render()
+            if phase == 1:
+                parts.append((yi.getFilm(Wd, Hd).copy(), yi.getRenderStats()))
+    assert contrib, "the light-counter exchange never ran"
+    assert sum(p[1].camera_samples for p in parts) == st_full.camera_samples
+    assert (sum(p[1].rays_closest for p in parts), sum(p[1].rays_shadow for p in parts)) == (st_full.rays_closest, st_full.rays_shadow)
+    total = np.zeros_like(full)
+    for f, _ in parts:
+        total = total + f
+    assert np.array_equal(total[..., 4], full[..., 4]), "weights differ"
+    interior = np.ones((Hd, Wd), bool)
+    interior[::T, :] = False; interior[:, ::T] = False
+    assert np.array_equal(total[interior], full[interior]), "interior pixels differ from the unsharded frame"
+    np.testing.assert_allclose(total, full, rtol=2.5e-7, atol=1e-7)
+
+
+def test_rccl_communicator_of_the_c_abi_world_one():
+    """yafaray_commCreate / yafaray_reduceFilm / yafaray_allReduce (csrc/yafaray_reduce.cpp) on the one GPU a box has: a
+    communicator of one rank through real RCCL calls (ncclCommInitRank, ncclReduce, ncclAllReduce in place) leaves the film as it is;
+    attached to an interface (yafaray_setComm) it serves the exchange of a 'sharded' one-rank render."""
+    import torch
+    from libyafaray_amd import Interface, scenes
+    from libyafaray_amd.parallel import FilmComm
+    torch.cuda.set_device(0)
+    comm = FilmComm(0, 1, 0)
+    assert "rccl" in comm.backend
+    film = torch.rand((64, 48, 5), device="cuda")
+    keep = film.clone()
+    comm.reduce_film(film, dst=0)
+    comm.all_reduce(film)
+    torch.cuda.synchronize()
+    assert torch.equal(film, keep)
+    sc = scenes.cornell_soup(600, seed=5, res=(48, 40), n_lights=2)
+    rd = scenes.render_settings(48, 40, 2, bounces=3, tile_size=16)
+    films = []
+    for attach in (False, True):
+        yi = Interface()
+        scenes.load_scene(yi, sc, rd)
+        yi.setRandState(3, 0)
+        if attach:
+            yi.setComm(comm)
+        yi.render()
+        films.append(yi.getFilm(48, 40).copy())
+        yi.setComm(None)
+    assert np.array_equal(films[0], films[1])
+    comm.close()

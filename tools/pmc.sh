@@ -11,9 +11,12 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/pass$i" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$out/pass$i.log" 2>&1 || echo "pass $i failed"
 done
-python3 - "$out" <<'PY'
+wl=m1; prev=""; for a in "$@"; do [ "$prev" = "--workload" ] && wl="$a"; prev="$a"; done
+python3 - "$out" "$wl" <<'PY'
 import csv, glob, sys, collections, re, json
 out = sys.argv[1]
+sys.path.insert(0, ".")
+import bench
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
@@ -39,7 +42,8 @@ def ratios(keys):
 # The traversal reads are 8/16-byte gathers (uncalibrated width): `traffic` is the raw sum, `traffic_fetch_x2` the upper
 # bound with the streaming correction applied to every fetched byte.  The shade kernel's record loads ARE 16 B/lane
 # coalesced streams, so its corrected figure uses the x2.
-doc = {"source": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE,TCC_HIT,TCC_MISS | SQ set 1 | SQ set 2), tools/pmc.sh",
+doc = {"workload": sys.argv[2], "kernel_key": bench.kernel_key(),
+       "source": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE,TCC_HIT,TCC_MISS | SQ set 1 | SQ set 2), tools/pmc.sh",
        "fetch_correction": "wf_trace: none (8/16-B gathers are an uncalibrated width, MI355X_MICROARCH.md HBM section); x2 upper bound in traffic_fetch_x2"}
 tr = [k for k in agg if k.startswith("wf_trace<") and ", false>" in k]
 n = sum(len(launches[k]) for k in tr)

@@ -20,7 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <sstream>
+#include <stdexcept>
 
 #include <zlib.h>
 
@@ -133,6 +135,15 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
 	return true;
 }
 
+// No decoded image may be larger than this many pixels (1 GiB of float4 texels), and none may claim more pixels than its file
+// could hold: headers are checked against the file BEFORE anything is allocated.
+constexpr uint64_t kMaxPixels = 1ull << 26;
+bool size_ok(uint64_t w, uint64_t h, std::string &err, const char *fmt)
+{
+	if(w == 0 || h == 0 || w * h > kMaxPixels) { err = std::string(fmt) + ": image size out of range (at most " + std::to_string(kMaxPixels) + " pixels)"; return false; }
+	return true;
+}
+
 void alloc(Image &img)
 {
 	// an ImageBuffer starts out zeroed (alpha included; Rgba1010108's a_ member starts at 1/255 but every pixel is set)
@@ -168,14 +179,19 @@ bool load_tga(const std::vector<uint8_t> &d, Image &img, std::string &err)
 		if(alpha_bits != 8 && bit_depth == 32) { err = "TGA: invalid alpha depth for a 32-bit image"; return false; }
 	}
 	const bool has_alpha = (alpha_bits != 0 || cm_bits == 32);
+	if(!size_ok((uint64_t)width, (uint64_t)height, err, "TGA")) return false;
+	const size_t bytes_pp = (size_t)((bit_depth + 7) / 8);
+	size_t pos = 18 + (size_t)id_length;
+	if(pos > d.size()) { err = "TGA: file too short"; return false; }
+	// declared pixels against the file: raw data must be there in full; a run-length packet (1 + bytes_pp bytes) yields at most 128 pixels
+	if(!is_rle && pos + (size_t)width * (size_t)height * bytes_pp > d.size()) { err = "TGA: pixel data truncated"; return false; }
+	if(is_rle && (uint64_t)width * (uint64_t)height > (uint64_t)(d.size() - pos) * 128ull) { err = "TGA: the file is too short for the size its header declares"; return false; }
 	img.width = width; img.height = height;
 	int n_channels = 3;
 	if(cm_bits == 16 || cm_bits == 32 || bit_depth == 16 || bit_depth == 32) n_channels = 4;
 	if(img.grayscale) n_channels = 1;
 	img.channels = n_channels; img.has_alpha = has_alpha;
 	alloc(img);
-	const size_t bytes_pp = (size_t)((bit_depth + 7) / 8);
-	size_t pos = 18 + (size_t)id_length;
 	// reading order (:433-455)
 	int min_x = 0, max_x = width, step_x = 1, min_y = 0, max_y = height, step_y = 1;
 	if(!from_top) { min_y = height - 1; max_y = -1; step_y = -1; }
@@ -205,7 +221,6 @@ bool load_tga(const std::vector<uint8_t> &d, Image &img, std::string &err)
 	float c[4];
 	if(!is_rle)
 	{
-		if(pos + (size_t)width * (size_t)height * bytes_pp > d.size()) { err = "TGA: pixel data truncated"; return false; }
 		for(int y = min_y; y != max_y; y += step_y)
 			for(int x = min_x; x != max_x; x += step_x) { decode(&d[pos], c); put(img, x, y, c); pos += bytes_pp; }
 		return true;
@@ -262,6 +277,13 @@ bool load_hdr(const std::vector<uint8_t> &d, Image &img, std::string &err)
 	if(!y_first) { wi = 1; hi = 3; xi = 0; yi = 2; f = 1; s = 0; }
 	const int width = std::atoi(tok[(size_t)wi].c_str()), height = std::atoi(tok[(size_t)hi].c_str());
 	if(width <= 0 || height <= 0) { err = "HDR: bad image size"; return false; }
+	if(!size_ok((uint64_t)width, (uint64_t)height, err, "HDR")) return false;
+	// every scanline takes at least 4 bytes of the file, and an adaptive run-length scanline at least 8 bytes per 127 pixels
+	{
+		const uint64_t rest = (uint64_t)(d.size() - std::min(pos, d.size()));
+		const uint64_t lines = (uint64_t)(y_first ? height : width), per_line = (uint64_t)(y_first ? width : height);
+		if(lines * std::max<uint64_t>(4, (per_line / 127) * 8) > rest + 8) { err = "HDR: the file is too short for the size its header declares"; return false; }
+	}
 	const bool from_left = tok[(size_t)xi].find("+") != std::string::npos, from_top = tok[(size_t)yi].find("-") != std::string::npos;
 	int mn[2], mx[2], st[2];
 	mn[f] = 0; mx[f] = height; st[f] = 1;
@@ -390,6 +412,10 @@ bool load_png(const std::vector<uint8_t> &d, Image &img, std::string &err)
 		default: err = "PNG: colour type not supported"; return false;
 	}
 	if(!(bit_depth == 8 || bit_depth == 16 || ((color_type == 0 || color_type == 3) && (bit_depth == 1 || bit_depth == 2 || bit_depth == 4)))) { err = "PNG: bit depth not supported"; return false; }
+	if(color_type == 3 && bit_depth == 16) { err = "PNG: a palette image cannot be 16 bits deep"; return false; }
+	if(!size_ok(w, h, err, "PNG")) return false;
+	// deflate expands at most ~1032:1: a file whose IDAT cannot inflate to the declared size is refused before anything is allocated
+	if(((uint64_t)w * (uint64_t)src_chan * (uint64_t)bit_depth + 7) / 8 * (uint64_t)h > (uint64_t)idat.size() * 1100ull + 1024ull) { err = "PNG: the file is too short for the size its header declares"; return false; }
 	const size_t bpp_bits = (size_t)src_chan * (size_t)bit_depth;
 	const size_t stride = ((size_t)w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
 	std::vector<uint8_t> raw((stride + 1) * (size_t)h);
@@ -496,7 +522,17 @@ std::string lower_ext(const std::string &path)
 
 } // namespace
 
+static bool load_checked(const std::string &path, Image &img, std::string &err);
+// nothing a damaged file can provoke may leave the library as a C++ exception: this is called from extern "C" entry points
 bool load(const std::string &path, Image &img, std::string &err)
+{
+	try { return load_checked(path, img, err); }
+	catch(const std::bad_alloc &) { err = "out of memory while decoding " + path; }
+	catch(const std::exception &e) { err = std::string("decoding ") + path + " failed: " + e.what(); }
+	img.texels.clear(); img.width = img.height = 0;
+	return false;
+}
+static bool load_checked(const std::string &path, Image &img, std::string &err)
 {
 	const std::string ext = lower_ext(path);
 	std::vector<uint8_t> data;

@@ -135,7 +135,16 @@ const std::string *attr(const Attrs &a, const char *k)
 
 } // namespace
 
+static yafaray_bool_t load_xml_impl(yafaray_interface_t *yi, const char *path);
+// no C++ exception (an allocation a damaged file provokes, a library error) may cross the C boundary
 extern "C" yafaray_bool_t yafaray_loadXml(yafaray_interface_t *yi, const char *path)
+{
+	try { return load_xml_impl(yi, path); }
+	catch(const std::exception &e) { yafaray_internal_set_error(yi, (std::string("loadXml: ") + e.what()).c_str()); }
+	catch(...) { yafaray_internal_set_error(yi, "loadXml: unknown failure"); }
+	return 0;
+}
+static yafaray_bool_t load_xml_impl(yafaray_interface_t *yi, const char *path)
 {
 	if(!yi || !path) return 0;
 	std::string src;

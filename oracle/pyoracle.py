@@ -287,7 +287,7 @@ def lib():
                                      C.POINTER(C.c_int32), fp]
     L.yor_lightmat_emit.argtypes = [C.POINTER(MaterialDesc), fp, fp, C.c_int, fp]
     L.yor_beer_transmittance.argtypes = [fp, C.c_double, C.c_float, C.POINTER(C.c_int32), fp]
-    L.yor_set_trace.argtypes = [fp, C.c_uint64, fp, C.c_uint64]
+    L.yor_set_trace.argtypes = [fp, C.c_uint64, fp, C.c_uint64, C.c_int]
     L.yor_trace_counts.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -548,19 +548,20 @@ class OracleScene:
             raise RuntimeError(f"oracle: unsupported configuration (code {rc})")
         return film, st
 
-    def render_traced(self, render, cap_samples, cap_rays):
-        """single-threaded render with the per-sample / per-query trace on: (film, stats, samples (n, 8), rays (m, 10) with the
-        triangle index as int bits in column 9, total closest-hit queries)"""
+    def render_traced(self, render, cap_samples, cap_rays, with_shadow=False):
+        """single-threaded render with the per-sample / per-query trace on: (film, stats, samples (n, 8), rays (m, 12): from, dir,
+        tmin, tmax, t or -1, the triangle index as int bits, the pixel — with_shadow: any-hit queries too, verdict in column 8 and -2
+        in the triangle column —, total queries recorded)"""
         L = lib()
         samples = np.zeros((max(1, cap_samples), 8), dtype=np.float32)
-        rays = np.zeros((max(1, cap_rays), 10), dtype=np.float32)
-        L.yor_set_trace(fptr(samples), cap_samples, fptr(rays), cap_rays)
+        rays = np.zeros((max(1, cap_rays), 12), dtype=np.float32)
+        L.yor_set_trace(fptr(samples), cap_samples, fptr(rays), cap_rays, int(with_shadow))
         try:
             film, st = self.render(dict(render, oracle_threads=1))
             ns, nr = C.c_uint64(), C.c_uint64()
             L.yor_trace_counts(C.byref(ns), C.byref(nr))
         finally:
-            L.yor_set_trace(None, 0, None, 0)
+            L.yor_set_trace(None, 0, None, 0, 0)
         return film, st, samples[:min(ns.value, cap_samples)], rays[:min(nr.value, cap_rays)], nr.value
 
     def set_tree(self, nodes, refs, bound6):

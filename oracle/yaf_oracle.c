@@ -979,6 +979,8 @@ static FILE *g_ray_log = NULL;
 /* test hook (yor_set_trace): the samples renderTile hands to addSample and the closest-hit queries, in call order (single-threaded renders) */
 static float *g_trace_samples = NULL, *g_trace_rays = NULL;
 static uint64_t g_trace_samples_cap = 0, g_trace_rays_cap = 0, g_trace_n_samples = 0, g_trace_n_rays = 0;
+static float g_trace_px = 0.f, g_trace_py = 0.f;      /* the pixel renderTile is at */
+static int g_trace_shadow = 0;
 static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, float *tmax, sp_t *sp, counters_t *cn)
 {
 	float dis, z, bu = 0, bv = 0; int ti = -1;
@@ -996,9 +998,10 @@ static int scene_intersect(const yor_scene *s, v3 from, v3 dir, float tmin, floa
 	{
 		if(g_trace_n_rays < g_trace_rays_cap)
 		{
-			float *rec = g_trace_rays + 10 * g_trace_n_rays;
+			float *rec = g_trace_rays + 12 * g_trace_n_rays;
 			rec[0] = from.x; rec[1] = from.y; rec[2] = from.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z; rec[6] = tmin; rec[7] = *tmax; rec[8] = got ? z : -1.f;
 			int32_t tri = got ? ti : -1; memcpy(&rec[9], &tri, 4);
+			rec[10] = g_trace_px; rec[11] = g_trace_py;
 		}
 		++g_trace_n_rays;
 	}
@@ -1017,7 +1020,19 @@ static int scene_is_shadowed(const yor_scene *s, v3 from, v3 dir, float tmin, fl
 	if(tmax < 0) dis = INFINITY;
 	else dis = tmax - 2 * tmin;
 	if(cn) cn->rays_shadow++;
-	return kd_intersect_s(s, sfrom, dir, dis, cn);
+	const int verdict = kd_intersect_s(s, sfrom, dir, dis, cn);
+	if(g_trace_rays && g_trace_shadow)
+	{	/* any-hit queries in the same stream: the caller's ray, the verdict in slot 8, -2 in the triangle slot */
+		if(g_trace_n_rays < g_trace_rays_cap)
+		{
+			float *rec = g_trace_rays + 12 * g_trace_n_rays;
+			rec[0] = from.x; rec[1] = from.y; rec[2] = from.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z; rec[6] = tmin; rec[7] = tmax; rec[8] = (float)verdict;
+			int32_t tri = -2; memcpy(&rec[9], &tri, 4);
+			rec[10] = g_trace_px; rec[11] = g_trace_py;
+		}
+		++g_trace_n_rays;
+	}
+	return verdict;
 }
 
 /* Scene::isShadowed with transparent shadows, scene.cc:996-1035: filt = product of the transparencies passed */
@@ -3717,6 +3732,7 @@ static void render_tile(worker_t *wk, int tx, int ty, rstate_t *st)
 				camera_shoot_lens(cam, j + dx, i + dy, lens_u, lens_v, &from, &dir, &tmin, &tmax, &wt);
 				wk->camera_samples++;
 				float c[4];
+				g_trace_px = (float)j; g_trace_py = (float)i;
 				integrate(st, from, dir, tmin, tmax, 0, c, NULL);
 				if(c[3] > 1.f) c[3] = 1.f;                 /* :459 */
 				c[0] *= wt; c[1] *= wt; c[2] *= wt; c[3] *= wt; /* :512 */
@@ -4016,12 +4032,14 @@ int yor_render(yor_scene *s, const yor_render_desc *rd, float *film_out, yor_sta
 }
 
 /* test hook: record what renderTile hands to ImageFilm::addSample (8 floats per sample: x, y, dx, dy, r, g, b, a) and every closest-hit
- * query (10 floats: from, dir, tmin, tmax, t or -1, triangle index as int bits), in call order.  Only meaningful for n_threads = 1.
+ * query (12 floats: from, dir, tmin, tmax, t or -1, triangle index as int bits, the pixel being rendered), in call order; with_shadow:
+ * the plain any-hit queries too (the caller's ray, the verdict in slot 8, -2 in the triangle slot).  Only meaningful for n_threads = 1.
  * NULL pointers switch it off.  yor_trace_counts reports how many of each the last renders produced (may exceed the capacities). */
-void yor_set_trace(float *samples8, uint64_t cap_samples, float *rays10, uint64_t cap_rays)
+void yor_set_trace(float *samples8, uint64_t cap_samples, float *rays12, uint64_t cap_rays, int with_shadow)
 {
 	g_trace_samples = samples8; g_trace_samples_cap = cap_samples; g_trace_n_samples = 0;
-	g_trace_rays = rays10; g_trace_rays_cap = cap_rays; g_trace_n_rays = 0;
+	g_trace_rays = rays12; g_trace_rays_cap = cap_rays; g_trace_n_rays = 0;
+	g_trace_shadow = with_shadow;
 }
 void yor_trace_counts(uint64_t *n_samples, uint64_t *n_rays) { if(n_samples) *n_samples = g_trace_n_samples; if(n_rays) *n_rays = g_trace_n_rays; }
 

@@ -256,8 +256,9 @@ void yor_nodes_probe(int32_t n_nodes, const yor_node_desc *nodes, int32_t n_text
 int yor_render(yor_scene *s, const yor_render_desc *rd, float *film, yor_stats *stats);
 
 /* test hook: record the samples renderTile hands to addSample (8 floats each: x, y, dx, dy, r, g, b, a) and every closest-hit query
- * (10 floats: from, dir, tmin, tmax, t or -1, triangle index as int bits) in call order; single-threaded renders only; NULL = off */
-void yor_set_trace(float *samples8, uint64_t cap_samples, float *rays10, uint64_t cap_rays);
+ * (12 floats: from, dir, tmin, tmax, t or -1, triangle index as int bits, pixel x, y) in call order — with_shadow: plain any-hit queries
+ * too (verdict in slot 8, triangle slot -2); single-threaded renders only; NULL = off */
+void yor_set_trace(float *samples8, uint64_t cap_samples, float *rays12, uint64_t cap_rays, int with_shadow);
 void yor_trace_counts(uint64_t *n_samples, uint64_t *n_rays);
 
 /* Replace the oracle's own kd-tree by an externally built one in the same 8-byte node layout

@@ -29,9 +29,10 @@ def compare_films(gpu_film, ora_film, what, max_outliers=0, exact_weights=True):
     return n_bad, exact
 
 
-@pytest.fixture(params=["wavefront", "megakernel"], autouse=True)
+@pytest.fixture(params=["wavefront"], autouse=True)
 def pipeline(request, monkeypatch):
-    """Both device pipelines (queue-per-stage wavefront, one-kernel persistent) must give the same film."""
+    """The wavefront pipeline is the product.  The one-kernel pipeline (render_kernel, YAFGPU_PIPELINE=megakernel) is kept as ONE
+    cross-check — test_pipelines_are_bit_identical — on the single-pass pinhole diffuse / glossy subset it renders."""
     monkeypatch.setenv("YAFGPU_PIPELINE", request.param)
     return request.param
 
@@ -1313,24 +1314,76 @@ def test_random_feature_mixes_with_serial_state(seed, pipeline):
         pytest.skip("the replay belongs to the wavefront pipeline")
     sc, rd, w, h, base, kw = _feature_mix(seed, serial=True)
     what = f"serial feature mix {seed}: {[m['type'] for m in sc['materials'][base:]]} {kw}"
-    firsts = []
+    evidence = []
     for same_tree in (True, False):      # (exact-distance ties resolve by tree topology: see assert_matches_an_oracle_render)
         film, st, ofilm, ost = _render_with_rand_state(sc, rd, same_tree=same_tree)
         if (st.camera_samples, st.rays_closest, st.rays_shadow) == (ost.camera_samples, ost.rays_closest, ost.rays_shadow):
             wide = rd.get("filter_type", "box") != "box" or rd.get("AA_pixelwidth", 1.0) > 1.002      # (splats from several tiles: the plane sums round in another order)
             compare_films(film, ofilm, what, exact_weights=not wide)
             return
-        # where, in the reference's tile order, the two renders part
-        ys, xs = np.nonzero(~np.isclose(film, ofilm, rtol=1e-4, atol=1e-6).all(axis=-1))
-        ts = rd.get("tile_size", 32)
-        order = np.lexsort((xs, ys, xs // ts, ys // ts))
-        firsts.append((int(xs[order[0]]), int(ys[order[0]])) if len(order) else None)
-    # With serial state ONE sample that resolves an exact-distance tie the other way (a camera ray into the edge two walls share)
-    # shifts the light counter of every sample after it.  Each tree has its own such pixels; a scene that has them in both trees
-    # cannot be checked this way — told apart from a device error by where the renders part: at another pixel per tree.
-    if firsts[0] is not None and firsts[1] is not None and firsts[0] != firsts[1]:
-        pytest.skip(f"{what}: tie artefacts with both trees (the renders part at {firsts[0]} / {firsts[1]})")
-    raise AssertionError(f"{what}: differs from the single-threaded oracle with either tree, from the same pixel on: {firsts}")
+        # With serial state ONE query that a tree answers otherwise than the geometry does — an exact-distance tie between two
+        # triangles resolved by visiting order, or a leaf the reference's walk skips over a foreign tree — shifts the light counter of
+        # every sample after it.  That is the only exemption, and it has to be SHOWN: the oracle's first query (in render order) whose
+        # answer over this tree differs from brute force over all triangles must be such a tie or skip, and the renders must not part
+        # before the pixel it belongs to.
+        evidence.append(_first_tree_artefact(sc, rd, same_tree, film, ofilm))
+    for ev in evidence:
+        assert ev["kind"] in ("tie", "skip", "shadow-skip"), f"{what}: differs from the single-threaded oracle and no tie explains it: {evidence}"
+        assert ev["parts_at_or_after_the_query"], f"{what}: the renders part BEFORE the first tie / skip: {evidence}"
+    print(f"{what}: exempt — every oracle tree has a shown artefact before the renders part: {evidence}")
+
+
+def _first_tree_artefact(sc, rd, same_tree, film, ofilm):
+    """the oracle's first ray query whose kd-tree answer differs from brute force, what kind of difference it is, and whether the
+    device film and the oracle film agree on every pixel rendered before it (tile order = the reference's render order)"""
+    yi = Interface()
+    scenes.load_scene(yi, sc, rd)
+    seed, skip = yi.getRandState()
+    osc = po.OracleScene(sc)
+    if same_tree:
+        osc.set_tree(*interface.build_kdtree(sc["verts"], threads=4, device=DEVICE_TREE)[:3])
+    cap = 4_000_000
+    _, _, _, rays, n = osc.render_traced(dict(rd, rand_srand=seed, rand_skip=skip), 1, cap, with_shadow=True)
+    assert n <= cap, "ray trace capacity"
+    tris = rays[:, 9].view(np.int32)
+    found = None
+    for i in range(len(rays)):
+        f, d, tmin, tmax = rays[i, :3], rays[i, 3:6], float(rays[i, 6]), float(rays[i, 7])
+        if tris[i] == -2:
+            if bool(osc.is_shadowed(f, d, tmin, tmax, use_tree=False)) != bool(rays[i, 8]):
+                found = dict(kind="shadow-skip" if not rays[i, 8] else "shadow-extra", query=i)
+        else:
+            h, bt, t, _ = osc.intersect(f, d, tmin, tmax, use_tree=False)
+            tree_hit = tris[i] >= 0
+            if bool(h) != tree_hit or (h and (bt != tris[i] or np.float32(t) != rays[i, 8])):
+                if h and tree_hit and np.float32(t) == rays[i, 8] and bt != tris[i]:
+                    kind = "tie"            # two triangles answer the same distance: visiting order decides (kdtree_triangle.cc:782,806)
+                elif h and (not tree_hit or rays[i, 8] > np.float32(t)):
+                    kind = "skip"           # the walk passed over the leaf that holds the nearer hit (kdtree_triangle.cc:725-750)
+                else:
+                    kind = "other"
+                found = dict(kind=kind, query=i, tree=(int(tris[i]), float(rays[i, 8])), brute=(int(bt) if h else -1, float(t) if h else -1.0))
+        if found:
+            found["pixel"] = (int(rays[i, 10]), int(rays[i, 11]))
+            break
+    if not found:
+        return dict(kind="none", parts_at_or_after_the_query=False)
+    # pixels in the reference's render order (tiles row-major, pixels row-major inside a tile); multi-pass renders revisit pixels,
+    # so "before" is decided on the first pass's order: a pixel rendered before the query's pixel in EVERY pass
+    ts = rd.get("tile_size", 32)
+    ys, xs = np.nonzero(~np.isclose(film, ofilm, rtol=1e-4, atol=1e-6).all(axis=-1))
+    x0, y0 = found["pixel"]
+    x00, y00 = rd.get("xstart", 0), rd.get("ystart", 0)
+
+    def key(x, y):
+        return ((y - y00) // ts, (x - x00) // ts, y, x)
+    k0 = key(x0, y0)
+    early = [(int(x), int(y)) for x, y in zip(xs + x00, ys + y00) if key(int(x), int(y)) < k0]
+    if rd.get("AA_passes", 1) > 1:
+        early = []      # a later pass re-renders earlier pixels after the query: order alone cannot separate them
+    found["parts_at_or_after_the_query"] = not early
+    found["pixels_differing_before_it"] = early[:4]
+    return found
 
 
 @pytest.mark.parametrize("seed", [3, 14, 25, 36, 47, 58, 69, 80])

@@ -49,6 +49,16 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 #define YAFGPU_WAVES 4                // __launch_bounds__ min waves/SIMD of the render kernel (C2 measured: 1:368 2:667 3:781 4:793 Mrays/s)
 #endif
 constexpr int kStack = YAFGPU_STACK;  // per-lane LDS stack slots (power of two)
+// Top of the tree apart (north_star: "LDS-staged node tiles"; measured in profiles/r03_ab_toptree.txt).  0: off.  1: the first kTopDepth levels
+// are walked in a heap-ordered copy (DevScene::top) that stays resident in the vector L1.  2: that copy is staged into LDS by every workgroup.
+#ifndef YAFGPU_TRACE_TOP
+#define YAFGPU_TRACE_TOP 0
+#endif
+#ifndef YAFGPU_TOP_DEPTH
+#define YAFGPU_TOP_DEPTH 10
+#endif
+constexpr int kTopDepth = YAFGPU_TOP_DEPTH, kTopN = (1 << kTopDepth) - 1, kTopBottom = (1 << (kTopDepth - 1)) - 1;      // entries; first entry of the last level
+constexpr uint32_t kTopTag = 0x80000000u;      // a node id with this bit is a heap index into the top copy
 constexpr int kDepthCap = 48;         // host tree depth cap; deeper pending lists restart
 constexpr int kQueues = 8;            // one per XCD
 constexpr float kMinRayDist = (float)0.00005;   // MIN_RAYDIST, CMakeLists.txt:46-48
@@ -63,6 +73,8 @@ struct DevScene
 	const uint2 *nodes_blk;      // the same tree in 64-B blocks of three levels (YAFGPU_TRACE_BLOCKS): node id = block * 8 + slot, slot s < 3 has its
 	                             // children in slots 2s + 1, 2s + 2; a node in slots 3..6 keeps (in the child field) the block of its left child, the right
 	                             // child's block is the next one; both children sit in their blocks' slot 0.  Or nullptr.
+	const uint4 *top;            // YAFGPU_TRACE_TOP: the tree's first kTopDepth levels in heap order (children of entry h at 2h + 1, 2h + 2):
+	                             // (split, flags as in `nodes`, the node's own index in `nodes`, 0); entries no node maps to are empty leaves.  Or nullptr.
 	const uint32_t *refs;        // leaf references
 	const float4 *tri;           // 3 x float4 per triangle: (a, eps) (e1, mat|vis<<30) (e2, 0)
 	const float4 *tri_ng;        // geometric normal + smooth flag
@@ -1346,6 +1358,26 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		dv.nodes2 = d_pairs;
 	}
 #endif
+	dv.top = nullptr;
+#if YAFGPU_TRACE_TOP
+	if(!s->tree.nodes.empty())
+	{	// the top of the tree once more, in heap order: every ray's first steps touch these few nodes (a breadth-first prefix is 128
+		// cache lines at depth 10; in the depth-first array the same nodes are spread over as many lines as there are left spines)
+		const std::vector<KdNode> &tn = s->tree.nodes;
+		std::vector<uint4> top((size_t)kTopN, make_uint4(0u, 3u, 0u, 0u));
+		std::vector<std::pair<uint32_t, uint32_t>> todo;      // (index in the depth-first array, heap index)
+		todo.emplace_back(0u, 0u);
+		while(!todo.empty())
+		{
+			const auto [g, h] = todo.back(); todo.pop_back();
+			const uint2 nd = *(const uint2 *)&tn[g];
+			top[h] = make_uint4(nd.x, nd.y, g, 0u);
+			if((nd.y & 3u) != 3u && 2u * h + 2u < (uint32_t)kTopN) { todo.emplace_back(nd.y >> 2, 2u * h + 2u); todo.emplace_back(g + 1u, 2u * h + 1u); }
+		}
+		if(tn.size() >= kTopTag) { yafgpu_scene_destroy(s); return fail(-2, "kd-tree too large for tagged node indices"); }
+		if((rc = upload(s, top.data(), top.size(), &dv.top))) { yafgpu_scene_destroy(s); return rc; }
+	}
+#endif
 	dv.nodes_blk = nullptr;
 #if YAFGPU_TRACE_BLOCKS
 	if(!s->tree.nodes.empty())
@@ -1915,7 +1947,14 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	// ... except for small chunks (a tile shard of a multi-GPU render, a small frame): with a few rays per lane a persistent
 	// launch is mostly tail, and the two traversal launches of an iteration side by side are worth +5 % at half the metric
 	// frame, +8 % at a quarter, +12 % at an eighth (bench.py --emulate-shard).  YAFGPU_OVERLAP=0 / 1 force either.
+	// ... and always since a path parks its next segment beside a vertex's last shadow pair (WfArgs::speculate): the middle phases of a
+	// pass then have BOTH queues full, and the two launches side by side are worth +2 % on the whole metric frame too (profiles/r03_ab_speculate.txt).
+	// The per-kernel durations of the roofline come from the profiled pass, which keeps one kernel on the GPU at a time either way.
 	bool overlap = (uint64_t)cap_pixels * spp < (12ull << 20);
+	{
+		const char *sp = std::getenv("YAFGPU_SPECULATE");
+		if(!(sp && std::atoi(sp) == 0)) overlap = true;
+	}
 	if(const char *e = std::getenv("YAFGPU_OVERLAP")) overlap = std::atoi(e) != 0;
 	if(overlap && !s->side_stream)
 	{
@@ -1954,6 +1993,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		a.ev_flags = s->rp_flags; a.ev_p = s->rp_p; a.ev_kill = s->rp_kill; a.ev_calls = s->rp_calls; a.lc_base = s->rp_base;
 		a.replay_lights = replay_lights ? 1 : 0; a.ev_m = (int)ev_m;
+		a.speculate = 1;      // the next segment beside a vertex's last shadow pair (WfArgs::speculate); YAFGPU_SPECULATE=0: the sequential phases
+		if(const char *e = std::getenv("YAFGPU_SPECULATE")) a.speculate = std::atoi(e) != 0 ? 1 : 0;
 		a.hit_cache = use_hits ? s->rp_hits : nullptr; a.hit_k = (int)hit_k;
 		const size_t cp = s->wf_cap;
 		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},

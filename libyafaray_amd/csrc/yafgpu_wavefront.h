@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 26;   // float4 records of parked state per path (416 B; 22 and 23 are only touched in textured scenes, 24 and 25 only with bump mapping)
+constexpr int kWfRecs = 28;   // float4 records of parked state per path (448 B; 22 and 23 are only touched in textured scenes, 24 and 25 only with bump mapping, 26 and 27 by a path that parks its next segment beside a vertex's last shadow pair)
 
 struct WfArgs
 {
@@ -63,12 +63,18 @@ struct WfArgs
 	uint8_t *ev_kill;                 // [path * P + path_sample]: depth of the test that kills it (255: none)
 	uint8_t *ev_calls;                // [path * P + path_sample]: light calls it makes (up to the kill)
 	uint32_t *lc_base;                // [path]: correlative_sample_number_ when the sample starts
+	// Next segment beside the last shadow pair (DESIGN.md "fewer phases per vertex"): a vertex's continuation ray does not depend on its
+	// shadow answers (the roulette test reads the throughput, the sampler the vertex), so a path that is about to park for the LAST shadow
+	// pair of a vertex's light estimate samples the next segment right away and parks for both: one traversal phase, one state round trip
+	// and one launch tail less per vertex.  Only where nothing in between can change course: no recursion frames, and a roulette test at
+	// this vertex only when the serial-state replay has its outcome on the table.  0: off (comparison runs, YAFGPU_SPECULATE=0).
+	int speculate;
 	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
 
-enum : int { kPcAfterClosest = 1, kPcAfterShadow = 2 };
-enum : int { kReqDone = 0, kReqClosest = 1, kReqShadow = 2 };
+enum : int { kPcAfterClosest = 1, kPcAfterShadow = 2, kPcAfterBoth = 3 };      // Both: the shadow pair of a vertex AND the next segment's closest hit are out
+enum : int { kReqDone = 0, kReqClosest = 1, kReqShadow = 2, kReqBoth = 3 };
 
 YG_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 YG_DEV float4 f4(Col c, float w) { return make_float4(c.r, c.g, c.b, w); }
@@ -270,7 +276,7 @@ YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
 
 enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECURSE, W_RETURN, W_EXTEND, W_START_PATH, W_FINISH, W_PARK_CLOSEST, W_PARK_SHADOW,
-       W_GLOSSY_NEXT, W_RECURSE_SPEC };
+       W_GLOSSY_NEXT, W_RECURSE_SPEC, W_PARK_BOTH, W_NEXT_VERTEX };
 
 // register-resident copies of records 11, 12, 14, 18 (and, with YAFGPU_HOT_ACC, the accumulators 15..17) during
 // one advance (see wf_advance); the other records of the 11..18 range go straight to memory
@@ -436,7 +442,8 @@ YG_DEV uint32_t wf_hit_key(const WfArgs &a, uint32_t slot, uint32_t ctl, uint32_
 }
 
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
-YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal, const float4 ans)
+// beside: the segment was parked beside the previous vertex's shadow pair — its direction is in record 26, its origin the vertex in record 0
+YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t ordinal, const float4 ans, bool beside)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int tri = (int)ubits(ans.x);
@@ -494,7 +501,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		return W_DL_DONE;
 	}
 	if(!got) { ++c.path_i; return W_START_PATH; }                                              // :218 / :259-266
-	const float4 r0 = REC(0), r1 = REC(1);
+	const float4 r0 = REC(0), r1 = beside ? REC(26) : REC(1);
 	const V3 dir = v3(r1);
 	SurfPt hit;
 	get_surface(sc, tri, v3(r0) + dir * ans.y, ans.z, ans.w, hit);
@@ -653,7 +660,8 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 }
 
 // the light estimate of the current vertex is complete: book it and decide how the path goes on
-YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
+// beside: the next segment was sampled and parked together with this vertex's last shadow pair (st_beside): its answer is in too
+YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool beside)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const Col total = c3(HGET(18));
@@ -666,6 +674,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 		const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
 		if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) return W_RECURSE;
 		c.path_i = 0;
+		if(beside) { c.stage = kStFirst; return W_NEXT_VERTEX; }      // st_start_path's work was done by st_beside
 		return W_START_PATH;
 	}
 	const yafgpu_material &pm_rec = sc.mats[(int)ubits(REC(7).w)];
@@ -696,6 +705,12 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 		path_col = path_col + lcol * throughput;                                                // :228
 		HSET(12, f4(path_col, r12.w));
 		c.depth = 1;
+		if(beside)
+		{	// st_extend's work was done by st_beside: throughput *= scol (:251)
+			HSET(11, f4(throughput * c3(REC(27)), r11.w));
+			c.stage = kStDepth;
+			return W_NEXT_VERTEX;
+		}
 		if(c.depth < rp.bounces) return W_EXTEND;
 		++c.path_i;
 		return W_START_PATH;
@@ -729,6 +744,12 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	{
 		path_col = path_col + lcol * throughput;                                                // :292
 		++c.depth;
+	}
+	if(beside)
+	{	// (no roulette test at this vertex, or st_beside would not have gone ahead)  throughput *= scol (:251)
+		HSET(11, f4(throughput * c3(REC(27)), r11.w)); HSET(12, f4(path_col, r12.w));
+		c.stage = kStDepth;
+		return W_NEXT_VERTEX;
 	}
 	HSET(11, f4(throughput, r11.w)); HSET(12, f4(path_col, r12.w));
 	if(alive && c.depth < rp.bounces) return W_EXTEND;
@@ -810,6 +831,90 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	REC(0) = f4(sp0.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
 	c.stage = kStFirst;
 	return W_PARK_CLOSEST;
+}
+
+// The path is about to park for a shadow pair.  If it is the LAST pair of this vertex's light estimate and the path goes on from here
+// whatever the answers are, take the next segment now — st_start_path's sample from the camera hit, or st_extend's from the path
+// vertex — and park for both (WfArgs::speculate).  Everything written here is what those steps would write after the answers, except
+// what the pending estimate still reads: the ray goes to record 26 (records 0 / 1 hold the shadow ray), st_extend's colour to
+// record 27 (record 11 must keep the throughput the estimate is booked with), and the control word's stage is advanced on resume.
+YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal)
+{
+	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
+	if(!a.speculate || a.replay == 1 || a.frames != 0 || rp.integrator != YAFGPU_INTEGRATOR_PATH) return W_PARK_SHADOW;      // (a record pass has no shadow parks anyway)
+	{	// the last pair of the estimate?
+		const uint32_t w14 = ubits(HGET(14).w);
+		const int li = (int)(w14 & 0xffu), l_end = (int)((w14 >> 8) & 0xffu), is = (int)(w14 >> 20);
+		if(li + 1 != l_end) return W_PARK_SHADOW;
+		const yafgpu_light &light = sc.lights[li];
+		if(light.type != YAFGPU_LIGHT_POINT && is + 1 != dl_area_samples(ra, light, 1)) return W_PARK_SHADOW;
+	}
+	if(c.stage == kStPrimary)
+	{	// st_dl_done will go to st_start_path(path_i = 0): :186-216
+		const float4 r5 = REC(5);
+		const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
+		if(!(ubits(r5.w) & path_flags)) return W_PARK_SHADOW;
+		c.incl = 0;
+		const float4 p = REC(3);
+		SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(r5), (int)ubits(p.w), sp0);
+		wf_frame_parked(a, slot, 0, sp0);
+		const float4 r6 = REC(6);
+		const V3 wo0 = v3(r6);
+		yafgpu_material m_tmp;
+		const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
+		BsdfDat dat0; mat_init_bsdf(m, dat0);
+		const uint32_t offs = (uint32_t)rp.path_samples * pixel_sample + sampling_offs;
+		BsdfSample bs;
+		bs.s_1 = ri_vdc(offs, 0u);
+		bs.s_2 = (float)scr_halton(sc, 2, offs);
+		bs.pdf = 0.f; bs.sampled = kNone;
+		bs.flags = path_flags | kDiffuse | kReflect | kTransmit;
+		float w = r6.w;
+		V3 p_dir = mk(0.f, 0.f, 0.f);
+		const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
+		REC(6).w = w;
+		if(bs.sampled == kNone || !YAFGPU_ACC_ZERO_FLAG) REC(10) = f4(wo0, 0.f);
+		Mwc rr; rr.init(fnv32a(ordinal) + 123u);
+		HSET(11, f4(scol, fbits(rr.x)));
+		HSET(12, make_float4(0.f, 0.f, 0.f, fbits(rr.c)));
+		float4 misc = REC(19);
+		misc.x = fbits(offs); misc.y = fbits(bs.sampled);
+		REC(19) = misc;
+		REC(26) = f4(p_dir, ra.ray_min_dist);
+		return W_PARK_BOTH;
+	}
+	// st_dl_done will book the estimate and go to st_extend: only if no roulette test stands in between and a bounce is left
+	const int next_depth = c.stage == kStFirst ? 1 : c.depth + 1;
+	if(next_depth >= rp.bounces) return W_PARK_SHADOW;
+	if(c.stage == kStDepth && c.depth > rp.rr_min_bounces)
+	{	// a roulette test stands between the estimate and the next segment (:282-288).  With the serial-state replay its outcome is
+		// already on the table (ev_kill, from the tile's stream); a per-sample stream would have to be drawn from here: no shortcut then
+		if(a.replay != 2) return W_PARK_SHADOW;
+		const uint32_t e = wf_event(a, slot, a.ev_m > 1 ? ubits(REC(19).z) : 0u, c.path_i);
+		if((int)a.ev_kill[e] == c.depth) return W_PARK_SHADOW;
+	}
+	const float4 p = REC(7);
+	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
+	wf_frame_parked(a, slot, 1, hit);
+	const float4 r10 = REC(10);
+	const V3 pwo = v3(r10);
+	yafgpu_material pm_tmp;
+	const yafgpu_material &pm = wf_mat_parked(a, slot, 1, hit, pm_tmp);
+	BsdfDat dat_n; mat_init_bsdf(pm, dat_n);
+	const uint32_t offs = ubits(REC(19).x);
+	const int d_4 = 4 * next_depth;
+	BsdfSample bs;
+	bs.s_1 = (float)scr_halton(sc, d_4 + 3, offs);
+	bs.s_2 = (float)scr_halton(sc, d_4 + 4, offs);
+	bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kAll;
+	float w = REC(6).w;
+	V3 p_dir = mk(REC(8).w, REC(9).w, r10.w);
+	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
+	if(is_black(scol)) return W_PARK_SHADOW;          // the path sample ends here (:249): nothing was written, st_extend finds it again
+	REC(6).w = w;
+	REC(26) = f4(p_dir, ra.ray_min_dist);
+	REC(27) = f4(scol, 0.f);
+	return W_PARK_BOTH;
 }
 
 // recursiveRaytrace, integrator_montecarlo.cc:782-1028 — the perfect specular branch (:971-1025): the level's own
@@ -1002,7 +1107,8 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, const float4 ans, float result[4], int &out_mask)
 {
 	Ctl c = load_ctl(a, slot);
-	int where = (c.pc == kPcAfterShadow) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
+	const bool beside = c.pc == kPcAfterBoth;        // the shadow pair of a vertex and the next segment's closest hit came back together
+	int where = (c.pc == kPcAfterShadow || beside) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
 	// The records the light-estimate bookkeeping passes from step to step (throughput, path colour, the estimate
 	// in flight and its accumulators) live in registers for the duration of the advance: a resumed shadow answer
 	// loads them in ONE round of loads instead of one dependent round per step (each step used to re-read what the
@@ -1021,14 +1127,26 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
 	// order (a dispatch loop makes the optimizer thread the transitions, duplicate the steps and keep the union
 	// of their registers alive: 163 VGPRs against 81 for the widest single step).
-	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal, ans);
+	// ... with one exception.  A path that parked its next segment beside a vertex's LAST shadow pair (st_beside) first closes that
+	// estimate — the small steps, a second time, ahead of everything: the answers, the one light still open, the booking — and then
+	// runs the vertex steps below for the segment's hit.  (A second turn through the big steps instead, as a loop or by calling the
+	// program again, made the optimizer keep the union of their registers alive: 65-90 spilled VGPRs.)
+	if(beside)
+	{
+		where = st_after_shadow(a, slot, h, verdict);
+		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);       // closes the light: st_beside only goes ahead at the last pair
+		if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c, true);
+		if(where == W_NEXT_VERTEX) where = W_AFTER_CLOSEST;
+	}
+	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal, ans, beside);
 	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
 	while(where == W_DL_NEXT || where == W_DL_EVAL)
 	{
 		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
 		else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
 	}
-	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c);
+	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c, false);
+	if(where == W_PARK_SHADOW) where = st_beside(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
 	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_RECURSE) where = st_recurse(a, slot, c);
@@ -1048,6 +1166,7 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	if(where != W_FINISH) hot_flush(a, slot, h, where == W_PARK_CLOSEST);      // a path that ends needs none of them again
 	if(where == W_PARK_CLOSEST) { c.pc = kPcAfterClosest; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqClosest; }
 	if(where == W_PARK_SHADOW) { c.pc = kPcAfterShadow; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqShadow; }
+	if(where == W_PARK_BOTH) { c.pc = kPcAfterBoth; REC(13) = f4(c.col, fbits(pack_ctl(c))); return kReqBoth; }
 	// W_FINISH
 	if(a.ra.rp.bg_transp) alpha = smax(alpha, 0.f);   // EmptyVolumeIntegrator: transmittance 1 (integrator_empty_volume.cc:32-38)
 	result[0] = c.col.r; result[1] = c.col.g; result[2] = c.col.b; result[3] = alpha;
@@ -1068,11 +1187,11 @@ __global__ __launch_bounds__(kBlock, PROBE_WAVES) void probe_advance(const WfArg
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; Ctl c = load_ctl(a, slot); int m = 0; (void)m; \
 	Hot h; hot_preload(a, slot, h, true); const int w = call; hot_flush(a, slot, h, false); \
 	a.state[(size_t)13 * a.cap + slot] = f4(c.col, fbits(pack_ctl(c))); out[slot] = w + m; }
-PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot]))
+PROBE(probe_after_closest, st_after_closest(a, slot, h, c, slot * 7u, a.state[2 * (size_t)a.cap + slot], false))
 PROBE(probe_after_shadow, st_after_shadow(a, slot, h, make_uint2(slot & 1u, slot & 2u)))
 PROBE(probe_dl_next, st_dl_next(a, slot, h, c.level))
 PROBE(probe_dl_eval, st_dl_eval(a, slot, h, c, slot * 3u, slot * 5u, m))
-PROBE(probe_dl_done, st_dl_done(a, slot, h, c))
+PROBE(probe_dl_done, st_dl_done(a, slot, h, c, false))
 PROBE(probe_extend, st_extend(a, slot, h, c))
 PROBE(probe_start_path, st_start_path(a, slot, h, c, slot * 3u, slot * 5u, slot * 7u))
 #undef PROBE
@@ -1214,6 +1333,29 @@ constexpr int kTraceBatch = YAFGPU_TRACE_BATCH;
 #ifndef YAFGPU_TRACE_BLOCKS
 #define YAFGPU_TRACE_BLOCKS 0    // measured, off: 1 = the any-hit launches walk the block layout of the tree (DevScene::nodes_blk): +4 %; 2 = the closest-hit ones too, instead of the pair array: +10 % (profiles/r02_ab_blocks.txt)
 #endif
+// Leaves apart.  A node burst used to handle a leaf the moment a lane fetched one: the empty-leaf pop (21 vector instructions) and
+// the non-empty leaf's note-and-go-on (30) sat as divergent branches inside EVERY node step, entered by the 15 % of the walking
+// lanes that stood at a leaf — with 35 lanes walking some lane nearly always does, so a step cost 28 + 21 + 30 instructions for
+// 28 useful ones.  Now a lane that fetches a leaf stands still for the rest of the burst (kAtLeaf) and all leaves of a burst are
+// handled together after it, once.  Per ray the steps and their order are what they were.  0: the old placement (comparison build).
+#ifndef YAFGPU_TRACE_LEAF_APART
+#define YAFGPU_TRACE_LEAF_APART 0      // measured (profiles/r03_ab_leaf.txt): fewer instructions, fewer lanes per step — closest-hit launches +6 %, any-hit launches equal
+#endif
+// Triangle records (48 MB at 1 M triangles, each read a few times per pass by unrelated rays) loaded with the non-temporal hint, so that
+// they do not push the node lines out of the 32 KB L1 / 4 MB L2 (measured: profiles/r03_ab_toptree.txt).
+#ifndef YAFGPU_TRACE_NT
+#define YAFGPU_TRACE_NT 0
+#endif
+typedef float yg_f4v __attribute__((ext_vector_type(4)));
+YG_DEV float4 ld_tri(const float4 *p)
+{
+#if YAFGPU_TRACE_NT
+	const yg_f4v v = __builtin_nontemporal_load((const yg_f4v *)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+#else
+	return *p;
+#endif
+}
 #ifndef YAFGPU_TRACE_WAVES
 #define YAFGPU_TRACE_WAVES 7     // waves per SIMD the register allocation must leave room for (22.5 KB of LDS per block allow 7): 70 / 68 VGPRs; without the bound the any-hit kernel took 81 (5 waves)
 #endif
@@ -1226,6 +1368,16 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 	__shared__ float2 s_axis[kWavesPerBlock][3][kWave];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const DevScene &sc = a.ra.sc;
+#if YAFGPU_TRACE_TOP == 2
+	__shared__ uint4 s_top[kTopN];
+	for(int i = (int)threadIdx.x; i < kTopN; i += (int)blockDim.x) s_top[i] = sc.top[i];
+	__syncthreads();
+#endif
+#ifdef YAFGPU_TRACE_LDS_PAD      // (A/B aid: the LDS the staged top would take, without it — the occupancy alone)
+	__shared__ uint32_t s_pad[YAFGPU_TRACE_LDS_PAD / 4];
+	if(a.cap == 0xffffffffu) s_pad[threadIdx.x] = 1u;
+#endif
+	constexpr uint32_t kRoot = YAFGPU_TRACE_TOP ? kTopTag : 0u;
 	LaneStack stk;
 	stk.col = &s_stack[wave][0][lane];
 	float2 *const axis_col = &s_axis[wave][0][lane];      // axis k at axis_col[k * kWave]
@@ -1251,7 +1403,8 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 		if(occluded) atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u));
 	};
 	// the walk: at a node | at a non-empty leaf, waiting for the pending slot | no node left | no ray
-	enum : uint32_t { kWalk = 0u, kBlocked = 1u, kWalkEnd = 2u, kNoRay = 3u };
+	enum : uint32_t { kWalk = 0u, kBlocked = 1u, kWalkEnd = 2u, kNoRay = 3u, kAtLeaf = 4u };
+	uint32_t lf_first = 0u, lf_np = 0u;              // the leaf a lane in kAtLeaf stands at: first reference, reference count
 	constexpr int kVoteNum = YAFGPU_VOTE_NUM, kVoteDen = YAFGPU_VOTE_DEN, kNodeBurst = YAFGPU_NODE_BURST;
 	constexpr bool kBlk = (YAFGPU_TRACE_BLOCKS == 2) || (YAFGPU_TRACE_BLOCKS == 1 && kAny);
 	uint32_t ws = kNoRay;
@@ -1291,9 +1444,14 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				const uint32_t i = first_i + rank;
 				slot = q ? q[i] : i;
 				qi = i;
-				which = 0u;
-				if(kAny) { which = slot >> 31; slot &= 0x7fffffffu; }
+				which = slot >> 31; slot &= 0x7fffffffu;      // any-hit: the second ray of a pair; closest-hit: a segment parked beside a shadow pair
 				float4 r0 = a.state[slot], r1 = a.state[c + slot];
+				if(!kAny && which)
+				{	// origin: the vertex in record 0; direction and tmin in record 26 (records 0.w / 1 hold the pair's first shadow ray)
+					const float4 r26 = a.state[26 * c + slot];
+					r1 = make_float4(r26.x, r26.y, r26.z, -1.f);
+					r0.w = r26.w;
+				}
 				if(kAny && which)
 				{	// second ray of the pair: same origin, direction/tmin in r20, tmax in r21.w
 					const float4 r20 = a.state[20 * c + slot];
@@ -1325,7 +1483,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 					axis_col[kWave] = make_float2(from.y, inv_dir.y);
 					axis_col[2 * kWave] = make_float2(from.z, inv_dir.z);
 					dneg = (dir.x <= 0.f ? 1u : 0u) | (dir.y <= 0.f ? 2u : 0u) | (dir.z <= 0.f ? 4u : 0u);
-					t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = 0u; ws = kWalk;
+					t_exit = eb; tmin = smax(ea, 0.f); tmax = t_exit; node = kRoot; ws = kWalk;
 					stk.reset();
 				}
 				else
@@ -1354,7 +1512,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			const bool restart = emp && stk.lost() && !(tmax >= t_exit);
 			if(kStats && restart && !hit_here) ++cn.restarts;
 			tmin = restart ? restart_from(tmin, tmax) : tmax;                          // see restart_from: progress on degenerate trees
-			node = emp ? 0u : top.x;
+			node = emp ? kRoot : top.x;
 			tmax = emp ? t_exit : __uint_as_float(top.y);
 			stk.sp = emp ? 0 : stk.sp - 1;
 			stk.lo = emp ? 0 : stk.lo;
@@ -1395,7 +1553,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 			}
 		};
 		// one step of the walk on the fetched node
-		auto node_step = [&](const uint2 nd) {
+		auto node_step = [&](const uint2 nd, const uint32_t left_c, const uint32_t right_c) {
 			if((nd.y & 3u) != 3u)
 			{
 				const uint32_t axis = nd.y & 3u;
@@ -1411,7 +1569,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 #else
 				const bool below = dn ? (o <= split) : (o < split);
 #endif
-				uint32_t left = node + 1u, right = nd.y >> 2;
+				uint32_t left = left_c, right = right_c;
 				if(kBlk)
 				{	// block layout: children inside the block for slots 0..2, the roots of the two child blocks for slots 3..6
 					const uint32_t sl = node & 7u;
@@ -1432,6 +1590,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				node = far_only ? far_c : near_c;
 				tmax = both ? tplane : tmax;
 			}
+			else if(YAFGPU_TRACE_LEAF_APART) { lf_first = nd.x; lf_np = nd.y >> 2; ws = kAtLeaf; }      // handled after the burst (leaf_visit)
 			else
 			{
 				const uint32_t np = nd.y >> 2;
@@ -1451,6 +1610,52 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				}
 			}
 		};
+		// one step on the heap-ordered copy of the tree's top (YAFGPU_TRACE_TOP): children by index arithmetic, and by the node's own
+		// place in the depth-first array on the copy's last level, below which the walk goes on in `nodes`
+		auto top_step = [&]() {
+#if YAFGPU_TRACE_TOP
+			const uint32_t hh = node & ~kTopTag;
+#if YAFGPU_TRACE_TOP == 2
+			const uint4 e = s_top[hh];
+#else
+			const uint4 e = sc.top[hh];
+#endif
+			const bool bottom = hh >= (uint32_t)kTopBottom;
+			node_step(make_uint2(e.x, e.y), bottom ? e.z + 1u : (kTopTag | (2u * hh + 1u)), bottom ? (e.y >> 2) : (kTopTag | (2u * hh + 2u)));
+#endif
+		};
+		// the leaves of a burst, together (YAFGPU_TRACE_LEAF_APART): an empty leaf is left at once, a non-empty one becomes the pending
+		// leaf (its first reference in flight while the lane walks on) — or the lane waits at it while another leaf is pending
+		auto leaf_visit = [&]() {
+			const bool empty = lf_np == 0u, pend = p_cur < p_end;
+			if(!YAFGPU_TRACE_POSTPONE && !empty)
+			{	// (comparison build) stop at every non-empty leaf until its tests are through
+				if(kStats) ++cn.leaves;
+				p_cur = lf_first; p_end = lf_first + lf_np; p_tmax = tmax; ti = sc.refs[lf_first]; ws = kBlocked;
+			}
+			else if(!empty && pend) ws = kBlocked;           // the node is read again when the pending leaf is through
+			else
+			{
+				if(kStats) { ++cn.leaves; if(empty && pend) ++spec_leaves; }
+				if(!empty)
+				{
+					p_cur = lf_first; p_end = lf_first + lf_np; p_tmax = tmax;
+					ti = sc.refs[lf_first];
+				}
+				leaf_end();
+			}
+		};
+#if YAFGPU_TRACE_TOP
+		// lanes that stand in the top copy (new rays; a far child popped off the stack) walk down it first, together: these steps wait for
+		// the L1 or LDS only, and afterwards the node rounds below find (nearly) every lane in the depth-first array
+#pragma unroll 1
+		for(int s = 0; s < kTopDepth + 2; ++s)
+		{
+			if(__ballot(ws == kWalk && (node & kTopTag)) == 0ull) break;
+			if(ws == kWalk && (node & kTopTag)) top_step();
+			if(YAFGPU_TRACE_LEAF_APART && ws == kAtLeaf) leaf_visit();
+		}
+#endif
 #if YAFGPU_TRACE_FUSED
 		// Fused rounds: every lane fetches what it can use — the node its walk stands at AND the next triangle of its pending
 		// leaf — the wave waits once, then runs the node section and the triangle section one after the other.  More
@@ -1469,7 +1674,8 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				r0 = sc.tri[3u * ti]; r1 = sc.tri[3u * ti + 1u]; r2 = sc.tri[3u * ti + 2u];
 			}
 			if(kStats) { ++rounds_node; ++rounds_tri; }
-			if(walking) node_step(nd);
+			if(walking) node_step(nd, node + 1u, nd.y >> 2);
+			if(YAFGPU_TRACE_LEAF_APART && ws == kAtLeaf) leaf_visit();
 			if(has_pend) tri_step(r0, r1, r2, ref_v);
 			(void)n_tri; (void)n_node;
 		}
@@ -1489,7 +1695,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				q_ok = p_cur < p_end;
 				if(q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; }
 #else
-				const float4 r0 = sc.tri[3u * ti], r1 = sc.tri[3u * ti + 1u], r2 = sc.tri[3u * ti + 2u];
+				const float4 r0 = ld_tri(&sc.tri[3u * ti]), r1 = ld_tri(&sc.tri[3u * ti + 1u]), r2 = ld_tri(&sc.tri[3u * ti + 2u]);
 				tri_step(r0, r1, r2, ref_v);
 #endif
 			}
@@ -1508,15 +1714,17 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 #if YAFGPU_TRACE_TRIPF
 				if(p_cur < p_end && !q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; q_ok = true; }
 #endif
-				if(ws == kWalk)
+				if(YAFGPU_TRACE_TOP && ws == kWalk && (node & kTopTag)) { top_step(); if(ws == kWalk && (node & kTopTag)) top_step(); }
+				else if(ws == kWalk)
 				{
 					const uint32_t n0 = node;
 					const uint4 a0 = sc.nodes2[n0], a1 = sc.nodes2[n0 + 1u];
-					node_step(make_uint2(a0.x, a0.y));
+					node_step(make_uint2(a0.x, a0.y), n0 + 1u, a0.y >> 2);
 					if((a0.y & 3u) != 3u)          // an interior node hands the walk to one of its two children
 					{
 						const bool to_left = node == n0 + 1u;
-						node_step(to_left ? make_uint2(a1.x, a1.y) : make_uint2(a0.z, a0.w));
+						const uint2 n1 = to_left ? make_uint2(a1.x, a1.y) : make_uint2(a0.z, a0.w);
+						node_step(n1, node + 1u, n1.y >> 2);
 					}
 				}
 			}
@@ -1528,8 +1736,10 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 #if YAFGPU_TRACE_TRIPF
 				if(p_cur < p_end && !q_ok) { q0 = sc.tri[3u * ti]; q1 = sc.tri[3u * ti + 1u]; q2 = sc.tri[3u * ti + 2u]; q_ok = true; }
 #endif
-				if(ws == kWalk) node_step(kBlk ? sc.nodes_blk[node] : sc.nodes[node]);
+				if(YAFGPU_TRACE_TOP && ws == kWalk && (node & kTopTag)) top_step();
+				else if(ws == kWalk) { const uint2 nd = kBlk ? sc.nodes_blk[node] : sc.nodes[node]; node_step(nd, node + 1u, nd.y >> 2); }
 			}
+			if(YAFGPU_TRACE_LEAF_APART && ws == kAtLeaf) leaf_visit();
 		}
 #endif
 		if(done || (ws == kWalkEnd && p_cur >= p_end))
@@ -1573,8 +1783,18 @@ __global__ __launch_bounds__(kBlock) void wf_cached_closest(const WfArgs a)
 	const size_t c = a.cap;
 	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
-		const uint32_t slot = q ? q[i] : i;
-		const uint32_t ctl = ubits(a.state[13 * c + slot].w);
+		uint32_t slot = q ? q[i] : i;
+		const bool beside = (slot >> 31) != 0u;
+		slot &= 0x7fffffffu;
+		uint32_t ctl = ubits(a.state[13 * c + slot].w);
+		if(beside)
+		{	// parked beside a shadow pair (st_beside): the control word is still the vertex's — the segment is the one st_start_path /
+			// st_extend would have parked after it: camera hit -> first segment; first hit -> depth 1; depth d -> depth d + 1
+			const uint32_t stage = (ctl >> 2) & 3u, depth = (ctl >> 8) & 0xfu;
+			const uint32_t stage_n = stage == (uint32_t)kStPrimary ? (uint32_t)kStFirst : (uint32_t)kStDepth;
+			const uint32_t depth_n = stage == (uint32_t)kStPrimary ? 0u : (stage == (uint32_t)kStFirst ? 1u : depth + 1u);
+			ctl = (ctl & ~((3u << 2) | (0xfu << 8))) | (stage_n << 2) | (depth_n << 8);
+		}
 		const uint32_t z19 = a.ev_m > 1 ? ubits(a.state[19 * c + slot].z) : 0u;
 		a.state[2 * c + i] = a.hit_cache[wf_hit_key(a, slot, ctl, z19)];
 	}
@@ -1588,6 +1808,16 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 	__shared__ uint32_t s_seen[kWavesPerBlock][kTsMaxDepth + 1][kWave];
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const DevScene &sc = a.ra.sc;
+#if YAFGPU_TRACE_TOP == 2
+	__shared__ uint4 s_top[kTopN];
+	for(int i = (int)threadIdx.x; i < kTopN; i += (int)blockDim.x) s_top[i] = sc.top[i];
+	__syncthreads();
+#endif
+#ifdef YAFGPU_TRACE_LDS_PAD      // (A/B aid: the LDS the staged top would take, without it — the occupancy alone)
+	__shared__ uint32_t s_pad[YAFGPU_TRACE_LDS_PAD / 4];
+	if(a.cap == 0xffffffffu) s_pad[threadIdx.x] = 1u;
+#endif
+	constexpr uint32_t kRoot = YAFGPU_TRACE_TOP ? kTopTag : 0u;
 	LaneStack stk;
 	stk.col = &s_stack[wave][0][lane];
 	uint32_t *seen = &s_seen[wave][0][lane];
@@ -1682,8 +1912,8 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 	const uint32_t per_block = (uint32_t)kBlock * kItems;
 	for(uint32_t base = blockIdx.x * per_block; base < total; base += gridDim.x * per_block)
 	{
-		// what each item asked for, kept in LDS between the two loops: slot | code << 28
-		// (code: bit0 closest, bit1 resume, bit2 shadow ray A, bit3 shadow ray B); the item loop is not unrolled, so
+		// what each item asked for, kept in LDS between the two loops: slot | code << 27
+		// (code: bit0 closest, bit1 resume, bit2 shadow ray A, bit3 shadow ray B, bit4 the closest ray is in record 26); the item loop is not unrolled, so
 		// the register footprint is that of one item
 		uint32_t wc = 0u, wr = 0u, ws = 0u;            // this wave's totals per queue
 #pragma unroll 1
@@ -1695,7 +1925,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 			uint32_t slot = 0u;
 			if(live)
 			{
-				slot = (i < nc) ? (a.q_closest_in ? a.q_closest_in[i] : i) : a.q_resume_in[i - nc];
+				slot = (i < nc) ? (a.q_closest_in ? (a.q_closest_in[i] & 0x7fffffffu) : i) : a.q_resume_in[i - nc];      // (bit 31: parked beside a shadow pair — the control word says so too)
 				// the closest-hit answer of queue entry i (the traversal kernel wrote it at the ray's queue position)
 				float4 ans = make_float4(0.f, 0.f, 0.f, 0.f);
 				if(i < nc) ans = a.state[2 * (size_t)a.cap + i];
@@ -1711,8 +1941,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 				}
 				else if(req == kReqClosest) code = 1;
 				else if(req == kReqShadow) code = 2 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);
+				else if(req == kReqBoth) code = 1 | 16 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);      // the closest queue resumes it: no resume entry
 			}
-			s_item[k][threadIdx.x] = slot | ((uint32_t)code << 28);
+			s_item[k][threadIdx.x] = slot | ((uint32_t)code << 27);
 			wc += (uint32_t)__popcll(__ballot(code & 1));
 			wr += (uint32_t)__popcll(__ballot(code & 2));
 			ws += (uint32_t)__popcll(__ballot(code & 4)) + (uint32_t)__popcll(__ballot(code & 8));
@@ -1735,10 +1966,10 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 		for(int k = 0; k < kItems; ++k)
 		{
 			const uint32_t item = s_item[k][threadIdx.x];
-			const int code = (int)(item >> 28);
-			const uint32_t slot = item & 0x0fffffffu;
+			const int code = (int)(item >> 27);
+			const uint32_t slot = item & 0x07ffffffu;
 			const unsigned long long bc = __ballot(code & 1), br = __ballot(code & 2), ba = __ballot(code & 4), bb = __ballot(code & 8);
-			if(code & 1) a.q_closest_out[oc + (uint32_t)__popcll(bc & below)] = slot;
+			if(code & 1) a.q_closest_out[oc + (uint32_t)__popcll(bc & below)] = slot | ((code & 16) ? 0x80000000u : 0u);
 			if(code & 2) a.q_resume_out[orr + (uint32_t)__popcll(br & below)] = slot;
 			if(code & 4) a.q_shadow_out[os + (uint32_t)__popcll(ba & below)] = slot;
 			const uint32_t na = (uint32_t)__popcll(ba);

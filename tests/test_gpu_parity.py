@@ -1378,7 +1378,12 @@ def _first_tree_artefact(sc, rd, same_tree, film, ofilm):
     def key(x, y):
         return ((y - y00) // ts, (x - x00) // ts, y, x)
     k0 = key(x0, y0)
-    early = [(int(x), int(y)) for x, y in zip(xs + x00, ys + y00) if key(int(x), int(y)) < k0]
+    # a sample lands on every pixel of its filter footprint (imagefilm.cc:124-187: filterw = AA_pixelwidth / 2, x2 gauss, x2.6 mitchell,
+    # clamped to [0.501, 4]): pixels that close to the query's are not "before" it
+    fw = rd.get("AA_pixelwidth", 1.5) * 0.5 * {"gauss": 2.0, "mitchell": 2.6}.get(rd.get("filter_type", "box"), 1.0)
+    reach = int(np.ceil(min(max(fw, 0.501), 4.0))) + 1
+    early = [(int(x), int(y)) for x, y in zip(xs + x00, ys + y00)
+             if key(int(x), int(y)) < k0 and (abs(int(x) - x0) > reach or abs(int(y) - y0) > reach)]
     if rd.get("AA_passes", 1) > 1:
         early = []      # a later pass re-renders earlier pixels after the query: order alone cannot separate them
     found["parts_at_or_after_the_query"] = not early

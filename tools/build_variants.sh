@@ -7,8 +7,8 @@ mkdir -p libyafaray_amd/variants
 for spec in "$@"; do
   name="${spec%%=*}"; flags="${spec#*=}"
   echo "== $name: $flags"
-  YAFGPU_OUT="$PWD/libyafaray_amd/variants/$name.so" YAFGPU_EXTRA_FLAGS="$flags" bash libyafaray_amd/csrc/build.sh > /tmp/build_$name.log 2>&1 || { tail -20 /tmp/build_$name.log; exit 1; }
+  # objects of a variant live in their own directory (kept between calls: only stale ones are rebuilt)
+  YAFGPU_OBJ="$PWD/libyafaray_amd/csrc/obj_$name" YAFGPU_OUT="$PWD/libyafaray_amd/variants/$name.so" YAFGPU_EXTRA_FLAGS="$flags" bash libyafaray_amd/csrc/build.sh > /tmp/build_$name.log 2>&1 || { tail -20 /tmp/build_$name.log; exit 1; }
 done
-# leave the default objects / library in place
 bash libyafaray_amd/csrc/build.sh > /tmp/build_default.log 2>&1 || { tail -20 /tmp/build_default.log; exit 1; }
 ls -la libyafaray_amd/variants/

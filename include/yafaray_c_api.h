@@ -173,7 +173,9 @@ void yafaray_setShard(yafaray_interface_t *yi, int shard_index, int shard_count)
  * in place (an all-reduce; libyafaray_amd/parallel.py does it with torch.distributed = RCCL) and return 0.  Without it a sharded
  * multi-pass render is refused.  The film a rank returns stays its own share (sum them as for a one-pass render).
  * The same function carries the light counter of the serial replay below across ranks (a small table of per-tile call counts once per
- * pass): with it a sharded render of a scene with several lights makes the single-GPU render's light choices; without it, its own. */
+ * pass): with it a sharded render of a scene with several lights makes the single-GPU render's light choices; without it, its own.
+ * The exchange is a collective: a rank that fails or is aborted (yafaray_abort) before it leaves the others waiting in theirs, as with
+ * any collective — abort a sharded render on EVERY rank (the flag is polled between chunks and passes, before each exchange). */
 typedef int (*yafaray_plane_exchange_t)(void *user, float *d_values, uint64_t n_floats);
 void yafaray_setPlaneExchange(yafaray_interface_t *yi, yafaray_plane_exchange_t fn, void *user);
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI, no Python on the data path (yafaray_reduce.cpp) -------------------------

@@ -1435,6 +1435,25 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			if(m.n_bump < 0 || m.n_bump > kMaxNodes || (m.n_bump > 0 && (m.bump_first < 0 || m.bump_first + m.n_bump > d->n_nodes || m.sh_bump < 0 || m.sh_bump >= m.n_bump)))
 			{ yafgpu_scene_destroy(s); return fail(-24, "a material's bump shader: more than " + std::to_string(kMaxNodes) + " nodes, or a range outside the node array"); }
 			if(m.n_bump > 0) { s->has_textures = true; s->has_bump = true; }
+			// every reference inside the material — a shader slot, a node's inputs — is -1 or names a node BEFORE the one that reads it
+			// (evaluation order): the device indexes a per-lane result stack with them (nodes_eval, mat_resolve, nodes_eval_derivative)
+			const int slots[] = {m.sh_diffuse, m.sh_mirror_color, m.sh_mirror, m.sh_transparency, m.sh_translucency, m.sh_sigma_oren, m.sh_diffuse_refl, m.sh_ior,
+			                     m.sh_glossy, m.sh_glossy_reflect, m.sh_exponent, m.sh_filter_color};
+			for(int sl : slots)
+				if(m.n_nodes > 0 && (sl < -1 || sl >= m.n_nodes)) { yafgpu_scene_destroy(s); return fail(-24, "a material's shader slot names a node outside its node range"); }
+			auto range_ok = [&](int first, int count) {
+				for(int k = 0; k < count; ++k)
+				{
+					const yafgpu_node &n = d->nodes[first + k];
+					auto ref_ok = [&](int r) { return r >= -1 && r < k; };
+					if(n.type == YAFGPU_NODE_MIX && !(ref_ok(n.input1) && ref_ok(n.input2) && ref_ok(n.factor))) return false;
+					if(n.type == YAFGPU_NODE_LAYER && !(n.input >= 0 && n.input < k && ref_ok(n.upper))) return false;
+					if(n.type < YAFGPU_NODE_TEXTURE_MAPPER || n.type > YAFGPU_NODE_LAYER) return false;
+				}
+				return true;
+			};
+			if(!range_ok(m.node_first, m.n_nodes) || (m.n_bump > 0 && !range_ok(m.bump_first, m.n_bump)))
+			{ yafgpu_scene_destroy(s); return fail(-24, "a shader node refers to a node that is not evaluated before it (or has an unknown type; a layer needs an input)"); }
 		}
 		for(int i = 0; i < d->n_nodes; ++i)
 		{
@@ -1847,7 +1866,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		// final pass then looks its closest hits up instead of tracing them again); never in a stats pass, whose per-ray traversal
 		// counts are the point
 		hit_k = ev_m * n_ps * ((uint32_t)std::max(rp.bounces, 1) + 1u);
-		use_hits = !stats && (size_t)hit_k * sizeof(float4) <= 1024;
+		use_hits = !stats && (size_t)hit_k * sizeof(float4) <= 1024 && (uint64_t)s->wf_cap * hit_k < (1ull << 32);      // (wf_hit_key is a 32-bit index)
 		if(const char *e = std::getenv("YAFGPU_HIT_CACHE")) use_hits = use_hits && std::atoi(e) != 0;
 		if(use_hits && (size_t)s->wf_cap * hit_k > s->rp_hits_cap)
 		{

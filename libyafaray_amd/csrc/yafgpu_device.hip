@@ -1237,21 +1237,24 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			return fail(-4, "material with a glossy transmission lobe (rough glass) needs the reflect + transmit case of recursiveRaytrace's glossy branch, which the GPU path does not implement");
 	}
 	auto *s = new yafgpu_scene();
-	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
-	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].anisotropic) s->has_aniso = true;
-	for(int i = 0; i < d->n_materials; ++i) s->max_add_depth = std::max(s->max_add_depth, std::min(std::max(d->materials[i].additional_depth, 0), 15));
-	for(int i = 0; i < d->n_materials; ++i) if(d->materials[i].bsdf_flags & kGlossy) s->has_glossy = true;
-	{	// material types some triangle actually uses (a definition nothing refers to does not cost a kernel variant)
+	{	// What the scene's materials ask of the pipeline — recursion frames, the glossy loop's wider frames, extra depth, the transparent-shadow
+		// kernel, the kernel variant — is taken from the materials some triangle actually USES: a definition nothing refers to can never be
+		// hit, and must not cost frames, a kernel variant or (through the size of the replay's event tables) the exactness of the serial state
 		std::vector<char> used((size_t)d->n_materials, 0);
 		for(int i = 0; i < d->n_tris; ++i) used[(size_t)d->tri_mat[i]] = 1;
 		for(int i = 0; i < d->n_materials; ++i)
 		{
 			if(!used[(size_t)i]) continue;
-			s->mat_mask |= 1u << (uint32_t)d->materials[i].type;
-			if(d->materials[i].bsdf_flags & kVolumetric) s->has_volumetric = true;
+			const yafgpu_material &m = d->materials[i];
+			s->mat_mask |= 1u << (uint32_t)m.type;
+			if(m.bsdf_flags & kVolumetric) s->has_volumetric = true;
+			if(m.bsdf_flags & (kSpecular | kFilter)) s->has_specular = true;
+			if(m.anisotropic) s->has_aniso = true;
+			s->max_add_depth = std::max(s->max_add_depth, std::min(std::max(m.additional_depth, 0), 15));
+			if(m.bsdf_flags & kGlossy) s->has_glossy = true;
+			if((m.type == YAFGPU_MAT_SHINYDIFFUSE && m.is_transparent) || (m.type == YAFGPU_MAT_GLASS && m.fake_shadow)) s->has_transparent = true;
 		}
 	}
-	for(int i = 0; i < d->n_materials; ++i) if((d->materials[i].type == YAFGPU_MAT_SHINYDIFFUSE && d->materials[i].is_transparent) || (d->materials[i].type == YAFGPU_MAT_GLASS && d->materials[i].fake_shadow)) s->has_transparent = true;
 	const auto t0 = std::chrono::steady_clock::now();
 	{
 		// 0: by size -- the device builder wins from a few ten thousand triangles on (1 M: 0.07 s against 0.33 s)

@@ -34,6 +34,10 @@
 //                                                      pixel resampled in every pass (the reference's behaviour at
 //                                                      AA_threshold = 0, imagefilm.cc:319,460,917-920)
 //   ImageFilm::addSample                               RECORDS the sample (x, y, dx, dy, rgba) — the harness's output
+//   RenderEnvironment::createVolumeH                   GlassMaterial::factory creates the Beer handler of an absorbing glass through it
+//                                                      (material_glass.cc:390-398; environment.cc:586-607 keeps a name table and dispatches
+//                                                      on the type): here it hands the ParamMap straight to the reference's
+//                                                      BeerVolumeHandler::factory
 //
 // So what the fixture pins is: given the same geometry answers, the reference's render() / renderTile() / integrate() /
 // doLightEstimation() / estimateOneDirectLight() / recursiveRaytrace() — run on the reference's real materials, lights,
@@ -78,6 +82,8 @@
 #include "material/material_simple.h"
 #include "light/light_area.h"
 #include "light/light_point.h"
+#include "volume/volumehandler_beer.h"
+#include "common/environment.h"
 
 using namespace yafaray4;
 
@@ -291,6 +297,9 @@ bool Scene::isShadowed(RenderState &state, const Ray &ray, int max_depth, Rgb &f
 	return isect;
 }
 
+// ---------------------------------------------------------------- harness-provided body: RenderEnvironment::createVolumeH
+VolumeHandler *RenderEnvironment::createVolumeH(const std::string &, const ParamMap &params) { return BeerVolumeHandler::factory(params, *this); }
+
 // ---------------------------------------------------------------- harness-provided bodies: ImageFilm
 struct SampleRec { int x, y; float dx, dy; float c[4]; };
 static std::vector<SampleRec> g_samples;
@@ -414,6 +423,7 @@ static Material *make_material(const Params &ps_)
 {
 	std::list<ParamMap> no_nodes;
 	ParamMap m = to_map(ps_);
+	m["name"] = std::string("material");      // RenderEnvironment::createMaterial, environment.cc:261 (GlassMaterial::factory creates its Beer handler only with it)
 	const std::string t = find(ps_, "type")->s;
 	if(t == "shinydiffusemat") return ShinyDiffuseMaterial::factory(m, no_nodes, fake_env());
 	if(t == "glossy") return GlossyMaterial::factory(m, no_nodes, fake_env());
@@ -468,7 +478,8 @@ static void box(double cx, double cy, double cz, double hx, double hy, double hz
 	for(int k = 0; k < 6; ++k) add_quad(v[f[k][0]], v[f[k][1]], v[f[k][2]], v[f[k][3]], slot);
 }
 
-enum { M_WHITE = 0, M_RED, M_GREEN_ON, M_LIGHT1, M_GLOSSY, M_SD_MIRROR_TRANSP, M_GLASS, M_COATED, M_GLOSSY_REC, M_MIRROR, M_SD_EMIT, M_LIGHT2, M_SD_TRANSP, N_MATS };
+enum { M_WHITE = 0, M_RED, M_GREEN_ON, M_LIGHT1, M_GLOSSY, M_SD_MIRROR_TRANSP, M_GLASS, M_COATED, M_GLOSSY_REC, M_MIRROR, M_SD_EMIT, M_LIGHT2, M_SD_TRANSP,
+       M_GLASS_ABS, M_GLASS_FAKE, M_ANISO, M_COATED_REC, M_SD_TRANSL, M_SD_FLAT, M_SD_DEPTH, M_SD_NOSHADOW, M_SD_SHADOWONLY, M_SD_NORECV, N_MATS };
 enum { SLOT_A = 0, SLOT_B, SLOT_C, SLOT_D, N_SLOTS };
 
 static std::vector<Params> g_mat_params;
@@ -495,6 +506,21 @@ static void build_catalogue()
 	g_mat_params[M_SD_EMIT] = {ps("type", "shinydiffusemat"), pv("color", 0.9, 0.6, 0.2), pf("diffuse_reflect", 0.8), pf("emit", 0.6)};
 	g_mat_params[M_LIGHT2] = {ps("type", "light_mat"), pv("color", 0.6, 0.8, 1.0), pf("power", 9.0)};
 	g_mat_params[M_SD_TRANSP] = {ps("type", "shinydiffusemat"), pv("color", 0.9, 0.5, 0.4), pf("diffuse_reflect", 0.6), pf("transparency", 0.7), pf("transmit_filter", 0.9)};
+	g_mat_params[M_GLASS_ABS] = {ps("type", "glass"), pf("IOR", 1.45), pv("filter_color", 0.9, 0.9, 1.0), pf("transmit_filter", 0.5), pv("mirror_color", 0.95, 1.0, 0.95),
+	                             pv("absorption", 0.4, 0.7, 0.9), pf("absorption_dist", 0.6)};
+	g_mat_params[M_GLASS_FAKE] = {ps("type", "glass"), pf("IOR", 1.33), pv("filter_color", 0.6, 0.9, 0.7), pf("transmit_filter", 0.8), pb("fake_shadows", true)};
+	g_mat_params[M_ANISO] = {ps("type", "glossy"), pv("color", 0.8, 0.85, 0.9), pv("diffuse_color", 0.7, 0.5, 0.3), pf("diffuse_reflect", 0.4), pf("glossy_reflect", 0.7),
+	                         pb("anisotropic", true), pf("exp_u", 20.0), pf("exp_v", 300.0), pb("as_diffuse", true)};
+	g_mat_params[M_COATED_REC] = {ps("type", "coated_glossy"), pv("color", 0.9, 0.9, 0.8), pv("diffuse_color", 0.4, 0.3, 0.6), pv("mirror_color", 1.0, 1.0, 1.0),
+	                              pf("diffuse_reflect", 0.6), pf("glossy_reflect", 0.5), pf("exponent", 120.0), pf("specular_reflect", 0.7), pf("IOR", 1.5), pb("as_diffuse", false),
+	                              ps("diffuse_brdf", "Oren-Nayar"), pf("sigma", 0.2)};
+	g_mat_params[M_SD_TRANSL] = {ps("type", "shinydiffusemat"), pv("color", 0.6, 0.8, 0.5), pf("diffuse_reflect", 0.7), pf("translucency", 0.4), pf("transmit_filter", 0.6), pf("emit", 0.2)};
+	g_mat_params[M_SD_FLAT] = {ps("type", "shinydiffusemat"), pv("color", 0.8, 0.7, 0.3), pf("diffuse_reflect", 0.9), pb("flat_material", true)};
+	g_mat_params[M_SD_DEPTH] = {ps("type", "shinydiffusemat"), pv("color", 0.7, 0.7, 0.8), pv("mirror_color", 0.9, 0.95, 1.0), pf("diffuse_reflect", 0.6), pf("specular_reflect", 0.5),
+	                            pf("transparency", 0.3), pf("transmit_filter", 0.7), pi("additionaldepth", 2), pf("transparentbias_factor", 0.01), pb("transparentbias_multiply_raydepth", true)};
+	g_mat_params[M_SD_NOSHADOW] = {ps("type", "shinydiffusemat"), pv("color", 0.3, 0.6, 0.8), pf("diffuse_reflect", 0.9), ps("visibility", "no_shadows")};
+	g_mat_params[M_SD_SHADOWONLY] = {ps("type", "shinydiffusemat"), pv("color", 0.8, 0.3, 0.6), pf("diffuse_reflect", 0.9), ps("visibility", "shadow_only")};
+	g_mat_params[M_SD_NORECV] = {ps("type", "shinydiffusemat"), pv("color", 0.7, 0.7, 0.4), pf("diffuse_reflect", 0.9), pb("receive_shadows", false)};
 	for(const Params &p : g_mat_params) g_mats.push_back(make_material(p));
 
 	// room
@@ -643,7 +669,9 @@ static void run_case(Emit &out, const Case &cs, bool first)
 	surf->preprocess();
 
 	alignas(64) static unsigned char fake_output[256];
-	ImageFilm film(W, H, 0, 0, *reinterpret_cast<ColorOutput *>(fake_output), 1.f, ImageFilm::FilterType::Box, nullptr, false, TILE, ImageSplitter::Linear, false);
+	// the film window (render parameters width / height / xstart / ystart, environment.cc:747-774) and the tile size
+	ImageFilm film(pint(cs.render, "width", W), pint(cs.render, "height", H), pint(cs.render, "xstart", 0), pint(cs.render, "ystart", 0),
+	               *reinterpret_cast<ColorOutput *>(fake_output), 1.f, ImageFilm::FilterType::Box, nullptr, false, pint(cs.render, "tile_size", TILE), ImageSplitter::Linear, false);
 	film.setBaseSamplingOffset((unsigned)pint(cs.render, "adv_base_sampling_offset", 0));
 
 	g_samples.clear(); g_tile_log.clear(); g_ray_log.clear(); g_ray_log_cap = 1500; g_n_closest = g_n_shadow = 0;
@@ -779,6 +807,38 @@ int main()
 		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2), pb("adv_auto_shadow_bias_enabled", false), pf("adv_shadow_bias_value", 0.001),
 		            pb("adv_auto_min_raydist_enabled", false), pf("adv_min_raydist_value", 0.0001)};
 		c.srand_seed = 9; c.background[0] = 0.0; c.background[1] = 0.0; c.background[2] = 0.0;
+		cases.push_back(c);
+	}
+
+	{	// glass with absorption (a Beer volume inside the material: recursive rays and path segments that ran inside it), the anisotropic lobe,
+		// a glossy-recursive coated material with an Oren-Nayar substrate, translucency + emission
+		Case c; c.name = "pt_absorption_aniso";
+		c.slot_mat[SLOT_A] = M_GLASS_ABS; c.slot_mat[SLOT_B] = M_ANISO; c.slot_mat[SLOT_C] = M_COATED_REC; c.slot_mat[SLOT_D] = M_SD_TRANSL;
+		c.lights = {0, 2};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 2), pi("bounces", 4), pi("russian_roulette_min_bounces", 4), pi("raydepth", 3), ps("caustic_type", "none")};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 6; c.background[0] = 0.1; c.background[1] = 0.12; c.background[2] = 0.15;
+		if(const char *e = getenv("YAF_ABLATE")) for(int k = 0; k < N_SLOTS; ++k) if(k != atoi(e)) c.slot_mat[k] = M_WHITE;      // (debugging aid: keep one slot's material)
+		cases.push_back(c);
+	}
+	{	// material switches the integrators read: additionaldepth (raydepth 1 + 2), the transparent bias, visibility no_shadows / shadow_only,
+		// receive_shadows off, a light that casts no shadows; roulette on; a film window off the origin with an odd tile size
+		Case c; c.name = "pt_depth_bias_visibility";
+		c.slot_mat[SLOT_A] = M_SD_DEPTH; c.slot_mat[SLOT_B] = M_SD_NOSHADOW; c.slot_mat[SLOT_C] = M_SD_SHADOWONLY; c.slot_mat[SLOT_D] = M_SD_NORECV;
+		c.lights = {0, 1};
+		c.light_override = {pb("1:cast_shadows", false), pi("1:samples", 1)};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 1), pi("bounces", 4), pi("russian_roulette_min_bounces", 1), pi("raydepth", 1), ps("caustic_type", "none")};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 3), pi("width", 14), pi("height", 11), pi("xstart", 3), pi("ystart", 2), pi("tile_size", 5)};
+		c.srand_seed = 8; c.background[0] = 0.0; c.background[1] = 0.0; c.background[2] = 0.0;
+		cases.push_back(c);
+	}
+	{	// direct lighting with transparent shadows through fake-shadow glass (a filter lobe), a flat material, the glossy-recursive branch under directlighting
+		Case c; c.name = "dl_fake_shadows_flat";
+		c.slot_mat[SLOT_A] = M_SD_FLAT; c.slot_mat[SLOT_B] = M_GLOSSY_REC; c.slot_mat[SLOT_C] = M_WHITE; c.slot_mat[SLOT_D] = M_GLASS_FAKE;
+		c.lights = {0, 2};
+		c.integrator = {ps("type", "directlighting"), pi("raydepth", 2), pb("caustics", false), pb("do_AO", false), pb("transpShad", true), pi("shadowDepth", 2), pb("bg_transp", true)};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 10; c.background[0] = 0.3; c.background[1] = 0.2; c.background[2] = 0.1;
 		cases.push_back(c);
 	}
 

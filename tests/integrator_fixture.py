@@ -52,7 +52,8 @@ def film_from_samples(doc, cs):
     """ImageFilm::addSample (imagefilm.cc:925-1015) for the box filter of width 1 the cases use: filterw = 0.501, every
     table entry 1; a sample lands on its pixel and on the right / lower neighbour when dx / dy >= 0.999.
     float32 accumulation in call order -> film (h, w, 5)"""
-    w, h = doc["width"], doc["height"]
+    rd = case_scene(doc, cs)[1]
+    w, h, x0, y0 = rd["width"], rd["height"], rd.get("xstart", 0), rd.get("ystart", 0)      # the film window (cx0, cy0 of imagefilm.cc:925-1015)
     xy, dxdy, rgba = samples(cs)
     film = np.zeros((h, w, 5), dtype=np.float32)
     filterw = np.float64(np.float32(0.501))
@@ -60,10 +61,10 @@ def film_from_samples(doc, cs):
     def r2i(v):
         return int(v + (0.5 - 1.4e-11))
     for (x, y), (dx, dy), c in zip(xy, dxdy, rgba):
-        dx0 = max(0 - x, r2i(float(dx) - filterw)); dx1 = min(w - x - 1, r2i(float(dx) + filterw - 1.0))
-        dy0 = max(0 - y, r2i(float(dy) - filterw)); dy1 = min(h - y - 1, r2i(float(dy) + filterw - 1.0))
+        dx0 = max(x0 - x, r2i(float(dx) - filterw)); dx1 = min(x0 + w - x - 1, r2i(float(dx) + filterw - 1.0))
+        dy0 = max(y0 - y, r2i(float(dy) - filterw)); dy1 = min(y0 + h - y - 1, r2i(float(dy) + filterw - 1.0))
         for j in range(y + dy0, y + dy1 + 1):
             for i in range(x + dx0, x + dx1 + 1):
-                film[j, i, :4] += c
-                film[j, i, 4] += np.float32(1.0)
+                film[j - y0, i - x0, :4] += c
+                film[j - y0, i - x0, 4] += np.float32(1.0)
     return film

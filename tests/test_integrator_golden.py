@@ -24,7 +24,7 @@ from oracle import pyoracle as po
 from tests.integrator_fixture import case_scene, closest_rays, film_from_samples, load, samples
 
 CASES = ["pt_mis_paths", "pt_three_lights_rr", "pt_recursive", "pt_multipass", "pt_dof", "directlighting",
-         "pt_transparent_shadows", "pt_no_recursive"]
+         "pt_transparent_shadows", "pt_no_recursive", "pt_absorption_aniso", "pt_depth_bias_visibility", "dl_fake_shadows_flat"]
 # one light and roulette off: every sample is a pure function of (pixel, sample index)
 NO_SERIAL_STATE = {"pt_mis_paths", "pt_dof"}
 
@@ -83,8 +83,9 @@ def test_tiles_are_handed_out_in_linear_order(docs):
     for cs in doc["cases"]:
         t = np.asarray(cs["tiles4"]).reshape(-1, 4)
         n_pass = cs["render"].get("AA_passes", 1)
-        ts, w, h = doc["tile_size"], doc["width"], doc["height"]
-        one = [(x, y, min(ts, w - x), min(ts, h - y)) for y in range(0, h, ts) for x in range(0, w, ts)]
+        rd = case_scene(doc, cs)[1]
+        ts, w, h, x0, y0 = rd["tile_size"], rd["width"], rd["height"], rd.get("xstart", 0), rd.get("ystart", 0)
+        one = [(x0 + x, y0 + y, min(ts, w - x), min(ts, h - y)) for y in range(0, h, ts) for x in range(0, w, ts)]
         assert [tuple(r) for r in t] == one * n_pass
 
 
@@ -101,8 +102,11 @@ def test_oracle_against_the_release_flag_build(docs, name):
     if name in NO_SERIAL_STATE:
         assert off.sum() <= 0.01 * len(off), f"{off.sum()} of {len(off)} samples over 1e-3"
     else:
-        first = int(np.argmax(off)) if off.any() else len(off)
-        assert first >= min(40, len(off)), f"forks from the release build at sample {first} already"
+        # the oracle parts from the release-flag build exactly where the reference's own IEEE build does
+        _, _, rgba_ieee = samples(_case(docs["ieee"], name))
+        off_ref = (np.abs(rgba_ieee - rgba) / np.maximum(np.abs(rgba), 1e-3)).max(axis=1) > 1e-3
+        first, first_ref = (int(np.argmax(o)) if o.any() else len(o) for o in (off, off_ref))
+        assert first == first_ref, f"parts from the release build at sample {first}, the IEEE build of the reference at {first_ref}"
     assert abs(int(st.rays_closest) - cs["n_closest"]) <= 0.01 * cs["n_closest"]
     assert abs(int(st.rays_shadow) - cs["n_shadow"]) <= 0.03 * cs["n_shadow"]
 

@@ -479,7 +479,7 @@ static void box(double cx, double cy, double cz, double hx, double hy, double hz
 }
 
 enum { M_WHITE = 0, M_RED, M_GREEN_ON, M_LIGHT1, M_GLOSSY, M_SD_MIRROR_TRANSP, M_GLASS, M_COATED, M_GLOSSY_REC, M_MIRROR, M_SD_EMIT, M_LIGHT2, M_SD_TRANSP,
-       M_GLASS_ABS, M_GLASS_FAKE, M_ANISO, M_COATED_REC, M_SD_TRANSL, M_SD_FLAT, M_SD_DEPTH, M_SD_NOSHADOW, M_SD_SHADOWONLY, M_SD_NORECV, N_MATS };
+       M_GLASS_ABS, M_GLASS_FAKE, M_ANISO, M_COATED_REC, M_SD_TRANSL, M_SD_FLAT, M_SD_DEPTH, M_SD_NOSHADOW, M_SD_SHADOWONLY, M_SD_NORECV, M_SD_NOLOBE, M_SD_MIRRORONLY, N_MATS };
 enum { SLOT_A = 0, SLOT_B, SLOT_C, SLOT_D, N_SLOTS };
 
 static std::vector<Params> g_mat_params;
@@ -521,6 +521,8 @@ static void build_catalogue()
 	g_mat_params[M_SD_NOSHADOW] = {ps("type", "shinydiffusemat"), pv("color", 0.3, 0.6, 0.8), pf("diffuse_reflect", 0.9), ps("visibility", "no_shadows")};
 	g_mat_params[M_SD_SHADOWONLY] = {ps("type", "shinydiffusemat"), pv("color", 0.8, 0.3, 0.6), pf("diffuse_reflect", 0.9), ps("visibility", "shadow_only")};
 	g_mat_params[M_SD_NORECV] = {ps("type", "shinydiffusemat"), pv("color", 0.7, 0.7, 0.4), pf("diffuse_reflect", 0.9), pb("receive_shadows", false)};
+	g_mat_params[M_SD_NOLOBE] = {ps("type", "shinydiffusemat"), pv("color", 0.9, 0.4, 0.1), pf("diffuse_reflect", 0.0), pf("emit", 0.4)};      // nothing to sample: sample() returns Rgb(1) and leaves wi, w alone
+	g_mat_params[M_SD_MIRRORONLY] = {ps("type", "shinydiffusemat"), pv("color", 0.5, 0.5, 0.5), pv("mirror_color", 0.8, 0.9, 0.7), pf("diffuse_reflect", 0.0), pf("specular_reflect", 1.0)};
 	for(const Params &p : g_mat_params) g_mats.push_back(make_material(p));
 
 	// room
@@ -839,6 +841,17 @@ int main()
 		c.integrator = {ps("type", "directlighting"), pi("raydepth", 2), pb("caustics", false), pb("do_AO", false), pb("transpShad", true), pi("shadowDepth", 2), pb("bg_transp", true)};
 		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
 		c.srand_seed = 10; c.background[0] = 0.3; c.background[1] = 0.2; c.background[2] = 0.1;
+		cases.push_back(c);
+	}
+	{	// materials with nothing to sample (the path runs straight on with the previous direction and weight, integrator_path_tracer.cc:243-249) and with a
+		// mirror lobe alone; clipping planes on the camera (camera rays with tmin / tmax); path samples 2, five bounces, roulette from depth 3
+		Case c; c.name = "pt_degenerate_lobes_clip";
+		c.slot_mat[SLOT_A] = M_SD_NOLOBE; c.slot_mat[SLOT_B] = M_SD_MIRRORONLY; c.slot_mat[SLOT_C] = M_GLOSSY; c.slot_mat[SLOT_D] = M_SD_NOLOBE;
+		c.lights = {0, 1};
+		c.camera = {pf("nearClip", 3.05), pf("farClip", 5.3)};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 2), pi("bounces", 5), pi("russian_roulette_min_bounces", 2), pi("raydepth", 2), ps("caustic_type", "none")};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 12; c.background[0] = 0.2; c.background[1] = 0.1; c.background[2] = 0.3;
 		cases.push_back(c);
 	}
 

@@ -29,7 +29,8 @@ extern "C" {
 #define YAFGPU_FILM_PLANES   4   /* own, right, down, diagonal splat planes */
 
 enum { YAFGPU_MAT_SHINYDIFFUSE = 0, YAFGPU_MAT_GLOSSY = 1, YAFGPU_MAT_LIGHT = 2, YAFGPU_MAT_GLASS = 3, YAFGPU_MAT_MIRROR = 4,
-       YAFGPU_MAT_COATED_GLOSSY = 5 /* glossy's fields + mirror_color, mirror_strength, glass_ior = IOR, c_flags[0..2], n_bsdf */ };
+       YAFGPU_MAT_COATED_GLOSSY = 5, /* glossy's fields + mirror_color, mirror_strength, glass_ior = IOR, c_flags[0..2], n_bsdf */
+       YAFGPU_MAT_ROUGH_GLASS = 6 /* glass's fields (glass_ior, filter_color, mirror_color, fake_shadow, beer_sigma) + rg_a2: RoughGlassMaterial, material_rough_glass.cc */ };
 enum { YAFGPU_LIGHT_AREA = 0, YAFGPU_LIGHT_POINT = 1 };
 enum { YAFGPU_INTEGRATOR_PATH = 0, YAFGPU_INTEGRATOR_DIRECT = 1 };
 enum { YAFGPU_FILTER_BOX = 0, YAFGPU_FILTER_MITCHELL = 1, YAFGPU_FILTER_GAUSS = 2, YAFGPU_FILTER_LANCZOS = 3 };
@@ -80,6 +81,7 @@ typedef struct yafgpu_material
 	int32_t transp_bias_mult;
 	float transp_ior;              /* glass: the index getTransparency's fresnel sees — ior_, or the IOR shader's value alone (material_glass.cc:223, sic) */
 	float ior_base;                /* ior_ (the IOR shader adds to it, :258-262; coated_glossy: material_coated_glossy.cc:147) */
+	float rg_a2;                   /* rough_glass: a_2_ = alpha^2 of its GGX lobe, alpha = max(1e-4, min(alpha / 2, 1)) (material_rough_glass.cc:33-36, :362) */
 	float emit_strength;           /* emit_strength_ (emit() with a diffuse shader: colour * emit_strength_, :300) */
 	int32_t has_diffuse_refl;      /* the fields below are only set in a resolved per-hit copy of the record (mat_resolve) */
 	float diffuse_refl;

@@ -669,6 +669,47 @@ bool make_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, st
 	}
 	return true;
 }
+// RoughGlassMaterial::factory + ctor, material_rough_glass.cc:320-455, :33-48 (no dispersion, no shader nodes)
+bool make_rough_glass(yafaray_interface *yi, const ParamMap &p, yafgpu_material &m, std::vector<yafgpu_node> &nodes)
+{
+	float ior = 1.4f, filt = 0.f, alpha = 0.5f, disp = 0.f, fcol[3] = {1, 1, 1}, scol[3] = {1, 1, 1}, absorp[3] = {1, 1, 1}, wire = 0.f;
+	bool fake = false, recv = true; std::string vis = "normal", node; int add_depth = 0;
+	p.get("IOR", ior); p.getColor("filter_color", fcol); p.get("transmit_filter", filt); p.getColor("mirror_color", scol); p.get("alpha", alpha);
+	p.get("dispersion_power", disp); p.get("fake_shadows", fake); p.get("receive_shadows", recv); p.get("visibility", vis);
+	p.get("additionaldepth", add_depth); p.get("wireframe_amount", wire); p.getColor("absorption", absorp);
+	if(disp > 0.f) return fail(yi, "rough_glass: dispersion is not supported by the GPU path (recursiveRaytrace's dispersive branch)");
+	if(add_depth < 0 || add_depth > 7) return fail(yi, "rough_glass: additionaldepth outside [0, 7]: the device path keeps at most 7 recursion frames per sample");
+	if(wire != 0.f) return fail(yi, "rough_glass: wireframe shading is not supported by the GPU path");
+	for(const char *name : {"mirror_color_shader", "bump_shader", "filter_color_shader", "IOR_shader", "wireframe_shader", "roughness_shader"})
+		if(p.get(name, node)) return fail(yi, std::string("rough_glass: ") + name + " is not supported by the GPU path (shader nodes on rough glass)");
+	std::memset(&m, 0, sizeof m);
+	clear_shader_slots(m);
+	nodes.clear();
+	alpha = std::max(1e-4f, std::min(alpha * 0.5f, 1.f));          // :375
+	m.type = YAFGPU_MAT_ROUGH_GLASS; m.receive_shadows = recv; m.visibility = visibility_from(vis);
+	m.additional_depth = add_depth;
+	m.glass_ior = ior; m.ior_base = ior; m.transp_ior = ior;
+	m.rg_a2 = alpha * alpha;
+	const float fc = 1.f - filt;                                   // filt * filt_col + Rgb(1.f - filt), floats here (:323)
+	for(int k = 0; k < 3; ++k) { m.filter_color[k] = filt * fcol[k] + fc; m.mirror_color[k] = scol[k]; }
+	m.fake_shadow = fake;
+	m.bsdf_flags = 0x2u | 0x10u | 0x20u;                           // BsdfAllGlossy
+	if(fake) m.bsdf_flags |= 0x40u;
+	if(absorp[0] < 1.f || absorp[1] < 1.f || absorp[2] < 1.f)
+	{	// :389-412: vol_i_ = BeerVolumeHandler(absorption, absorption_dist); volumehandler_beer.cc:28-35
+		double dist = 1.0;
+		p.get("absorption_dist", dist);
+		const float maxlog = (float)std::log(1e38);
+		for(int k = 0; k < 3; ++k)
+		{
+			m.beer_sigma[k] = (absorp[k] > 1e-38) ? (float)-std::log((double)absorp[k]) : maxlog;
+			if(dist != 0.f) m.beer_sigma[k] = m.beer_sigma[k] * (float)(1.f / dist);
+		}
+		m.has_vol_i = 1;
+		m.bsdf_flags |= 0x100u;                                   // BsdfVolumetric
+	}
+	return true;
+}
 // MirrorMaterial::factory + ctor, material_glass.cc:486-493, material_glass.h:74-79
 bool make_mirror(const ParamMap &p, yafgpu_material &m)
 {
@@ -1099,6 +1140,7 @@ yafaray_material_t *yafaray_createMaterial(yafaray_interface_t *yi, const char *
 	else if(type == "glossy") ok = make_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "light_mat") ok = make_lightmat(yi->params, m->m);
 	else if(type == "glass") ok = make_glass(yi, yi->params, m->m, m->nodes);
+	else if(type == "rough_glass") ok = make_rough_glass(yi, yi->params, m->m, m->nodes);
 	else if(type == "coated_glossy") ok = make_coated_glossy(yi, yi->params, m->m, m->nodes);
 	else if(type == "mirror") ok = make_mirror(yi->params, m->m);
 	else { fail(yi, "createMaterial: material type \"" + type + "\" is outside the GPU path's scope (shinydiffusemat, glossy, coated_glossy, glass, mirror, light_mat)"); return nullptr; }

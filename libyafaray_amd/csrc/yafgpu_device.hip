@@ -1079,6 +1079,21 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const DevScene sc, int op
 			}
 			break;
 		}
+		case 16:
+		{	// the two-direction Material::sample of recursiveRaytrace's glossy branch (rough glass): op 11's 16 words in,
+			// dir[0], ret, w[0], dir[1], tcol, w[1], pdf, sampled flags out
+			const yafgpu_material &m = sc.mats[__float_as_uint(x[0])];
+			if(m.type != YAFGPU_MAT_ROUGH_GLASS || n_out < 16) break;
+			SurfPt sp; sp.n = mk(x[1], x[2], x[3]); sp.ng = mk(x[4], x[5], x[6]); sp.p = mk(0.f, 0.f, 0.f); sp.mat = 0;
+			create_cs(sp.n, sp.nu, sp.nv);
+			const V3 wo = mk(x[7], x[8], x[9]);
+			BsdfSample bs; bs.s_1 = x[13]; bs.s_2 = x[14]; bs.pdf = 0.f; bs.flags = __float_as_uint(x[15]); bs.sampled = kNone;
+			V3 d0 = mk(0.f, 0.f, 0.f), d1 = d0; Col tcol = mkc(0.f, 0.f, 0.f); float w0 = 0.f, w1 = 0.f;
+			const Col ret = rough_glass_sample(m, sp, wo, bs, true, d0, w0, d1, tcol, w1);
+			o[0] = d0.x; o[1] = d0.y; o[2] = d0.z; o[3] = ret.r; o[4] = ret.g; o[5] = ret.b; o[6] = w0;
+			o[7] = d1.x; o[8] = d1.y; o[9] = d1.z; o[10] = tcol.r; o[11] = tcol.g; o[12] = tcol.b; o[13] = w1; o[14] = bs.pdf; o[15] = __uint_as_float(bs.sampled);
+			break;
+		}
 		default: break;
 	}
 }
@@ -1131,6 +1146,7 @@ struct yafgpu_scene
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
 	int max_add_depth = 0;               // the largest Material::additional_depth_ of the scene: recursion frames beyond raydepth
+	bool has_glossy_two = false;         // rough glass: a glossy trajectory sends two rays (the replay's call count)
 	bool has_glossy = false;             // some material has a glossy lobe that recursiveRaytrace samples (glossy / coated_glossy with as_diffuse off): 12-record frames
 	bool has_aniso = false;              // some material has the anisotropic glossy lobe: the general shading kernel
 	bool has_bump = false;               // some material has a bump shader: the shading frame is parked per vertex (records 24 / 25, frame record 12)
@@ -1229,12 +1245,15 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 		if(d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_materials) return fail(-3, "triangle material index out of range");
 	for(int i = 0; i < d->n_materials; ++i)
 	{
-		// recursiveRaytrace (integrator_montecarlo.cc:782-1028): the perfect specular branch and the glossy branch for materials
-		// that reflect only are on the device path; the dispersive branch and the reflect + transmit glossy case (rough glass) are not
+		// recursiveRaytrace (integrator_montecarlo.cc:782-1028): the perfect specular branch and both cases of the glossy branch (reflect
+		// only; reflect + transmit, which is rough glass and nothing else) are on the device path; the dispersive branch is not
+		if(d->materials[i].type < 0 || d->materials[i].type > YAFGPU_MAT_ROUGH_GLASS) return fail(-3, "material " + std::to_string(i) + ": unknown type");
 		if(d->materials[i].bsdf_flags & kDispersive)
 			return fail(-4, "material with a dispersive lobe needs recursiveRaytrace's dispersive branch, which the GPU path does not implement");
-		if((d->materials[i].bsdf_flags & kGlossy) && (d->materials[i].bsdf_flags & kTransmit))
-			return fail(-4, "material with a glossy transmission lobe (rough glass) needs the reflect + transmit case of recursiveRaytrace's glossy branch, which the GPU path does not implement");
+		if((d->materials[i].bsdf_flags & kGlossy) && (d->materials[i].bsdf_flags & kTransmit) && d->materials[i].type != YAFGPU_MAT_ROUGH_GLASS)
+			return fail(-4, "a glossy transmission lobe on a material that is not rough glass: the reflect + transmit case of recursiveRaytrace's glossy branch takes RoughGlassMaterial's two-direction sample");
+		if(d->materials[i].type == YAFGPU_MAT_ROUGH_GLASS && !(d->materials[i].rg_a2 > 0.f))
+			return fail(-3, "rough glass material " + std::to_string(i) + ": rg_a2 (alpha squared) must be positive");
 	}
 	auto *s = new yafgpu_scene();
 	{	// What the scene's materials ask of the pipeline — recursion frames, the glossy loop's wider frames, extra depth, the transparent-shadow
@@ -1252,7 +1271,8 @@ int yafgpu_scene_create(const yafgpu_scene_desc *d, yafgpu_scene_t **out)
 			if(m.anisotropic) s->has_aniso = true;
 			s->max_add_depth = std::max(s->max_add_depth, std::min(std::max(m.additional_depth, 0), 15));
 			if(m.bsdf_flags & kGlossy) s->has_glossy = true;
-			if((m.type == YAFGPU_MAT_SHINYDIFFUSE && m.is_transparent) || (m.type == YAFGPU_MAT_GLASS && m.fake_shadow)) s->has_transparent = true;
+			if(m.type == YAFGPU_MAT_ROUGH_GLASS) s->has_glossy_two = true;
+			if((m.type == YAFGPU_MAT_SHINYDIFFUSE && m.is_transparent) || ((m.type == YAFGPU_MAT_GLASS || m.type == YAFGPU_MAT_ROUGH_GLASS) && m.fake_shadow)) s->has_transparent = true;
 		}
 	}
 	const auto t0 = std::chrono::steady_clock::now();
@@ -1713,10 +1733,11 @@ static ReplayPlan replay_plan(const yafgpu_scene *s, const yafgpu_render_params 
 	p.need_lc = path && s->n_lights > 1;
 	// integrate() calls one camera sample can make (WfArgs::ev_m): without glossy-recursive materials every call sends at most a
 	// reflected and a transmitted ray, frames levels deep; with them a call whose trajectory splitting is still 1 also sends 8 glossy
-	// trajectories, whose calls (division >= 8: one trajectory each) send at most 3.  The ordinal has 8 bits.
+	// trajectories (two rays each through rough glass), whose calls (division >= 8: one trajectory each) send at most 3.  The ordinal has 8 bits.
 	{
 		long long t = 1, g = 1;
-		for(int k = 0; k < p.frames; ++k) { const long long t2 = s->has_glossy ? 1 + 8 * g + 2 * t : 1 + 2 * t; g = 1 + 3 * g; t = std::min<long long>(t2, 1 << 20); }
+		const long long per_traj = s->has_glossy_two ? 2 : 1;
+		for(int k = 0; k < p.frames; ++k) { const long long t2 = s->has_glossy ? 1 + 8 * per_traj * g + 2 * t : 1 + 2 * t; g = 1 + 3 * g; t = std::min<long long>(t2, 1 << 20); }
 		p.ev_m = (int)t;
 	}
 	p.replay = rp.serial_replay != 0 && p.ev_m <= 255 && (p.need_rr || p.need_lc);
@@ -2035,7 +2056,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 			a.q_closest_out = qset[1][0]; a.q_shadow_out = qset[1][1]; a.q_resume_out = qset[1][2];
 			if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_generate, dim3(g_gen), dim3(kBlock), 0, stream, a); }))) return rc;
 			int cur = 0;
-			const int iter_cap = n_iters * (frames > 0 ? (1 << (frames + 1)) : 1) * (s->has_glossy ? 16 : 1);      // (a safety net: the loop ends when the queues are empty)
+			const int iter_cap = n_iters * (frames > 0 ? (1 << (frames + 1)) : 1) * (s->has_glossy ? (s->has_glossy_two ? 32 : 16) : 1);      // (a safety net: the loop ends when the queues are empty)
 			for(int it = 0; it < iter_cap; ++it)
 			{
 				if(frames > 0 && it >= n_iters)

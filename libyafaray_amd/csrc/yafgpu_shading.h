@@ -22,7 +22,7 @@ namespace yafgpu {
 // Material types this compilation of the shading code handles: a kernel built for scenes without some material types
 // (YAFGPU_MAT_MASK, one bit per YAFGPU_MAT_*) drops their code and the registers it would pin.
 #ifndef YAFGPU_MAT_MASK
-#define YAFGPU_MAT_MASK 0x3fu
+#define YAFGPU_MAT_MASK 0x7fu
 #endif
 #define YG_IS(m, T) ((((YAFGPU_MAT_MASK) >> (T)) & 1u) != 0u && (m).type == (T))
 
@@ -430,7 +430,7 @@ YG_DEV float sd_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt &
 // shadows (material_glass.cc:217-228); Material's default: opaque
 YG_DEV bool mat_is_transparent(const yafgpu_material &m)
 {
-	return (YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE) && m.is_transparent) || (YG_IS(m, YAFGPU_MAT_GLASS) && m.fake_shadow);
+	return (YG_IS(m, YAFGPU_MAT_SHINYDIFFUSE) && m.is_transparent) || ((YG_IS(m, YAFGPU_MAT_GLASS) || YG_IS(m, YAFGPU_MAT_ROUGH_GLASS)) && m.fake_shadow);
 }
 YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 {
@@ -446,7 +446,7 @@ YG_DEV Col mat_transparency(const yafgpu_material &m, const SurfPt &sp, V3 wo)
 		const Col tcol = col3(m.diffuse_color) * f + mkc(1.f - f, 1.f - f, 1.f - f);
 		return tcol * accum;
 	}
-	if(YG_IS(m, YAFGPU_MAT_GLASS))
+	if(YG_IS(m, YAFGPU_MAT_GLASS) || YG_IS(m, YAFGPU_MAT_ROUGH_GLASS))      // material_glass.cc:217-228, material_rough_glass.cc:288-299
 	{
 		const V3 n = face_forward(sp.ng, sp.n, wo);
 		float kr, kt;
@@ -468,6 +468,11 @@ YG_DEV float mat_alpha(const yafgpu_material &m, const BsdfDat &d, const SurfPt 
 		const Col t = col3(m.filter_color) * kt;
 		const float alpha = (float)(1.0 - (double)((t.r + t.g + t.b) * 0.333333f));
 		return alpha < 0.f ? 0.f : alpha;
+	}
+	if(YG_IS(m, YAFGPU_MAT_ROUGH_GLASS))
+	{	// material_rough_glass.cc:301-310: max(0, min(1, 1 - getTransparency().energy()))
+		const Col t = mat_transparency(m, sp, wo);
+		return smax(0.f, smin(1.f, 1.f - (t.r + t.g + t.b) * 0.333333f));
 	}
 	return 1.f;
 }
@@ -552,10 +557,139 @@ YG_DEV void mat_get_specular(const yafgpu_material &m, const BsdfDat &d, const S
 	}
 }
 
+// GGX microfacet helpers, material_utils_microfacet.h:108-185
+YG_DEV V3 ggx_sample(float alpha_2, float s_1, float s_2)                                // :111-121
+{
+	const float tan_theta_2 = alpha_2 * (s_1 / (1.00001f - s_1));
+	const float cos_theta = 1.f / f_sqrt(1.f + tan_theta_2);
+	const float sin_theta = f_sqrt(1.00001f - (cos_theta * cos_theta));
+	const float phi = (float)(k2Pi * (double)s_2);
+	return mk(sin_theta * f_cos(phi), sin_theta * f_sin(phi), cos_theta);
+}
+YG_DEV float ggx_d(float alpha_2, float cos_theta_2, float tan_theta_2)                 // :123-129: M_PI makes the divisor a double product
+{
+	const float cos_theta_4 = cos_theta_2 * cos_theta_2;
+	const float a_tan = alpha_2 + tan_theta_2;
+	const float div = (float)(((kPi * (double)cos_theta_4) * (double)a_tan) * (double)a_tan);
+	return alpha_2 / div;
+}
+YG_DEV float ggx_g(float alpha_2, float wo_n, float wi_n)                                // :131-143
+{
+	const float wo_n_2 = wo_n * wo_n, wi_n_2 = wi_n * wi_n;
+	const float sqr_term_1 = f_sqrt(1.f + alpha_2 * ((1.f - wo_n_2) / wo_n_2));
+	const float sqr_term_2 = f_sqrt(1.f + alpha_2 * ((1.f - wi_n_2) / wi_n_2));
+	const float g_1_wo = 2.f / (1.f + (sqr_term_1));
+	const float g_1_wi = 2.f / (1.f + (sqr_term_2));
+	return g_1_wo * g_1_wi;
+}
+YG_DEV float ggx_pdf(float d, float cos_theta, float jacobian) { return d * cos_theta * jacobian; }      // :145-148
+YG_DEV float microfacet_fresnel(float wo_h, float ior)                                   // :150-162
+{
+	const float c = fabsf(wo_h);
+	float g = ior * ior - 1.f + c * c;
+	if(g > 0.f)
+	{
+		g = f_sqrt(g);
+		const float a = (g - c) / (g + c);
+		const float b = (c * (g + c) - 1.f) / (c * (g - c) + 1.f);
+		return 0.5f * a * a * (1.f + b * b);
+	}
+	return 1.0f;
+}
+YG_DEV bool refract_microfacet(float eta, V3 wo, V3 &wi, V3 h, float wo_h, float &kr, float &kt)      // :164-179
+{
+	wi = mk(0.f, 0.f, 0.f);
+	const float c = dot(-wo, h);
+	const float sign = (c > 0.f) ? 1.f : -1.f;
+	const float t_1 = 1.f - (eta * eta * (1.f - c * c));
+	if(t_1 < 0.f) return false;
+	wi = wo * eta + h * (eta * c - sign * f_sqrt(t_1));
+	wi = -wi;
+	kr = 0.f; kt = 0.f;
+	kr = microfacet_fresnel(wo_h, 1.f / eta);
+	if(kr == 1.f) return false;
+	kt = 1.f - kr;
+	return true;
+}
+YG_DEV V3 reflect_microfacet(V3 wo, V3 h) { const V3 wi = wo + h * (2.f * dot(h, -wo)); return -wi; }      // :181-185
+// RoughGlassMaterial::sample, both forms (material_rough_glass.cc:62-163 one direction, :165-286 two): the half vector of the GGX lobe,
+// refraction and reflection about it.  two == false: the lobe is picked by s_1 against kt, (dir0, w0) out.  two == true: both directions —
+// the reference writes the TRANSMITTED one to dir[0] / w[0] with the returned colour and the REFLECTED one to dir[1] / w[1] with tcol, which
+// recursiveRaytrace then reads the other way round (integrator_montecarlo.cc:925-958): restated as it is.
+YG_MAT Col rough_glass_sample(const yafgpu_material &m, const SurfPt &sp, V3 wo, BsdfSample &s, bool two, V3 &dir0, float &w0, V3 &dir1, Col &tcol, float &w1)
+{
+	const V3 n = face_forward(sp.ng, sp.n, wo);
+	const bool outside = dot(sp.ng, wo) > 0.f;
+	s.pdf = 1.f;
+	const float alpha_2 = m.rg_a2;
+	V3 h = ggx_sample(alpha_2, s.s_1, s.s_2);
+	h = (sp.nu * h.x + sp.nv * h.y) + n * h.z;
+	h = normalize(h);
+	const float cur_ior = m.glass_ior;
+	float glossy, glossy_d = 0.f, glossy_g = 0.f, wi_n, wi_h, jacobian = 0.f;
+	const float cos_theta = dot(h, n);
+	const float cos_theta_2 = cos_theta * cos_theta;
+	const float tan_theta_2 = (1.f - cos_theta_2) / smax(1.0e-8f, cos_theta_2);
+	if(cos_theta > 0.f) glossy_d = ggx_d(alpha_2, cos_theta_2, tan_theta_2);
+	const float wo_h = dot(wo, h), wo_n = dot(wo, n);
+	float kr, kt;
+	Col ret = mkc(0.f, 0.f, 0.f);
+	V3 wi;
+	if(two) s.sampled = 0u;
+	if(refract_microfacet(outside ? 1.f / cur_ior : cur_ior, wo, wi, h, wo_h, kr, kt))
+	{
+		const bool take_t = two ? (s.flags & kTransmit) != 0u : (s.s_1 < kt && (s.flags & kTransmit) != 0u);
+		if(take_t)
+		{
+			wi_n = dot(wi, n); wi_h = dot(wi, h);
+			if((wi_h * wi_n) > 0.f && (wo_h * wo_n) > 0.f) glossy_g = ggx_g(alpha_2, wi_n, wo_n);
+			float ior_wi = 1.f, ior_wo = 1.f;
+			if(outside) ior_wi = cur_ior; else ior_wo = cur_ior;
+			const float ht = ior_wo * wo_h + ior_wi * wi_h;
+			jacobian = (ior_wi * ior_wi) / smax(1.0e-8f, ht * ht);
+			glossy = fabsf((wo_h * wi_h) / (wi_n * wo_n)) * kt * glossy_g * glossy_d * jacobian;
+			s.pdf = ggx_pdf(glossy_d, cos_theta, jacobian * fabsf(wi_h));
+			s.sampled = kGlossy | kTransmit;
+			ret = col3(m.filter_color) * glossy;
+			w0 = fabsf(wi_n) / smax(0.1f, s.pdf);
+			dir0 = wi;
+		}
+		if(two ? (s.flags & kReflect) != 0u : (!take_t && (s.flags & kReflect) != 0u))
+		{
+			wi = reflect_microfacet(wo, h);
+			wi_n = dot(wi, n); wi_h = dot(wi, h);
+			glossy_g = ggx_g(alpha_2, wi_n, wo_n);
+			jacobian = 1.f / smax(1.0e-8f, (4.f * fabsf(wi_h)));
+			glossy = (kr * glossy_g * glossy_d) / smax(1.0e-8f, (4.f * fabsf(wo_n * wi_n)));
+			s.pdf = ggx_pdf(glossy_d, cos_theta, jacobian);
+			if(two) s.sampled |= kGlossy | kReflect; else s.sampled = kGlossy | kReflect;
+			const Col rc = col3(m.mirror_color) * glossy;
+			const float ww = fabsf(wi_n) / smax(0.1f, s.pdf);
+			if(two) { tcol = rc; w1 = ww; dir1 = wi; }
+			else { ret = rc; w0 = ww; dir0 = wi; }
+		}
+		else if(!two && !take_t) dir0 = wi;      // neither lobe asked for: wi is what refractMicrofacet__ left, w untouched
+	}
+	else
+	{	// total inner reflection about the half vector
+		wi = vec_reflect(wo, h);
+		if(two) s.sampled |= kGlossy | kReflect; else s.sampled = kGlossy | kReflect;
+		dir0 = wi;
+		ret = mkc(1.f, 1.f, 1.f);
+		w0 = 1.f;
+	}
+	return ret;
+}
+
 // Material::sample — material_shiny_diffuse.cc:308-408, material_glossy.cc:176-357 (Blinn branch),
 // material_simple.cc:41-46
 YG_MAT Col mat_sample(const yafgpu_material &m, const BsdfDat &d, const SurfPt &sp, V3 wo, V3 &wi, BsdfSample &s, float &w)
 {
+	if(YG_IS(m, YAFGPU_MAT_ROUGH_GLASS))
+	{
+		V3 d1 = wi; Col tc = mkc(0.f, 0.f, 0.f); float w1 = w;
+		return rough_glass_sample(m, sp, wo, s, false, wi, w, d1, tc, w1);
+	}
 	if(YG_IS(m, YAFGPU_MAT_GLASS))
 	{	// GlassMaterial::sample, material_glass.cc:65-215, the branch without dispersion (:143-213)
 		if(!(s.flags & kSpecular)) { s.pdf = 0.f; return mkc(0.f, 0.f, 0.f); }

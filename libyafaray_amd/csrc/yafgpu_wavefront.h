@@ -975,10 +975,17 @@ YG_DEV int st_recurse_spec(const WfArgs &a, uint32_t slot, Ctl &c)
 	c.level = L + 1;
 	return W_PARK_CLOSEST;
 }
-// recursiveRaytrace's glossy branch (:861-972) for materials that reflect only (:897-918): gsam trajectories through the glossy
-// lobe, each a full integrate() one level down under the trajectory-splitting state of frame record 5.  The loop lives in the
-// frame (flag 16 in F2.w): F6 normal | ns, gsam   F7 geometric normal | bsdf flags   F8 wo | integrate()'s w   F9 gcol | material
-// F10 the sample's colour | weight   F11 texture coordinates of the hit (tri, bu, bv)   F12 (bump mapping) the hit's nu | bumped
+// recursiveRaytrace's glossy branch (:861-972): gsam trajectories through the glossy lobe, each a full integrate() one level down
+// under the trajectory-splitting state of frame record 5 — one per trajectory for materials that reflect only (:897-918), two for
+// those that reflect and transmit (rough glass, :919-959).  The loop lives in the frame (flag 16 in F2.w):
+// F6 normal | ns, gsam, kGl* bits   F7 geometric normal | bsdf flags   F8 wo | integrate()'s w   F9 gcol | material
+// F10 the (first) sample's colour | weight   F11 texture coordinates of the hit (tri, bu, bv)   F12 (bump mapping) the hit's nu | bumped
+// two directions: F1.x the material's alpha   F3 the second direction | the tmax_ of the ray that is out   F4 its colour | weight
+enum : uint32_t { kGlSecond = 1u << 16,      // a second direction waits in F3 / F4
+                  kGlOnSecond = 1u << 17,    // the ray that is out is the second one
+                  kGlVolFirst = 1u << 18, kGlVolSecond = 1u << 19,      // that ray runs inside the absorbing material (:935, :949)
+                  kGlTwo = 1u << 20,         // the two-direction form (factor association :940, :954)
+                  kGlBits = 0x1fu << 16 };
 YG_DEV int st_glossy_begin(const WfArgs &a, uint32_t slot, Ctl &c)
 {
 	const int L = c.level;
@@ -1001,7 +1008,7 @@ YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
 	const int L = c.level;
 	const float4 f2 = FREC(L, 2), f6 = FREC(L, 6), f7 = FREC(L, 7);
-	const int ns = (int)(ubits(f6.w) & 0xffu), gsam = (int)(ubits(f6.w) >> 8);
+	const int ns = (int)(ubits(f6.w) & 0xffu), gsam = (int)((ubits(f6.w) >> 8) & 0xffu);
 	SurfPt sp0; make_sp(v3(f2), v3(f6), v3(f7), (int)ubits(FREC(L, 9).w), sp0);
 	if(YAFGPU_FEAT_TEXTURE && sc.tex.has_bump) wf_frame_set(sp0, FREC(L, 12));
 	const V3 wo0 = v3(FREC(L, 8));
@@ -1027,6 +1034,24 @@ YG_DEV int st_glossy_next(const WfArgs &a, uint32_t slot, Ctl &c, uint32_t pixel
 	BsdfSample bs; bs.s_1 = s_1; bs.s_2 = s_2; bs.pdf = 0.f; bs.sampled = kNone; bs.flags = kGlossy | kReflect;
 	float w = 0.f;
 	V3 wi = mk(0.f, 0.f, 0.f);
+	if(YG_IS(*mp, YAFGPU_MAT_ROUGH_GLASS))
+	{	// :919-959 Reflect and Transmit: dir[0] goes out under the "reflect" test, dir[1] under the "transmit" one (both as the reference has them)
+		bs.flags = kGlossy | kReflect | kTransmit;
+		V3 d1 = mk(0.f, 0.f, 0.f); Col tcol = mkc(0.f, 0.f, 0.f); float w1 = 0.f;
+		const Col mcol = rough_glass_sample(*mp, sp0, wo0, bs, true, wi, w, d1, tcol, w1);
+		const bool vol = (ubits(f7.w) & kVolumetric) && mp->has_vol_i;
+		uint32_t bits = kGlTwo;
+		if(vol && dot(sp0.ng, wi) < 0.f) bits |= kGlVolFirst;
+		if(bs.sampled & kTransmit) { bits |= kGlSecond; if(vol && dot(sp0.ng, d1) < 0.f) bits |= kGlVolSecond; }
+		FREC(L, 6) = f4(v3(f6), fbits((ubits(f6.w) & ~kGlBits) | bits));
+		FREC(L, 10) = f4(mcol, w);
+		FREC(L, 3) = f4(d1, 0.f);
+		FREC(L, 4) = f4(tcol, w1);
+		if(ns == 0) FREC(L, 1) = make_float4(mat_alpha(*mp, dat0, sp0, wo0), 0.f, 0.f, 0.f);
+		wf_start_level(a, slot, c, sp0.p, wi);      // (sampled_flags_ has Reflect on every way out of the sample: the first ray always goes)
+		c.level = L + 1;
+		return W_PARK_CLOSEST;
+	}
 	const Col mcol = mat_sample(*mp, dat0, sp0, wo0, wi, bs, w);
 	FREC(L, 10) = f4(mcol, w);
 	wf_start_level(a, slot, c, sp0.p, wi);
@@ -1058,13 +1083,36 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 		if(flags & 16u)
 		{	// a trajectory of the glossy loop is back: gcol += integ * mcol * w (:918), then the next one or the loop's end (:958)
 			const float4 f9 = FREC(P, 9), f10 = FREC(P, 10), f6 = FREC(P, 6);
-			const Col gcol = c3(f9) + (integ * c3(f10)) * f10.w;
-			const int ns = (int)(ubits(f6.w) & 0xffu) + 1, gsam = (int)(ubits(f6.w) >> 8);
+			const uint32_t gl = ubits(f6.w);
+			Col gcol;
+			float alpha_p = f0.w;
+			if(gl & kGlTwo)
+			{	// :932-956: integ *= vcol inside the absorbing material, gcol += integ * (mcol * w); the second ray's alpha is the level's
+				const bool second = (gl & kGlOnSecond) != 0u;
+				if(gl & (second ? kGlVolSecond : kGlVolFirst)) integ = integ * beer_transmittance(a.ra.sc.mats[ubits(f9.w)].beer_sigma, FREC(P, 3).w);
+				const float4 fs = second ? FREC(P, 4) : f10;
+				gcol = c3(f9) + integ * (c3(fs) * fs.w);
+				if(!second && (gl & kGlSecond))
+				{
+					FREC(P, 9) = f4(gcol, f9.w);
+					FREC(P, 6) = f4(v3(f6), fbits((gl & ~kGlSecond) | kGlOnSecond));
+					wf_start_level(a, slot, c, v3(f2), v3(FREC(P, 3)));
+					return W_PARK_CLOSEST;
+				}
+				if(second)
+				{	// :957 alpha = integ.a_, then integrator_path_tracer.cc:321-326 / integrator_direct_light.cc:165-170
+					const float m_alpha = FREC(P, 1).x;
+					alpha_p = rp.bg_transp_refract ? m_alpha + (1.f - m_alpha) * alpha : 1.f;
+				}
+			}
+			else gcol = c3(f9) + (integ * c3(f10)) * f10.w;
+			const int ns = (int)(gl & 0xffu) + 1, gsam = (int)((gl >> 8) & 0xffu);
 			c.level = P;
 			if(ns < gsam)
 			{
 				FREC(P, 9) = f4(gcol, f9.w);
 				FREC(P, 6) = f4(v3(f6), fbits((uint32_t)ns | ((uint32_t)gsam << 8)));
+				if(alpha_p != f0.w) FREC(P, 0) = f4(c3(f0), alpha_p);
 				return W_GLOSSY_NEXT;
 			}
 			c.col = c3(f0) + gcol * (1.f / (float)gsam);
@@ -1072,7 +1120,7 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 			REC(3) = f4(v3(f2), f9.w); REC(4) = f4(v3(f6), 0.f); REC(5) = FREC(P, 7); REC(6) = FREC(P, 8);
 			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.nodes != nullptr) REC(22) = FREC(P, 11);
 			if(YAFGPU_FEAT_TEXTURE && a.ra.sc.tex.has_bump) REC(24) = FREC(P, 12);
-			REC(19) = make_float4(0.f, 0.f, a.ev_m > 1 ? REC(19).z : 0.f, f0.w);
+			REC(19) = make_float4(0.f, 0.f, a.ev_m > 1 ? REC(19).z : 0.f, alpha_p);
 			return W_RECURSE_SPEC;
 		}
 		if(flags & ((flags & 2u) ? 8u : 4u))

@@ -41,6 +41,7 @@ class MaterialDesc(C.Structure):
         ("sh_glossy", C.c_int32), ("sh_glossy_reflect", C.c_int32), ("sh_exponent", C.c_int32), ("sh_filter_color", C.c_int32),
         ("additional_depth", C.c_int32), ("transp_bias_factor", C.c_float), ("transp_bias_mult", C.c_int32),
         ("n_bump_nodes", C.c_int32), ("sh_bump", C.c_int32), ("pad5", C.c_int32), ("bump_nodes", C.c_void_p),
+        ("rough_alpha", C.c_float), ("pad6", C.c_int32),
     ]
 
 
@@ -286,6 +287,7 @@ def lib():
     L.yor_material_probe.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp, fp,
                                      C.POINTER(C.c_int32), fp]
     L.yor_lightmat_emit.argtypes = [C.POINTER(MaterialDesc), fp, fp, C.c_int, fp]
+    L.yor_material_sample_two.argtypes = [C.POINTER(MaterialDesc), fp, C.c_int32, C.POINTER(C.c_int32), fp]
     L.yor_beer_transmittance.argtypes = [fp, C.c_double, C.c_float, C.POINTER(C.c_int32), fp]
     L.yor_set_trace.argtypes = [fp, C.c_uint64, fp, C.c_uint64, C.c_int]
     L.yor_trace_counts.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -308,7 +310,7 @@ def material_desc(m):
     # (material_shiny_diffuse.cc:627-646, material_glossy.cc:427-439, material_coated_glossy.cc, material_glass.cc:340-360);
     # MirrorMaterial::factory and LightMaterial::factory (material_glass.cc:486-493, material_simple.cc:63-73) leave the
     # Material defaults (normal, receiving); "flat_material" belongs to shinydiffuse alone
-    reads_flags = t in ("shinydiffusemat", "glossy", "coated_glossy", "glass")
+    reads_flags = t in ("shinydiffusemat", "glossy", "coated_glossy", "glass", "rough_glass")
     vis = {"normal": 0, "no_shadows": 1, "shadow_only": 2, "invisible": 3}[m.get("visibility", "normal")]
     d.visibility = vis if reads_flags else 0
     d.receive_shadows = int(m.get("receive_shadows", True)) if reads_flags else 1
@@ -366,6 +368,20 @@ def material_desc(m):
             d.absorption = f3(*m["absorption"][:3])
             d.has_absorption = 1
             d.absorption_dist = m.get("absorption_dist", 1.0)
+    elif t == "rough_glass":
+        d.type = 6
+        d.color = f3(*m.get("filter_color", (1, 1, 1))[:3])
+        d.mirror_color = f3(*m.get("mirror_color", (1, 1, 1))[:3])
+        d.ior = m.get("IOR", 1.4)
+        d.transmit_filter = m.get("transmit_filter", 0.0)
+        d.fresnel_effect = int(m.get("fake_shadows", False))
+        d.rough_alpha = m.get("alpha", 0.5)
+        if m.get("dispersion_power", 0.0) not in (0, 0.0):
+            raise ValueError("rough_glass: dispersion is outside the restated path")
+        if "absorption" in m:
+            d.absorption = f3(*m["absorption"][:3])
+            d.has_absorption = 1
+            d.absorption_dist = m.get("absorption_dist", 1.0)
     elif t == "mirror":
         d.type = 4
         d.color = f3(*m.get("color", (1, 1, 1))[:3])
@@ -379,7 +395,7 @@ def material_desc(m):
         raise ValueError(t)
     d.sh_diffuse = d.sh_mirror_color = d.sh_mirror = d.sh_transparency = d.sh_translucency = d.sh_sigma_oren = d.sh_diffuse_refl = d.sh_ior = -1
     d.sh_glossy = d.sh_glossy_reflect = d.sh_exponent = d.sh_filter_color = -1
-    if t in ("shinydiffusemat", "glossy", "coated_glossy", "glass"):
+    if t in ("shinydiffusemat", "glossy", "coated_glossy", "glass", "rough_glass"):
         d.additional_depth = m.get("additionaldepth", 0)
     if t == "shinydiffusemat":
         d.transp_bias_factor = m.get("transparentbias_factor", 0.0)

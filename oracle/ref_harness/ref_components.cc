@@ -40,6 +40,7 @@
 #include "material/material_shiny_diffuse.h"
 #include "material/material_glossy.h"
 #include "material/material_simple.h"
+#include "material/material_rough_glass.h"
 #include "volume/volumehandler_beer.h"
 
 using namespace yafaray4;
@@ -633,6 +634,69 @@ static void sec_beer(Json &j)
 	j.arr_u32("beer_in5", in); j.arr_u32("beer_out4", out);
 }
 
+// RoughGlassMaterial (material_rough_glass.cc): the GGX lobe that both reflects and transmits — one-direction sample() for path
+// segments, the two-direction sample() recursiveRaytrace's glossy branch calls (integrator_montecarlo.cc:919-970), getTransparency /
+// getAlpha / isTransparent for fake shadows.  Appended after every other section so that their random inputs stay what they were.
+static void run_rough_glass(Json &j, const char *prefix, Material *mat, int n_cases)
+{
+	run_material(j, prefix, mat, n_cases, true, 1);
+	alignas(16) static unsigned char userdata[4096];
+	RenderState state(nullptr);
+	state.userdata_ = (void *)userdata;
+	state.raylevel_ = 1;
+	std::vector<uint32_t> in, out;
+	std::vector<int> sflags_in, sflags_out;
+	for(int i = 0; i < n_cases; ++i)
+	{
+		SurfacePoint sp;
+		Vec3 n = rand_unit();
+		make_sp(sp, n, Point3(srand11(), srand11(), srand11()), (i % 4 == 3));
+		Vec3 wo = rand_unit();
+		if(i % 3 != 2 && (wo * sp.ng_) < 0.f) wo = -wo;      // a third of the rays leave the glass
+		float s_1 = urand(), s_2 = urand();
+		Bsdf_t bsdfs;
+		sp.material_ = mat;
+		mat->initBsdf(state, sp, bsdfs);
+		Bsdf_t sf = BsdfGlossy | BsdfAllGlossy;                // what the glossy branch asks for (:921)
+		if(i % 5 == 3) sf = BsdfGlossy | BsdfReflect;
+		if(i % 5 == 4) sf = BsdfGlossy | BsdfTransmit;
+		Sample s(s_1, s_2, sf);
+		Vec3 dir[2] = {Vec3(0.f), Vec3(0.f)};
+		Rgb tcol(0.f);
+		float w[2] = {0.f, 0.f};
+		Rgb ret = mat->sample(state, sp, wo, dir, tcol, s, w);
+		pushv(in, sp.n_); pushv(in, sp.ng_); pushv(in, wo); pushv(in, Vec3(0.f)); in.push_back(f2u(s_1)); in.push_back(f2u(s_2));
+		sflags_in.push_back((int)sf); sflags_out.push_back((int)s.sampled_flags_);
+		pushv(out, dir[0]); pushc(out, ret); out.push_back(f2u(w[0]));
+		pushv(out, dir[1]); pushc(out, tcol); out.push_back(f2u(w[1]));
+		out.push_back(f2u(s.pdf_));
+	}
+	std::string p(prefix);
+	j.arr_u32((p + "_two_in14").c_str(), in); j.arr_i32((p + "_two_sflags_in").c_str(), sflags_in); j.arr_i32((p + "_two_sflags_out").c_str(), sflags_out);
+	j.arr_u32((p + "_two_out15").c_str(), out);
+}
+static void sec_rough_glass(Json &j)
+{
+	std::list<ParamMap> no_nodes;
+	{	// rg0: moderately rough, tinted transmission and reflection
+		ParamMap pm;
+		pm["IOR"] = Parameter(1.5); pm["filter_color"] = Parameter(Rgba(0.7f, 0.9f, 0.8f, 1.f)); pm["transmit_filter"] = Parameter(0.7);
+		pm["mirror_color"] = Parameter(Rgba(0.95f, 0.9f, 1.f, 1.f)); pm["alpha"] = Parameter(0.3);
+		run_rough_glass(j, "rg0", RoughGlassMaterial::factory(pm, no_nodes, fake_env()), 240);
+	}
+	{	// rg1: very rough, high index, fake shadows (a filter lobe for transparent shadows)
+		ParamMap pm;
+		pm["IOR"] = Parameter(2.0); pm["filter_color"] = Parameter(Rgba(1.f, 0.6f, 0.5f, 1.f)); pm["transmit_filter"] = Parameter(0.4);
+		pm["alpha"] = Parameter(0.9); pm["fake_shadows"] = Parameter(true);
+		run_rough_glass(j, "rg1", RoughGlassMaterial::factory(pm, no_nodes, fake_env()), 160);
+	}
+	{	// rg2: nearly smooth (alpha clamps at 1e-4 * ... : factory takes max(1e-4, min(alpha / 2, 1)))
+		ParamMap pm;
+		pm["IOR"] = Parameter(1.33); pm["alpha"] = Parameter(0.0001);
+		run_rough_glass(j, "rg2", RoughGlassMaterial::factory(pm, no_nodes, fake_env()), 120);
+	}
+}
+
 int main()
 {
 	Json j;
@@ -645,6 +709,7 @@ int main()
 	sec_lights(j);
 	sec_materials(j);
 	sec_beer(j);
+	sec_rough_glass(j);
 	j.s += "\n}\n";
 	fputs(j.s.c_str(), stdout);
 	return 0;

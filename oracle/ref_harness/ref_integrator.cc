@@ -80,6 +80,7 @@
 #include "material/material_shiny_diffuse.h"
 #include "material/material_glossy.h"
 #include "material/material_simple.h"
+#include "material/material_rough_glass.h"
 #include "light/light_area.h"
 #include "light/light_point.h"
 #include "volume/volumehandler_beer.h"
@@ -430,6 +431,7 @@ static Material *make_material(const Params &ps_)
 	if(t == "coated_glossy") return CoatedGlossyMaterial::factory(m, no_nodes, fake_env());
 	if(t == "glass") return GlassMaterial::factory(m, no_nodes, fake_env());
 	if(t == "mirror") return MirrorMaterial::factory(m, no_nodes, fake_env());
+	if(t == "rough_glass") return RoughGlassMaterial::factory(m, no_nodes, fake_env());
 	if(t == "light_mat") return LightMaterial::factory(m, no_nodes, fake_env());
 	fprintf(stderr, "unknown material type %s\n", t.c_str());
 	exit(2);
@@ -479,7 +481,7 @@ static void box(double cx, double cy, double cz, double hx, double hy, double hz
 }
 
 enum { M_WHITE = 0, M_RED, M_GREEN_ON, M_LIGHT1, M_GLOSSY, M_SD_MIRROR_TRANSP, M_GLASS, M_COATED, M_GLOSSY_REC, M_MIRROR, M_SD_EMIT, M_LIGHT2, M_SD_TRANSP,
-       M_GLASS_ABS, M_GLASS_FAKE, M_ANISO, M_COATED_REC, M_SD_TRANSL, M_SD_FLAT, M_SD_DEPTH, M_SD_NOSHADOW, M_SD_SHADOWONLY, M_SD_NORECV, M_SD_NOLOBE, M_SD_MIRRORONLY, N_MATS };
+       M_GLASS_ABS, M_GLASS_FAKE, M_ANISO, M_COATED_REC, M_SD_TRANSL, M_SD_FLAT, M_SD_DEPTH, M_SD_NOSHADOW, M_SD_SHADOWONLY, M_SD_NORECV, M_SD_NOLOBE, M_SD_MIRRORONLY, M_ROUGH_GLASS, M_ROUGH_GLASS_ABS_FAKE, N_MATS };
 enum { SLOT_A = 0, SLOT_B, SLOT_C, SLOT_D, N_SLOTS };
 
 static std::vector<Params> g_mat_params;
@@ -523,6 +525,9 @@ static void build_catalogue()
 	g_mat_params[M_SD_NORECV] = {ps("type", "shinydiffusemat"), pv("color", 0.7, 0.7, 0.4), pf("diffuse_reflect", 0.9), pb("receive_shadows", false)};
 	g_mat_params[M_SD_NOLOBE] = {ps("type", "shinydiffusemat"), pv("color", 0.9, 0.4, 0.1), pf("diffuse_reflect", 0.0), pf("emit", 0.4)};      // nothing to sample: sample() returns Rgb(1) and leaves wi, w alone
 	g_mat_params[M_SD_MIRRORONLY] = {ps("type", "shinydiffusemat"), pv("color", 0.5, 0.5, 0.5), pv("mirror_color", 0.8, 0.9, 0.7), pf("diffuse_reflect", 0.0), pf("specular_reflect", 1.0)};
+	g_mat_params[M_ROUGH_GLASS] = {ps("type", "rough_glass"), pf("IOR", 1.5), pv("filter_color", 0.75, 0.9, 0.8), pf("transmit_filter", 0.6), pv("mirror_color", 0.95, 0.9, 1.0), pf("alpha", 0.35)};
+	g_mat_params[M_ROUGH_GLASS_ABS_FAKE] = {ps("type", "rough_glass"), pf("IOR", 1.33), pv("filter_color", 0.9, 0.7, 0.6), pf("transmit_filter", 0.5), pf("alpha", 0.15), pb("fake_shadows", true),
+	                                        pv("absorption", 0.6, 0.8, 0.5), pf("absorption_dist", 0.4)};
 	for(const Params &p : g_mat_params) g_mats.push_back(make_material(p));
 
 	// room
@@ -852,6 +857,17 @@ int main()
 		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 2), pi("bounces", 5), pi("russian_roulette_min_bounces", 2), pi("raydepth", 2), ps("caustic_type", "none")};
 		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
 		c.srand_seed = 12; c.background[0] = 0.2; c.background[1] = 0.1; c.background[2] = 0.3;
+		cases.push_back(c);
+	}
+	{	// rough glass: the reflect + transmit case of recursiveRaytrace's glossy branch (two trajectories per glossy sample), a box of it (rays inside:
+		// total inner reflection about the half vector) and an absorbing, fake-shadow sheet under transparent shadows; as a path vertex it is sampled through BsdfAll
+		Case c; c.name = "pt_rough_glass";
+		c.slot_mat[SLOT_A] = M_ROUGH_GLASS; c.slot_mat[SLOT_B] = M_WHITE; c.slot_mat[SLOT_C] = M_GLOSSY; c.slot_mat[SLOT_D] = M_ROUGH_GLASS_ABS_FAKE;
+		c.lights = {0, 2};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 1), pi("bounces", 3), pi("russian_roulette_min_bounces", 3), pi("raydepth", 2), ps("caustic_type", "none"),
+		                pb("transpShad", true), pi("shadowDepth", 3), pb("bg_transp_refract", true)};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 13; c.background[0] = 0.15; c.background[1] = 0.2; c.background[2] = 0.25;
 		cases.push_back(c);
 	}
 

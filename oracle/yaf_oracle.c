@@ -449,6 +449,7 @@ typedef struct
 	rgb light_col; int double_sided;
 	/* glass (material_glass.cc:32-49) and mirror (material_glass.h:74-79) */
 	float ior; rgb filter_color, spec_refl_color; int fake_shadow; unsigned tm_flags;
+	float rg_a2;                          /* rough glass: a_2_ = alpha^2 of the GGX lobe (material_rough_glass.cc:33-36) */
 	rgb ref_col;
 	/* shader nodes: the list in evaluation order and the node each slot reads (-1: none) */
 	int n_nodes; struct node_s *nodes;
@@ -1858,6 +1859,27 @@ static void mat_configure_(mat_t *m, const yor_material_desc *d)
 			m->beer_sigma = beer_sigma(d->absorption, d->absorption_dist);
 		}
 	}
+	else if(d->type == YOR_MAT_ROUGH_GLASS)
+	{	/* RoughGlassMaterial::factory + ctor, material_rough_glass.cc:33-48, 322-400 (no dispersion, no nodes) */
+		m->ior = d->ior; m->transp_ior = d->ior;
+		m->sh_diffuse = m->sh_mirror_color = m->sh_mirror = m->sh_transparency = m->sh_translucency = m->sh_sigma_oren = m->sh_diffuse_refl = m->sh_ior = -1;
+		m->sh_glossy = m->sh_glossy_reflect = m->sh_exponent = m->sh_filter_color = -1;
+		const float filt = d->transmit_filter;                            /* a float parameter here (:324); glass reads a double */
+		const float fc = 1.f - filt;                                      /* filt * filt_col + Rgb(1.f - filt) */
+		m->filter_color = C(filt * d->color[0] + fc, filt * d->color[1] + fc, filt * d->color[2] + fc);
+		m->spec_refl_color = C(d->mirror_color[0], d->mirror_color[1], d->mirror_color[2]);
+		m->fake_shadow = d->fresnel_effect;
+		const float alpha = fmaxf_(1e-4f, fminf_(d->rough_alpha * 0.5f, 1.f));      /* :362 */
+		m->rg_a2 = alpha * alpha;
+		m->flags = BSDF_GLOSSY | BSDF_REFLECT | BSDF_TRANSMIT;            /* BsdfAllGlossy */
+		if(m->fake_shadow) m->flags |= BSDF_FILTER;
+		if(d->has_absorption && (d->absorption[0] < 1.f || d->absorption[1] < 1.f || d->absorption[2] < 1.f))
+		{	/* :370-398, as for glass */
+			m->flags |= BSDF_VOLUMETRIC;
+			m->has_vol_i = 1;
+			m->beer_sigma = beer_sigma(d->absorption, d->absorption_dist);
+		}
+	}
 	else if(d->type == YOR_MAT_MIRROR)
 	{	/* MirrorMaterial, material_glass.h:74-79, material_glass.cc:486-493 */
 		m->ref_col = cscale(C(d->color[0], d->color[1], d->color[2]), d->specular_reflect);
@@ -2361,7 +2383,7 @@ static rgb mat_transparency(const mat_t *m, const sp_t *sp, v3 wo)
 		rgb tcol = cadd(cscale(m->diffuse_color, f), C(1.f - f, 1.f - f, 1.f - f));
 		return cscale(tcol, accum);
 	}
-	if(m->type == YOR_MAT_GLASS)
+	if(m->type == YOR_MAT_GLASS || m->type == YOR_MAT_ROUGH_GLASS)      /* material_glass.cc:217-228, material_rough_glass.cc:288-299 */
 	{
 		v3 n = face_forward(sp->ng, sp->n, wo);
 		float kr, kt;
@@ -2373,6 +2395,7 @@ static rgb mat_transparency(const mat_t *m, const sp_t *sp, v3 wo)
 /* Material::isTransparent: ShinyDiffuse m_is_transparent_ (material_shiny_diffuse.h:53), Glass fake_shadow_ (material_glass.h) */
 static int mat_is_transparent(const mat_t *m)
 {
+	if(m->type == YOR_MAT_ROUGH_GLASS) return m->fake_shadow;      /* material_rough_glass.h:38 */
 	return (m->type == YOR_MAT_SHINYDIFFUSE && m->is_transparent) || (m->type == YOR_MAT_GLASS && m->fake_shadow);
 }
 static int mat_is_transparent_idx(const yor_scene *s, int mat) { return mat_is_transparent(&s->mats[mat]); }
@@ -2400,6 +2423,11 @@ static float mat_alpha(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 w
 {
 	if(m->type == YOR_MAT_SHINYDIFFUSE) return sd_alpha(m, dat, sp, wo);
 	if(m->type == YOR_MAT_GLASS) return glass_alpha(m, sp, wo);
+	if(m->type == YOR_MAT_ROUGH_GLASS)
+	{	/* material_rough_glass.cc:301-310: max(0, min(1, 1 - getTransparency().energy())) */
+		const rgb t = mat_transparency(m, sp, wo);
+		return fmaxf_(0.f, fminf_(1.f, 1.f - (t.r + t.g + t.b) * 0.333333f));
+	}
 	return 1.f;
 }
 /* raylevel: RenderState::raylevel_ as getSpecular sees it (recursiveRaytrace has already incremented it) */
@@ -2483,8 +2511,148 @@ static void mat_get_specular(const mat_t *m, const bsdf_dat *dat, const sp_t *sp
 	}
 }
 
+/* GGX microfacet helpers, material_utils_microfacet.h:108-185 */
+static inline v3 ggx_sample(float alpha_2, float s_1, float s_2)                       /* :111-121 */
+{
+	const float tan_theta_2 = alpha_2 * (s_1 / (1.00001f - s_1));
+	const float cos_theta = 1.f / yor_fsqrt(1.f + tan_theta_2);
+	const float sin_theta = yor_fsqrt(1.00001f - (cos_theta * cos_theta));
+	const float phi = (float)(Y_M_2PI * (double)s_2);
+	return V(sin_theta * yor_fcos(phi), sin_theta * yor_fsin(phi), cos_theta);
+}
+static inline float ggx_d(float alpha_2, float cos_theta_2, float tan_theta_2)        /* :123-129: M_PI makes the divisor a double product */
+{
+	const float cos_theta_4 = cos_theta_2 * cos_theta_2;
+	const float a_tan = alpha_2 + tan_theta_2;
+	const float div = (float)(((Y_M_PI * (double)cos_theta_4) * (double)a_tan) * (double)a_tan);
+	return alpha_2 / div;
+}
+static inline float ggx_g(float alpha_2, float wo_n, float wi_n)                       /* :131-143 */
+{
+	const float wo_n_2 = wo_n * wo_n, wi_n_2 = wi_n * wi_n;
+	const float sqr_term_1 = yor_fsqrt(1.f + alpha_2 * ((1.f - wo_n_2) / wo_n_2));
+	const float sqr_term_2 = yor_fsqrt(1.f + alpha_2 * ((1.f - wi_n_2) / wi_n_2));
+	const float g_1_wo = 2.f / (1.f + (sqr_term_1));
+	const float g_1_wi = 2.f / (1.f + (sqr_term_2));
+	return g_1_wo * g_1_wi;
+}
+static inline float ggx_pdf(float d, float cos_theta, float jacobian) { return d * cos_theta * jacobian; }      /* :145-148 */
+static inline float microfacet_fresnel(float wo_h, float ior)                          /* :150-162 */
+{
+	const float c = fabsf(wo_h);
+	float g = ior * ior - 1 + c * c;
+	if(g > 0)
+	{
+		g = yor_fsqrt(g);
+		const float a = (g - c) / (g + c);
+		const float b = (c * (g + c) - 1) / (c * (g - c) + 1);
+		return 0.5f * a * a * (1 + b * b);
+	}
+	return 1.0f;
+}
+static inline int refract_microfacet(float eta, v3 wo, v3 *wi, v3 h, float wo_h, float *kr, float *kt)      /* :164-179 */
+{
+	*wi = V(0, 0, 0);
+	const float c = vdot(vneg(wo), h);
+	const float sign = (c > 0.f) ? 1 : -1;
+	const float t_1 = 1 - (eta * eta * (1 - c * c));
+	if(t_1 < 0.f) return 0;
+	*wi = vadd(vmul(wo, eta), vmul(h, eta * c - sign * yor_fsqrt(t_1)));
+	*wi = vneg(*wi);
+	*kr = 0.f; *kt = 0.f;
+	*kr = microfacet_fresnel(wo_h, 1.f / eta);
+	if(*kr == 1.f) return 0;
+	*kt = 1 - *kr;
+	return 1;
+}
+static inline v3 reflect_microfacet(v3 wo, v3 h)                                       /* :181-185 */
+{
+	const v3 wi = vadd(wo, vmul(h, 2.f * vdot(h, vneg(wo))));
+	return vneg(wi);
+}
+static inline v3 vreflect(v3 v, v3 n)                                                  /* Vec3::reflect, vector.h:291-298 */
+{
+	const float vn = 2.0f * (v.x * n.x + v.y * n.y + v.z * n.z);
+	return V(vn * n.x - v.x, vn * n.y - v.y, vn * n.z - v.z);
+}
+/* RoughGlassMaterial::sample, both forms (material_rough_glass.cc:62-163 one direction, :165-286 two): the half vector of the GGX
+ * lobe, refraction and reflection about it.  two == 0: the lobe is picked by s_1 against kt, (wi, w) out.  two != 0: both
+ * directions — the reference writes the TRANSMITTED one to dir[0] / w[0] with the returned colour and the REFLECTED one to dir[1] /
+ * w[1] with tcol, which recursiveRaytrace then reads the other way round (:925-958): restated as it is. */
+static rgb rough_glass_sample(const mat_t *m, const sp_t *sp, v3 wo, sample_t *s, int two, v3 dir[2], rgb *tcol, float w[2])
+{
+	const v3 n = face_forward(sp->ng, sp->n, wo);
+	const int outside = vdot(sp->ng, wo) > 0.f;
+	s->pdf = 1.f;
+	const float alpha_2 = m->rg_a2;
+	v3 h = ggx_sample(alpha_2, s->s_1, s->s_2);
+	h = vadd(vadd(vmul(sp->nu, h.x), vmul(sp->nv, h.y)), vmul(n, h.z));
+	h = vnormalize(h);
+	const float cur_ior = m->ior;
+	float glossy, glossy_d = 0.f, glossy_g = 0.f, wi_n, wi_h, jacobian = 0.f;
+	const float cos_theta = vdot(h, n);
+	const float cos_theta_2 = cos_theta * cos_theta;
+	const float tan_theta_2 = (1.f - cos_theta_2) / fmaxf_(1.0e-8f, cos_theta_2);
+	if(cos_theta > 0.f) glossy_d = ggx_d(alpha_2, cos_theta_2, tan_theta_2);
+	const float wo_h = vdot(wo, h), wo_n = vdot(wo, n);
+	float kr, kt;
+	rgb ret = C(0, 0, 0);
+	v3 wi;
+	if(two) s->sampled_flags = 0;
+	if(refract_microfacet(outside ? 1.f / cur_ior : cur_ior, wo, &wi, h, wo_h, &kr, &kt))
+	{
+		const int take_t = two ? (s->flags & BSDF_TRANSMIT) != 0 : (s->s_1 < kt && (s->flags & BSDF_TRANSMIT));
+		if(take_t)
+		{
+			wi_n = vdot(wi, n); wi_h = vdot(wi, h);
+			if((wi_h * wi_n) > 0.f && (wo_h * wo_n) > 0.f) glossy_g = ggx_g(alpha_2, wi_n, wo_n);
+			float ior_wi = 1.f, ior_wo = 1.f;
+			if(outside) ior_wi = cur_ior; else ior_wo = cur_ior;
+			const float ht = ior_wo * wo_h + ior_wi * wi_h;
+			jacobian = (ior_wi * ior_wi) / fmaxf_(1.0e-8f, ht * ht);
+			glossy = fabsf((wo_h * wi_h) / (wi_n * wo_n)) * kt * glossy_g * glossy_d * jacobian;
+			s->pdf = ggx_pdf(glossy_d, cos_theta, jacobian * fabsf(wi_h));
+			s->sampled_flags = BSDF_GLOSSY | BSDF_TRANSMIT;
+			ret = cscale(m->filter_color, glossy);
+			w[0] = fabsf(wi_n) / fmaxf_(0.1f, s->pdf);
+			dir[0] = wi;
+		}
+		if(two ? (s->flags & BSDF_REFLECT) != 0 : (!take_t && (s->flags & BSDF_REFLECT)))
+		{
+			wi = reflect_microfacet(wo, h);
+			wi_n = vdot(wi, n); wi_h = vdot(wi, h);
+			glossy_g = ggx_g(alpha_2, wi_n, wo_n);
+			jacobian = 1.f / fmaxf_(1.0e-8f, (4.f * fabsf(wi_h)));
+			glossy = (kr * glossy_g * glossy_d) / fmaxf_(1.0e-8f, (4.f * fabsf(wo_n * wi_n)));
+			s->pdf = ggx_pdf(glossy_d, cos_theta, jacobian);
+			if(two) s->sampled_flags |= BSDF_GLOSSY | BSDF_REFLECT; else s->sampled_flags = BSDF_GLOSSY | BSDF_REFLECT;
+			const rgb rc = cscale(m->spec_refl_color, glossy);
+			const float ww = fabsf(wi_n) / fmaxf_(0.1f, s->pdf);
+			if(two) { *tcol = rc; w[1] = ww; dir[1] = wi; }
+			else { ret = rc; w[0] = ww; dir[0] = wi; }
+		}
+		else if(!two && !take_t) dir[0] = wi;      /* neither lobe asked for: wi is what refractMicrofacet__ left, w untouched */
+	}
+	else
+	{	/* total inner reflection about the half vector */
+		wi = vreflect(wo, h);
+		if(two) s->sampled_flags |= BSDF_GLOSSY | BSDF_REFLECT; else s->sampled_flags = BSDF_GLOSSY | BSDF_REFLECT;
+		dir[0] = wi;
+		ret = C(1.f, 1.f, 1.f);
+		w[0] = 1.f;
+	}
+	return ret;
+}
+
 static rgb mat_sample(const mat_t *m, const bsdf_dat *dat, const sp_t *sp, v3 wo, v3 *wi, sample_t *s, float *w)
 {
+	if(m->type == YOR_MAT_ROUGH_GLASS)
+	{
+		v3 dir[2] = {*wi, *wi}; rgb tcol; float ww[2] = {*w, *w};
+		const rgb ret = rough_glass_sample(m, sp, wo, s, 0, dir, &tcol, ww);
+		*wi = dir[0]; *w = ww[0];
+		return ret;
+	}
 	if(m->type == YOR_MAT_GLASS)
 	{	/* GlassMaterial::sample, material_glass.cc:65-215, the branch without dispersion (:143-213) */
 		if(!(s->flags & BSDF_SPECULAR)) { s->pdf = 0.f; return C(0, 0, 0); }
@@ -3475,6 +3643,30 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 					if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, wi) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
 					gcol = cadd(gcol, cscale(cmul(ic, mcol), gw));
 				}
+				else if((material->flags & BSDF_GLOSSY) && (material->flags & BSDF_REFLECT) && (material->flags & BSDF_TRANSMIT))
+				{	/* :919-970: a lobe that reflects and transmits (rough glass): the two-direction sample, an integrate() per direction it reports.
+					 * (dir[0] / mcol[0] / w[0] go with the `Reflect` test, dir[1] / mcol[1] / w[1] with `Transmit`, whatever the material put there.) */
+					sample_t sm; sm.s_1 = s_1; sm.s_2 = s_2; sm.pdf = 0.f; sm.flags = BSDF_GLOSSY | BSDF_REFLECT | BSDF_TRANSMIT; sm.sampled_flags = BSDF_NONE;
+					v3 gdir[2] = {V(0, 0, 0), V(0, 0, 0)}; rgb mcol[2] = {C(0, 0, 0), C(0, 0, 0)}; float gw[2] = {0.f, 0.f};
+					mcol[0] = rough_glass_sample(material, &sp, wo, &sm, 1, gdir, &mcol[1], gw);
+					if((sm.sampled_flags & BSDF_REFLECT) && !(sm.sampled_flags & BSDF_DISPERSIVE))
+					{
+						float integ[4], ref_tmax;
+						integrate_d(st, sp.p, gdir[0], st->ray_min_dist, -1.0f, raylevel + 1, additional_depth, integ, &ref_tmax);
+						rgb ic = C(integ[0], integ[1], integ[2]);
+						if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, gdir[0]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
+						gcol = cadd(gcol, cmul(ic, cscale(mcol[0], gw[0])));
+					}
+					if(sm.sampled_flags & BSDF_TRANSMIT)
+					{
+						float integ[4], ref_tmax;
+						integrate_d(st, sp.p, gdir[1], st->ray_min_dist, -1.0f, raylevel + 1, additional_depth, integ, &ref_tmax);
+						rgb ic = C(integ[0], integ[1], integ[2]);
+						if((bsdfs & BSDF_VOLUMETRIC) && vdot(sp.ng, gdir[1]) < 0 && material->has_vol_i) ic = cmul(ic, beer_transmittance(material->beer_sigma, ref_tmax));
+						gcol = cadd(gcol, cmul(ic, cscale(mcol[1], gw[1])));
+						alpha = integ[3];
+					}
+				}
 			}
 			col = cadd(col, cscale(gcol, d_1));
 			st->ray_division = old_division; st->ray_offset = old_offset; st->dc_1 = old_dc_1; st->dc_2 = old_dc_2;
@@ -4136,6 +4328,20 @@ void yor_material_probe(const yor_material_desc *md, const float in14[14], int32
 	rgb sc = mat_sample(&m, &dat, &sp, wo, &wi, &s, &w);
 	*sampled_flags = (int32_t)s.sampled_flags;
 	sample8[0] = sc.r; sample8[1] = sc.g; sample8[2] = sc.b; sample8[3] = wi.x; sample8[4] = wi.y; sample8[5] = wi.z; sample8[6] = s.pdf; sample8[7] = w;
+}
+void yor_material_sample_two(const yor_material_desc *md, const float in14[14], int32_t sample_flags, int32_t *sampled_flags, float out15[15])
+{
+	mat_t m; mat_configure(&m, md);
+	sp_t sp; memset(&sp, 0, sizeof sp);
+	sp.n = V(in14[0], in14[1], in14[2]); sp.ng = V(in14[3], in14[4], in14[5]);
+	create_cs(sp.n, &sp.nu, &sp.nv);
+	const v3 wo = V(in14[6], in14[7], in14[8]);
+	sample_t s; s.s_1 = in14[12]; s.s_2 = in14[13]; s.pdf = 0.f; s.flags = (unsigned)sample_flags; s.sampled_flags = BSDF_NONE;
+	v3 dir[2] = {V(0, 0, 0), V(0, 0, 0)}; rgb tcol = C(0, 0, 0), ret = C(0, 0, 0); float w[2] = {0.f, 0.f};
+	if(m.type == YOR_MAT_ROUGH_GLASS) ret = rough_glass_sample(&m, &sp, wo, &s, 1, dir, &tcol, w);
+	*sampled_flags = (int32_t)s.sampled_flags;
+	const float o[15] = {dir[0].x, dir[0].y, dir[0].z, ret.r, ret.g, ret.b, w[0], dir[1].x, dir[1].y, dir[1].z, tcol.r, tcol.g, tcol.b, w[1], s.pdf};
+	memcpy(out15, o, sizeof o);
 }
 void yor_material_transparency(const yor_material_desc *md, const float in14[14], float out3[3])
 {

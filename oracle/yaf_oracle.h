@@ -29,7 +29,8 @@ extern "C" {
 enum { YOR_MAT_SHINYDIFFUSE = 0, YOR_MAT_GLOSSY = 1, YOR_MAT_LIGHT = 2,
        YOR_MAT_GLASS = 3,   /* color = filter_color, mirror_color, ior = IOR, sigma = transmit_filter (double), fresnel_effect = fake_shadows */
        YOR_MAT_MIRROR = 4,  /* color, specular_reflect = reflect */
-       YOR_MAT_COATED_GLOSSY = 5 /* glossy's fields + mirror_color, specular_reflect = mirror strength, ior = IOR */ };
+       YOR_MAT_COATED_GLOSSY = 5, /* glossy's fields + mirror_color, specular_reflect = mirror strength, ior = IOR */
+       YOR_MAT_ROUGH_GLASS = 6 /* color = filter_color, mirror_color, ior = IOR, transmit_filter (float), fresnel_effect = fake_shadows, rough_alpha = alpha, absorption */ };
 enum { YOR_LIGHT_AREA = 0, YOR_LIGHT_POINT = 1 };
 enum { YOR_INTEGRATOR_PATH = 0, YOR_INTEGRATOR_DIRECT = 1 };
 enum { YOR_FILTER_BOX = 0, YOR_FILTER_MITCHELL = 1, YOR_FILTER_GAUSS = 2, YOR_FILTER_LANCZOS = 3 };
@@ -88,6 +89,8 @@ typedef struct yor_material_desc
 	int32_t n_bump_nodes;      /* bump mapping: the nodes the bump shader reaches, in evaluation order, and its index among them (material_node.cc:132-139) */
 	int32_t sh_bump, pad5;
 	const struct yor_node_desc *bump_nodes;
+	float rough_alpha;         /* rough_glass "alpha" as given (the factory halves and clamps it, material_rough_glass.cc:362) */
+	int32_t pad6;
 } yor_material_desc;
 
 /* ImageTexture (texture_image.cc) over texels as ImageBuffer::getColor returns them (imagehandler.h:137-160): the loader has
@@ -304,6 +307,9 @@ void yor_material_transparency(const yor_material_desc *m, const float in14[14],
 void yor_material_specular(const yor_material_desc *m, const float in14[14], int32_t raylevel, int32_t *flags, float out12[12], float *alpha);
 void yor_material_probe(const yor_material_desc *m, const float in14[14], int32_t sample_flags,
                         int32_t *bsdf_flags, float eval3[3], float *pdf, int32_t *sampled_flags, float sample8[8]);
+/* the two-direction Material::sample recursiveRaytrace's glossy branch calls for a lobe that reflects and transmits (integrator_montecarlo.cc:919-970;
+ * RoughGlassMaterial::sample, material_rough_glass.cc:165-286): out15 = dir[0], the returned colour, w[0], dir[1], tcol, w[1], s.pdf_ */
+void yor_material_sample_two(const yor_material_desc *m, const float in14[14], int32_t sample_flags, int32_t *sampled_flags, float out15[15]);
 /* BeerVolumeHandler(acol, dist)::transmittance over a ray of length tmax (volumehandler_beer.cc:28-48) */
 void yor_beer_transmittance(const float acol[3], double dist, float tmax, int32_t *ok, float out3[3]);
 void yor_lightmat_emit(const yor_material_desc *m, const float n[3], const float wo[3], int include_lights, float out3[3]);

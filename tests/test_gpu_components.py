@@ -167,3 +167,19 @@ def test_materials(gold, probe_scene, name):
     exact(s[:, 1:13], g[f"{name}_spec12"], f"{name} getSpecular")
     exact(s[:, 13], g[f"{name}_alpha"], f"{name} getAlpha")
     exact(s[:, 14:17], g[f"{name}_transp3"], f"{name} getTransparency")
+
+
+@pytest.mark.parametrize("name", [k for k in sorted(MATERIALS) if MATERIALS[k]["type"] == "rough_glass"])
+def test_rough_glass_two_direction_sample(gold, probe_scene, name):
+    """RoughGlassMaterial::sample with two directions (material_rough_glass.cc:165-286), the one recursiveRaytrace's glossy branch
+    calls for a lobe that reflects and transmits (integrator_montecarlo.cc:919-959)"""
+    g = gold
+    sc, names = probe_scene
+    s2 = dict(sc); s2["materials"] = [MATERIALS[name]]
+    yi = make_iface(s2)
+    inp = u2f(g[f"{name}_two_in14"]).reshape(-1, 14)
+    n = inp.shape[0]
+    x = np.concatenate([np.zeros((n, 1), np.uint32).view(np.float32), inp, g[f"{name}_two_sflags_in"].astype(np.uint32).view(np.float32).reshape(-1, 1)], axis=1)
+    o = yi.probe(16, x, 16)
+    assert np.array_equal(o[:, 15].view(np.uint32), g[f"{name}_two_sflags_out"].astype(np.uint32)), "sampled flags"
+    exact(o[:, :15], g[f"{name}_two_out15"], f"{name} two-direction sample")

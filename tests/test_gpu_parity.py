@@ -1122,12 +1122,29 @@ def _feature_mix(seed, textures=True, serial=False):
         cw, ch = int(rng.integers(8, w - 4)), int(rng.integers(8, h - 4))
         kw.update(xstart=int(rng.integers(0, w - cw)), ystart=int(rng.integers(0, h - ch)))
         w, h = cw, ch
+    rough = seed % 4 == 1
+    if rough:      # rough glass on a fifth of the free triangles, from a stream of its own (the draws above stay what they were)
+        rr = np.random.default_rng(7000 + seed)
+        rcol = lambda lo: tuple(float(x) for x in rr.uniform(lo, 1.0, 3))
+        m = {"type": "rough_glass", "IOR": float(rr.uniform(1.1, 2.2)), "alpha": float(rr.choice([rr.uniform(0.02, 1.0), 1e-5, 2.5])), "filter_color": rcol(0.5),
+             "transmit_filter": float(rr.uniform(0.0, 1.0)), "mirror_color": rcol(0.8), "fake_shadows": bool(rr.random() < 0.5)}
+        if rr.random() < 0.4:
+            m.update({"absorption": rcol(0.05), "absorption_dist": float(rr.uniform(0.1, 2.0))})
+        if rr.random() < 0.2:
+            m["visibility"] = str(rr.choice(["no_shadows", "shadow_only"]))
+        sc["materials"].append(m)
+        tm = np.array(sc["tri_mat"], np.int32)
+        cand = np.arange(10, len(tm))
+        tm[cand[rr.random(len(cand)) < 0.2]] = len(sc["materials"]) - 1
+        sc["tri_mat"] = tm
+        kw["raydepth"] = max(kw["raydepth"], 1)           # (so that the glossy branch of recursiveRaytrace runs at all)
     if serial:
         rs = np.random.default_rng(5000 + seed)
         kw["integrator"] = "pathtracing"
         kw["bounces"] = max(kw["bounces"], 2)
         kw["russian_roulette_min_bounces"] = int(rs.integers(0, kw["bounces"]))
-        kw["raydepth"] = min(kw["raydepth"], 3)          # (up to 255 integrate() calls per camera sample are replayed: DESIGN.md, serial state)
+        # (up to 255 integrate() calls per camera sample are replayed: DESIGN.md, serial state; a rough-glass trajectory makes two)
+        kw["raydepth"] = min(kw["raydepth"], 2 if rough else 3)
         for m in sc["materials"]:
             m.pop("additionaldepth", None)
         if rs.random() < 0.7:

@@ -56,7 +56,9 @@ def test_factories_fail_loudly_outside_scope():
     yi = fresh()
     yi.startScene(0)
     for kind, params, needle in [
-        ("material", {"type": "rough_glass"}, "scope"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
+        ("material", {"type": "blend_mat"}, "scope"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"),
+        ("material", {"type": "rough_glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "rough_glass", "roughness_shader": "n"}, "roughness_shader"),
+        ("material", {"type": "rough_glass", "additionaldepth": 9}, "additionaldepth"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
         ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),
@@ -64,6 +66,8 @@ def test_factories_fail_loudly_outside_scope():
         yi.paramsClearAll(); yi.paramsSet(params)
         r = getattr(yi, "create" + kind.capitalize())("x_" + needle)
         assert not r and needle in yi.getLastError(), (kind, params, yi.getLastError())
+    yi.paramsClearAll(); yi.paramsSet({"type": "rough_glass", "IOR": 1.6, "alpha": 0.3, "transmit_filter": 0.5, "fake_shadows": True, "absorption": (0.5, 0.6, 0.7), "absorption_dist": 2.0})
+    assert yi.createMaterial("rough"), yi.getLastError()
     yi.paramsClearAll()
     assert not yi.createMaterial("untyped") and "type" in yi.getLastError()
     strict = fresh(strict=True)

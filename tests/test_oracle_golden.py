@@ -236,6 +236,8 @@ def test_lights(gold):
 
 
 # RenderState::raylevel_ when the golden getSpecular calls were made (GlassMaterial::getSpecular depends on it)
+# rg2: alpha at the factory's clamp (1e-4): D() reaches 1e8 and the two reference builds differ by 5 % on it; pinned against the IEEE build only
+FAST_SKIP = {"rg2"}
 SPEC_RAYLEVEL = {"gg0d": 4, "gg1": 2, "cg1": 6, "cg2": 2}
 
 MATERIALS = {
@@ -266,12 +268,18 @@ MATERIALS = {
     "gl4": {"type": "glossy", "color": (1, 1, 1), "glossy_reflect": 0.9, "anisotropic": True, "exp_u": 8.0, "exp_v": 900.0},
     "cg3": {"type": "coated_glossy", "color": (0.9, 0.9, 0.8), "diffuse_color": (0.2, 0.6, 0.5), "diffuse_reflect": 0.6, "glossy_reflect": 0.5,
             "specular_reflect": 0.7, "IOR": 1.5, "as_diffuse": True, "anisotropic": True, "exp_u": 30.0, "exp_v": 250.0},
+    # rough glass (material_rough_glass.cc): the GGX lobe that reflects and transmits
+    "rg0": {"type": "rough_glass", "IOR": 1.5, "filter_color": (0.7, 0.9, 0.8), "transmit_filter": 0.7, "mirror_color": (0.95, 0.9, 1.0), "alpha": 0.3},
+    "rg1": {"type": "rough_glass", "IOR": 2.0, "filter_color": (1.0, 0.6, 0.5), "transmit_filter": 0.4, "alpha": 0.9, "fake_shadows": True},
+    "rg2": {"type": "rough_glass", "IOR": 1.33, "alpha": 0.0001},
 }
 
 
 @pytest.mark.parametrize("name", sorted(MATERIALS))
 def test_materials(gold, name):
     variant, g = gold
+    if variant == "fast" and name in FAST_SKIP:
+        pytest.skip("a near-singular lobe amplifies -ffast-math's reassociation to several percent between the reference's own two builds")
     L = po.lib()
     md = po.material_desc(MATERIALS[name])
     inp = f32(g[f"{name}_in14"]).reshape(-1, 14).copy()
@@ -308,6 +316,27 @@ def test_materials(gold, name):
         L.yor_material_transparency(C.byref(md), po.fptr(inp[i]), po.fptr(t3))
         tr.extend(t3.tolist())
     check(variant, tr, g[f"{name}_transp3"], f"{name} getTransparency")
+
+
+@pytest.mark.parametrize("name", ["rg0", "rg1", "rg2"])
+def test_rough_glass_two_direction_sample(gold, name):
+    """the Material::sample overload recursiveRaytrace's glossy branch calls for a lobe that reflects AND transmits
+    (integrator_montecarlo.cc:919-970; RoughGlassMaterial::sample, material_rough_glass.cc:165-286)"""
+    variant, g = gold
+    if variant == "fast" and name in FAST_SKIP:
+        pytest.skip("see FAST_SKIP")
+    L = po.lib()
+    md = po.material_desc(MATERIALS[name])
+    inp = f32(g[f"{name}_two_in14"]).reshape(-1, 14).copy()
+    sfl = g[f"{name}_two_sflags_in"]
+    out, sfo = [], []
+    o15 = np.zeros(15, np.float32)
+    for i in range(inp.shape[0]):
+        so = C.c_int32()
+        L.yor_material_sample_two(C.byref(md), po.fptr(inp[i]), int(sfl[i]), C.byref(so), po.fptr(o15))
+        out.extend(o15.tolist()); sfo.append(so.value)
+    assert sfo == [int(v) for v in g[f"{name}_two_sflags_out"]]
+    check(variant, out, g[f"{name}_two_out15"], f"{name} two-direction sample")
 
 
 def test_light_material(gold):

@@ -853,6 +853,35 @@ def test_glossy_branch_of_recursive_raytrace(raydepth, integrator, pipeline):
     compare_films(film, ofilm, f"glossy branch raydepth {raydepth} {integrator}")
 
 
+@pytest.mark.parametrize("raydepth,integrator,extra", [(1, "pathtracing", {}), (2, "pathtracing", {"bg_transp": True, "bg_transp_refract": True}),
+                                                       (3, "pathtracing", {"transpShad": True, "shadowDepth": 3}), (2, "directlighting", {"transpShad": True, "bg_transp_refract": True})])
+def test_rough_glass(raydepth, integrator, extra, pipeline):
+    """RoughGlassMaterial (material_rough_glass.cc): a glossy lobe that reflects AND transmits.  recursiveRaytrace's glossy branch takes the
+    two-direction sample and sends two rays per trajectory (integrator_montecarlo.cc:919-959: absorption along either, the second one's
+    alpha for the level); path segments take the one-direction sample; fake shadows filter the light through getTransparency; glossy,
+    mirror and glass in the scene nest the other branches inside it and the other way round."""
+    sc = scenes.cornell_soup(260, seed=53, res=(40, 32), sigma=0.08)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["lights"] = [dict(l, samples=2) for l in sc["lights"]]
+    sc["materials"].append({"type": "rough_glass", "IOR": 1.5, "alpha": 0.3, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6, "mirror_color": (1.0, 0.95, 0.9)})
+    sc["materials"].append({"type": "rough_glass", "IOR": 1.33, "alpha": 0.8, "filter_color": (0.9, 0.7, 0.8), "transmit_filter": 0.9, "fake_shadows": True,
+                            "absorption": (0.4, 0.7, 0.9), "absorption_dist": 0.5, "additionaldepth": 1})
+    sc["materials"].append({"type": "rough_glass", "IOR": 2.1, "alpha": 0.05, "fake_shadows": True, "visibility": "no_shadows"})
+    sc["materials"].append({"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5,
+                            "exponent": 60.0, "as_diffuse": False})
+    sc["materials"].append({"type": "mirror", "color": (0.9, 0.9, 0.9), "reflect": 0.9})
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[4:6] = nm - 6; tm[6:8] = nm - 2          # back wall rough glass (the background shows through it), left wall mirror
+    free = np.arange(10, len(tm)); tm[free[0::4]] = nm - 6; tm[free[1::5]] = nm - 5; tm[free[2::7]] = nm - 4; tm[free[3::9]] = nm - 3; tm[free[5::11]] = nm - 1
+    sc["tri_mat"] = tm
+    rd = scenes.render_settings(40, 32, 3, bounces=2, raydepth=raydepth, path_samples=4, integrator=integrator, background=(0.2, 0.3, 0.5), **extra)
+    film, st, ofilm, ost = render_both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"rough glass raydepth {raydepth} {integrator} {extra}")
+
+
 @pytest.mark.parametrize("raydepth", [0, 1, 2])
 def test_additional_depth_and_transparent_bias(raydepth, pipeline):
     """Material::additional_depth_ (integrate() carries the largest one met on the way down and recursiveRaytrace goes that much
@@ -1396,11 +1425,19 @@ def _first_tree_artefact(sc, rd, same_tree, film, ofilm):
         return ((y - y00) // ts, (x - x00) // ts, y, x)
     k0 = key(x0, y0)
     # a sample lands on every pixel of its filter footprint (imagefilm.cc:124-187: filterw = AA_pixelwidth / 2, x2 gauss, x2.6 mitchell,
-    # clamped to [0.501, 4]): pixels that close to the query's are not "before" it
+    # clamped to [0.501, 4]), and from the query on EVERY sample may differ (the light counter is shifted): a film pixel is "before" the
+    # query only if no pixel rendered at or after it lies within the filter's reach
     fw = rd.get("AA_pixelwidth", 1.5) * 0.5 * {"gauss": 2.0, "mitchell": 2.6}.get(rd.get("filter_type", "box"), 1.0)
     reach = int(np.ceil(min(max(fw, 0.501), 4.0))) + 1
-    early = [(int(x), int(y)) for x, y in zip(xs + x00, ys + y00)
-             if key(int(x), int(y)) < k0 and (abs(int(x) - x0) > reach or abs(int(y) - y0) > reach)]
+    fh, fwid = film.shape[0], film.shape[1]
+
+    def reached_from_later(x, y):
+        for qy in range(max(y - reach, y00), min(y + reach, y00 + fh - 1) + 1):
+            for qx in range(max(x - reach, x00), min(x + reach, x00 + fwid - 1) + 1):
+                if key(qx, qy) >= k0:
+                    return True
+        return False
+    early = [(int(x), int(y)) for x, y in zip(xs + x00, ys + y00) if not reached_from_later(int(x), int(y))]
     if rd.get("AA_passes", 1) > 1:
         early = []      # a later pass re-renders earlier pixels after the query: order alone cannot separate them
     found["parts_at_or_after_the_query"] = not early

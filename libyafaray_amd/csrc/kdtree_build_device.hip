@@ -496,6 +496,8 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 	const double log_leaves = 1.442695f * std::log((double)n_tris);
 	if(log_leaves > 16.0) cost_ratio += (float)(0.25 * (log_leaves - 16.0));
 	if(const char *e = std::getenv("YAFGPU_COST_RATIO")) cost_ratio = (float)std::atof(e);      // experiments: node-step cost / triangle-test cost
+	float empty_bonus = 0.33f;
+	if(const char *e = std::getenv("YAFGPU_EMPTY_BONUS")) empty_bonus = (float)std::atof(e);
 
 	const size_t n = (size_t)n_tris;
 	// room: references / nodes the arrays hold per triangle (x8).  Overlapping geometry (long needles, stacked sheets)
@@ -539,7 +541,7 @@ int build_kdtree_device(const float *verts, int n_tris, int depth_cap, KdTree &o
 		a.verts = (const float *)d_verts.p;
 		a.nodes = (BfsNode *)d_nodes.p; a.leaf_refs = (uint32_t *)d_leaf.p; a.counters = (uint32_t *)d_cnt.p;
 		a.n_work = n_work; a.node_base = node_count; a.cap_refs = cap_refs; a.cap_work = cap_work; a.cap_nodes = cap_nodes; a.cap_leaf_refs = cap_leaf;
-		a.depth_cap = md; a.cost_ratio = cost_ratio; a.empty_bonus = 0.33f;
+		a.depth_cap = md; a.cost_ratio = cost_ratio; a.empty_bonus = empty_bonus;
 		const uint32_t zero2[2] = {0u, 0u};
 		if(hipMemcpy(d_cnt.p, zero2, sizeof zero2, hipMemcpyHostToDevice) != hipSuccess) return fail("device kd build: counter reset failed");
 		level_begin.push_back(node_count);

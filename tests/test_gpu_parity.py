@@ -853,7 +853,7 @@ def test_glossy_branch_of_recursive_raytrace(raydepth, integrator, pipeline):
     compare_films(film, ofilm, f"glossy branch raydepth {raydepth} {integrator}")
 
 
-@pytest.mark.parametrize("raydepth,integrator,extra", [(1, "pathtracing", {}), (2, "pathtracing", {"bg_transp": True, "bg_transp_refract": True}),
+@pytest.mark.parametrize("raydepth,integrator,extra", [(0, "pathtracing", {"no_recursive": True, "bounces": 3}), (1, "pathtracing", {}), (2, "pathtracing", {"bg_transp": True, "bg_transp_refract": True}),
                                                        (3, "pathtracing", {"transpShad": True, "shadowDepth": 3}), (2, "directlighting", {"transpShad": True, "bg_transp_refract": True})])
 def test_rough_glass(raydepth, integrator, extra, pipeline):
     """RoughGlassMaterial (material_rough_glass.cc): a glossy lobe that reflects AND transmits.  recursiveRaytrace's glossy branch takes the
@@ -876,7 +876,7 @@ def test_rough_glass(raydepth, integrator, extra, pipeline):
     tm[4:6] = nm - 6; tm[6:8] = nm - 2          # back wall rough glass (the background shows through it), left wall mirror
     free = np.arange(10, len(tm)); tm[free[0::4]] = nm - 6; tm[free[1::5]] = nm - 5; tm[free[2::7]] = nm - 4; tm[free[3::9]] = nm - 3; tm[free[5::11]] = nm - 1
     sc["tri_mat"] = tm
-    rd = scenes.render_settings(40, 32, 3, bounces=2, raydepth=raydepth, path_samples=4, integrator=integrator, background=(0.2, 0.3, 0.5), **extra)
+    rd = scenes.render_settings(40, 32, 3, **dict(dict(bounces=2, raydepth=raydepth, path_samples=4, integrator=integrator, background=(0.2, 0.3, 0.5)), **extra))
     film, st, ofilm, ost = render_both(sc, rd)
     assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
     compare_films(film, ofilm, f"rough glass raydepth {raydepth} {integrator} {extra}")

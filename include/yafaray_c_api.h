@@ -229,6 +229,9 @@ yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *r
  * ms[4]/launches[4] = closest-hit traversal, any-hit traversal, shading, other */
 yafaray_bool_t yafaray_setProfiling(yafaray_interface_t *yi, yafaray_bool_t enable);
 yafaray_bool_t yafaray_getKernelProfile(yafaray_interface_t *yi, double ms[4], uint64_t launches[4]);
+/* consecutive renderPassDevice calls of independent passes on two internal streams (yafgpu_scene_set_pass_pipelining, include/yafgpu.h):
+ * -1 by size (default), 0 off, 1 on.  What the caller sees — planes, counters — is written on the caller's stream, in call order, either way. */
+yafaray_bool_t yafaray_setPassPipelining(yafaray_interface_t *yi, int mode);
 /* device-side component probe (yafgpu_probe) against the prepared scene's materials/lights/camera */
 yafaray_bool_t yafaray_probe(yafaray_interface_t *yi, int op, int n, const float *in, int n_in, float *out, int n_out);
 

@@ -119,6 +119,7 @@ struct yafaray_interface
 	// Material / ObjectGeometric constructor calls srand(its running index) and then draws a random colour
 	// (material.cc:53-66, object_geom.cc:39-51); whichever object was made last leaves the state rand() continues from
 	uint32_t last_srand = 0u; bool have_srand = false;
+	int pass_pipelining = -1;            // yafaray_setPassPipelining: -1 by size, 0 off, 1 on (yafgpu_scene_set_pass_pipelining)
 	int user_srand = -1, user_skip = 0;  // yafaray_setRandState: the embedder's own srand() after the last constructor
 	bool serial_replay = true;           // yafaray_setSerialReplay
 	std::vector<int32_t> tile_rand0;     // the first pass's value per tile (yafaray_renderPassDevice)
@@ -1568,6 +1569,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	if(threads > 0) d.build_threads = threads;
 	if(yafgpu_scene_create(&d, &yi->gpu)) return fail(yi, std::string("scene upload: ") + yafgpu_last_error());
 	yi->scene_dirty = false; yi->scene_cam = cam->second->c.cam; yi->scene_threads = threads;
+	yafgpu_scene_set_pass_pipelining(yi->gpu, yi->pass_pipelining);
 	yafgpu_scene_set_abort_flag(yi->gpu, &yi->abort_flag);
 	yafgpu_scene_set_exchange(yi->gpu, yi->exchange, yi->exchange_user);
 	yafgpu_tree_info ti{};
@@ -1610,6 +1612,12 @@ yafaray_bool_t yafaray_shadowRays(yafaray_interface_t *yi, int n, const float *r
 	return 1;
 }
 
+yafaray_bool_t yafaray_setPassPipelining(yafaray_interface_t *yi, int mode)
+{
+	yi->pass_pipelining = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+	if(yi->gpu) yafgpu_scene_set_pass_pipelining(yi->gpu, yi->pass_pipelining);
+	return 1;
+}
 yafaray_bool_t yafaray_setProfiling(yafaray_interface_t *yi, yafaray_bool_t enable)
 {
 	if(!yi->prepared) return fail(yi, "setProfiling: call prepareRender first");

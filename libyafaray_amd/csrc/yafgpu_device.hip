@@ -1143,6 +1143,23 @@ struct yafgpu_scene
 	std::vector<uint32_t> h_pix_prefix; uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
 	float4 *wf_state = nullptr, *wf_results = nullptr; uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr; uint32_t wf_cap = 0;
 	hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the any-hit launch of an iteration runs beside the closest-hit one
+	// Pass pipelining (render_wavefront): consecutive passes that do not depend on each other's film take turns on two internal streams, each
+	// with its own set of the wavefront buffers, so that one pass's launch tails are filled by the other's launches; the film is added to
+	// on the caller's stream, in call order.  `alt[]` are the sets that are not in the members above at the moment.
+	struct WfSet
+	{
+		uint32_t *d_pix_prefix = nullptr; size_t pix_prefix_cap = 0;
+		float4 *wf_state = nullptr, *wf_results = nullptr, *wf_filt = nullptr;
+		uint32_t *wf_queues = nullptr, *wf_counts = nullptr, *wf_verdict = nullptr, *wf_pix_xy = nullptr;
+		uint32_t wf_cap = 0, wf_filt_cap = 0; int wf_frames = 0;
+		hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	} alt[2];
+	static constexpr int kPipeMax = 3;      // passes in flight at most (buffer sets: the members above + alt[])
+	hipStream_t pipe_stream[kPipeMax] = {};
+	hipEvent_t pipe_done[kPipeMax] = {}, pipe_acc[kPipeMax] = {}, pipe_sync = nullptr;
+	bool pipe_acc_set[kPipeMax] = {}, pipe_prev = false;
+	int pipe_next = 0, pass_pipelining = -1;      // -1: by size (render_wavefront), 0 / 1: forced (yafgpu_scene_set_pass_pipelining)
+	yafgpu_counters *pipe_counters[kPipeMax] = {};      // a pipelined pass counts here; the sums reach the caller's block on the caller's stream
 	uint32_t mat_mask = 0u;              // bit per YAFGPU_MAT_* present; picks the shading kernel variant
 	bool has_volumetric = false;
 	int max_add_depth = 0;               // the largest Material::additional_depth_ of the scene: recursion frames beyond raydepth
@@ -1550,6 +1567,22 @@ void yafgpu_scene_destroy(yafgpu_scene_t *s)
 	if(s->wf_verdict) (void)hipFree(s->wf_verdict);
 	if(s->wf_pix_xy) (void)hipFree(s->wf_pix_xy);
 	if(s->wf_filt) (void)hipFree(s->wf_filt);
+	for(yafgpu_scene::WfSet &o : s->alt)
+	{
+		for(void *q : {(void *)o.d_pix_prefix, (void *)o.wf_state, (void *)o.wf_results, (void *)o.wf_filt, (void *)o.wf_queues, (void *)o.wf_counts, (void *)o.wf_verdict, (void *)o.wf_pix_xy})
+			if(q) (void)hipFree(q);
+		if(o.side_stream) (void)hipStreamDestroy(o.side_stream);
+		if(o.ev_fork) (void)hipEventDestroy(o.ev_fork);
+		if(o.ev_join) (void)hipEventDestroy(o.ev_join);
+	}
+	for(int k = 0; k < yafgpu_scene::kPipeMax; ++k)
+	{
+		if(s->pipe_stream[k]) (void)hipStreamDestroy(s->pipe_stream[k]);
+		if(s->pipe_done[k]) (void)hipEventDestroy(s->pipe_done[k]);
+		if(s->pipe_acc[k]) (void)hipEventDestroy(s->pipe_acc[k]);
+	}
+	if(s->pipe_sync) (void)hipEventDestroy(s->pipe_sync);
+	for(int k = 0; k < yafgpu_scene::kPipeMax; ++k) if(s->pipe_counters[k]) (void)hipFree(s->pipe_counters[k]);
 	if(s->side_stream) (void)hipStreamDestroy(s->side_stream);
 	if(s->ev_fork) (void)hipEventDestroy(s->ev_fork);
 	if(s->ev_join) (void)hipEventDestroy(s->ev_join);
@@ -1775,8 +1808,24 @@ static int lc_exchange_counts(yafgpu_scene *s, const yafgpu_render_params &rp, c
 	return 0;
 }
 
-static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream, bool stats)
+__global__ void add_counters(yafgpu_counters *dst, const yafgpu_counters *src)
 {
+	const unsigned i = threadIdx.x;
+	if(i < sizeof(yafgpu_counters) / sizeof(uint64_t)) ((uint64_t *)dst)[i] += ((const uint64_t *)src)[i];
+}
+static void swap_wf_sets(yafgpu_scene *s, int which)
+{
+	yafgpu_scene::WfSet &o = s->alt[which];
+	std::swap(s->d_pix_prefix, o.d_pix_prefix); std::swap(s->pix_prefix_cap, o.pix_prefix_cap);
+	std::swap(s->wf_state, o.wf_state); std::swap(s->wf_results, o.wf_results); std::swap(s->wf_filt, o.wf_filt);
+	std::swap(s->wf_queues, o.wf_queues); std::swap(s->wf_counts, o.wf_counts); std::swap(s->wf_verdict, o.wf_verdict); std::swap(s->wf_pix_xy, o.wf_pix_xy);
+	std::swap(s->wf_cap, o.wf_cap); std::swap(s->wf_filt_cap, o.wf_filt_cap); std::swap(s->wf_frames, o.wf_frames);
+	std::swap(s->side_stream, o.side_stream); std::swap(s->ev_fork, o.ev_fork); std::swap(s->ev_join, o.ev_join);
+}
+
+static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller, bool stats)
+{
+	hipStream_t stream = caller;
 	const yafgpu_render_params &rp = ra.rp;
 	const uint32_t spp = (uint32_t)rp.aa_minsamples;
 	// per-tile pixel prefix (same tile list as the unit prefix)
@@ -1802,6 +1851,53 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 	}
 	const std::vector<uint32_t> &tile_px = masked ? listed_prefix : pp;      // pixels of the pass before every tile of the shard
 	const uint32_t n_pixels_total = tile_px.back();
+	// Pass pipelining: this pass's path work goes to one of two internal streams with its own buffer set and does NOT wait for what the
+	// caller's stream holds (the previous pass, its film combine, a reduce); only the film accumulation is put on the caller's stream, after
+	// the path work.  Eligible: one chunk, no serial-state replay (its tables are per scene), no recursion polling, no resample mask (the
+	// host reads the film between such passes anyway), no per-kernel profiling.
+	bool pass_piped = false; int pipe_k = 0;
+	struct SwapBack { yafgpu_scene *s; int which; ~SwapBack() { if(which >= 0) swap_wf_sets(s, which); } } swap_back{s, -1};
+	{
+		// measured (profiles/r03_ab_pipeline.txt): +18 % at an eighth of the metric frame, +10 % at a quarter, +4 % at half, -3 % at the whole
+		// frame (two full-size passes only compete) -- on by size, like the two traversal launches side by side
+		bool want = s->pass_pipelining < 0 ? (uint64_t)n_pixels_total * spp <= (12ull << 20) : s->pass_pipelining != 0;
+		if(const char *e = std::getenv("YAFGPU_PASS_PIPELINE")) want = std::atoi(e) != 0;
+		uint32_t mp = kWfMaxPaths;
+		if(const char *e = std::getenv("YAFGPU_WF_CHUNK")) mp = std::max(256u, (uint32_t)std::strtoul(e, nullptr, 10));
+		const ReplayPlan pl = replay_plan(s, rp);
+		pass_piped = want && !masked && !stats && !s->profiling && !pl.replay && pl.frames == 0 && (uint64_t)n_pixels_total * spp <= mp && !std::getenv("YAFGPU_CHUNK_PIPELINE");
+		if(pass_piped)
+		{
+			int depth = 2;      // (a third pass in flight adds nothing: two chains already keep a launch beside every tail, profiles/r03_ab_pipeline.txt)
+			if(const char *e = std::getenv("YAFGPU_PASS_PIPELINE_DEPTH")) depth = std::min(std::max(std::atoi(e), 2), (int)yafgpu_scene::kPipeMax);
+			for(int k = 0; k < depth; ++k) if(!s->pipe_stream[k])
+			{
+				HIP_OK(hipStreamCreateWithFlags(&s->pipe_stream[k], hipStreamNonBlocking));
+				HIP_OK(hipEventCreateWithFlags(&s->pipe_done[k], hipEventDisableTiming));
+				HIP_OK(hipEventCreateWithFlags(&s->pipe_acc[k], hipEventDisableTiming));
+			}
+			if(!s->pipe_sync) HIP_OK(hipEventCreateWithFlags(&s->pipe_sync, hipEventDisableTiming));
+			if(!s->pipe_prev)
+			{	// the first of a run (or new tile arrays): what the caller's stream holds so far precedes both internal streams, once
+				HIP_OK(hipEventRecord(s->pipe_sync, caller));
+				for(int k = 0; k < depth; ++k) HIP_OK(hipStreamWaitEvent(s->pipe_stream[k], s->pipe_sync, 0));
+			}
+			if(s->pipe_next >= depth) s->pipe_next = 0;
+			pipe_k = s->pipe_next; s->pipe_next = (s->pipe_next + 1) % depth;
+			if(pipe_k > 0) { swap_wf_sets(s, pipe_k - 1); swap_back.which = pipe_k - 1; }
+			stream = s->pipe_stream[pipe_k];
+			// the set's previous pass has been added to the film (its results and pixel list are free again)
+			if(s->pipe_acc_set[pipe_k]) HIP_OK(hipStreamWaitEvent(stream, s->pipe_acc[pipe_k], 0));
+			if(ra.counters)
+			{
+				if(!s->pipe_counters[pipe_k]) HIP_OK(hipMalloc((void **)&s->pipe_counters[pipe_k], sizeof(yafgpu_counters)));
+				HIP_OK(hipMemsetAsync(s->pipe_counters[pipe_k], 0, sizeof(yafgpu_counters), stream));
+			}
+		}
+		s->pipe_prev = pass_piped;
+	}
+	yafgpu_counters *const caller_counters = ra.counters;
+	if(pass_piped && ra.counters) ra.counters = s->pipe_counters[pipe_k];
 	if(pp.size() > s->pix_prefix_cap)
 	{
 		HIP_OK(hipStreamSynchronize(stream));
@@ -2161,6 +2257,19 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t stream,
 		}
 		if((rc = run(iters, false))) return rc;
 		const uint32_t g_acc = std::min<uint32_t>((a.n_pixels + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
+		if(pass_piped)
+		{	// the film on the caller's stream, after this pass's path work and (by that stream's order) after the previous pass's film
+			HIP_OK(hipEventRecord(s->pipe_done[pipe_k], stream));
+			HIP_OK(hipStreamWaitEvent(caller, s->pipe_done[pipe_k], 0));
+			WfArgs acc = a;
+			acc.ra.counters = caller_counters;
+			hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, caller, acc);
+			if(caller_counters) hipLaunchKernelGGL(add_counters, dim3(1), dim3(64), 0, caller, caller_counters, (const yafgpu_counters *)s->pipe_counters[pipe_k]);
+			HIP_OK(hipGetLastError());
+			HIP_OK(hipEventRecord(s->pipe_acc[pipe_k], caller));
+			s->pipe_acc_set[pipe_k] = true;
+			return 0;
+		}
 		if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_accumulate, dim3(g_acc), dim3(kBlock), 0, stream, a); }))) return rc;
 		return 0;
 	};
@@ -2363,6 +2472,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		HIP_OK(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(s->d_prefix, s->h_prefix.data(), s->h_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		std::memcpy(s->tile_key, key, sizeof key);
+		s->pipe_prev = false;      // (pipelined passes: the new tile arrays precede the internal streams' next launches)
 	}
 	HIP_OK(hipMemsetAsync(s->d_queue, 0, kQueues * 32 * sizeof(uint32_t), stream));
 	ra.tile_rect = s->d_tiles; ra.unit_prefix = s->d_prefix; ra.queue_next = s->d_queue;
@@ -2778,6 +2888,12 @@ int yafgpu_scene_set_abort_flag(yafgpu_scene_t *s, const volatile int32_t *flag)
 	return 0;
 }
 
+int yafgpu_scene_set_pass_pipelining(yafgpu_scene_t *s, int32_t mode)
+{
+	if(!s) return fail(-1, "null scene");
+	s->pass_pipelining = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+	return 0;
+}
 int yafgpu_set_profiling(yafgpu_scene_t *s, int32_t enable)
 {
 	if(!s) return fail(-1, "null argument");

@@ -66,7 +66,7 @@ C_API_SYMBOLS = [
     "yafaray_createLight", "yafaray_createMaterial", "yafaray_createCamera", "yafaray_createBackground",
     "yafaray_createIntegrator", "yafaray_clearAll", "yafaray_render", "yafaray_abort", "yafaray_getRenderedImage",
     "yafaray_getFilm", "yafaray_getRenderStats", "yafaray_setShard", "yafaray_setPlaneExchange", "yafaray_setSerialReplay", "yafaray_getRandState", "yafaray_setRandState", "yafaray_prepareRender",
-    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile",
+    "yafaray_renderPassDevice", "yafaray_getRenderSize", "yafaray_loadXml", "yafaray_intersectRays", "yafaray_shadowRays", "yafaray_probe", "yafaray_setProfiling", "yafaray_getKernelProfile", "yafaray_setPassPipelining",
     "yafaray_commGetUniqueId", "yafaray_commCreate", "yafaray_commDestroy", "yafaray_commRank", "yafaray_commWorld", "yafaray_commLastError",
     "yafaray_commBackend", "yafaray_reduceFilm", "yafaray_allReduce", "yafaray_commExchange", "yafaray_setComm",
 ]
@@ -75,7 +75,7 @@ GPU_ABI_SYMBOLS = [
     "yafgpu_scene_info", "yafgpu_planes_bytes", "yafgpu_render_tiles", "yafgpu_film_combine", "yafgpu_render_to_host", "yafgpu_render_passes_to_host",
     "yafgpu_trace_closest", "yafgpu_trace_shadow", "yafgpu_scene_get_tree", "yafgpu_probe",
     "yafgpu_kdtree_build", "yafgpu_kdtree_build_device", "yafgpu_kdtree_info", "yafgpu_kdtree_get", "yafgpu_kdtree_destroy",
-    "yafgpu_set_profiling", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag", "yafgpu_scene_set_exchange", "yafgpu_glibc_rand",
+    "yafgpu_set_profiling", "yafgpu_scene_set_pass_pipelining", "yafgpu_get_profile", "yafgpu_scene_set_abort_flag", "yafgpu_scene_set_exchange", "yafgpu_glibc_rand",
 ]
 
 
@@ -135,6 +135,7 @@ def load():
         "yafaray_shadowRays": (ci, [vp, ci, C.POINTER(cf), C.POINTER(ci)]),
         "yafaray_probe": (ci, [vp, ci, ci, C.POINTER(cf), ci, C.POINTER(cf), ci]),
         "yafaray_setProfiling": (ci, [vp, ci]),
+        "yafaray_setPassPipelining": (ci, [vp, ci]),
         "yafaray_getKernelProfile": (ci, [vp, C.POINTER(cd), C.POINTER(C.c_uint64)]),
         "yafaray_commGetUniqueId": (ci, [C.c_char_p]), "yafaray_commCreate": (vp, [C.c_char_p, ci, ci, ci]), "yafaray_commDestroy": (None, [vp]),
         "yafaray_commRank": (ci, [vp]), "yafaray_commWorld": (ci, [vp]), "yafaray_commLastError": (cp, []), "yafaray_commBackend": (cp, []),
@@ -500,6 +501,10 @@ class Interface:
         fp = C.POINTER(C.c_float)
         self._ok(self._L.yafaray_probe(self._h, op, x.shape[0], x.ctypes.data_as(fp), x.shape[1], out.ctypes.data_as(fp), n_out), "probe")
         return out
+
+    def setPassPipelining(self, mode):
+        """-1: by size (default), 0: off, 1: on — consecutive independent passes on two internal streams (include/yafgpu.h)"""
+        return self._ok(self._L.yafaray_setPassPipelining(self._h, int(mode)), "setPassPipelining")
 
     def setProfiling(self, enable):
         return self._ok(self._L.yafaray_setProfiling(self._h, int(enable)), "setProfiling")

@@ -24,6 +24,7 @@ int yafgpu_render_passes_to_host(yafgpu_scene_t *, const yafgpu_render_params *,
 int yafgpu_trace_closest(yafgpu_scene_t *, int32_t, const float *, int32_t *, float *, float *) { return -100; }
 int yafgpu_trace_shadow(yafgpu_scene_t *, int32_t, const float *, int32_t *) { return -100; }
 int yafgpu_set_profiling(yafgpu_scene_t *, int32_t) { return -100; }
+int yafgpu_scene_set_pass_pipelining(yafgpu_scene_t *, int32_t) { return -100; }
 int yafgpu_scene_set_abort_flag(yafgpu_scene_t *, const volatile int32_t *) { return -100; }
 int yafgpu_scene_set_exchange(yafgpu_scene_t *, yafgpu_exchange_fn, void *) { return -100; }
 void yafgpu_glibc_rand(uint32_t, int32_t count, int32_t *out) { for(int32_t k = 0; k < count; ++k) out[k] = 0; }

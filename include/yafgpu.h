@@ -221,6 +221,9 @@ typedef struct yafgpu_render_params
 	                                  TiledIntegrator::renderTile seeds that tile's Random with in THIS pass; NULL = 0 for all */
 	const uint8_t *resample_mask;  /* HOST pointer, width*height bytes, row-major in window coordinates: the pixels that
 	                                  get samples in this pass (ImageFilm::doMoreSamples, imagefilm.cc:917-920); NULL = all */
+	int32_t trace_caustics;        /* PathIntegrator::trace_caustics_ (integrator_path_tracer.cc:85): caustic_type "path" — the factory's default when the
+	                                  parameter is absent — or "both": after a bounce through a specular, glossy or filter lobe the next vertex shows its
+	                                  lights and adds its emission (:252-253, :290).  0 = caustic_type "none" */
 } yafgpu_render_params;
 
 /* Scene::setAntialiasing (scene.cc:761-778; defaults environment.cc:682-695) */

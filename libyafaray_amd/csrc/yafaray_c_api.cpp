@@ -66,6 +66,7 @@ struct IntegratorCfg
 	std::string type;
 	int path_samples = 32, bounces = 3, rr_min_bounces = 0, raydepth = 5;
 	bool no_recursive = false, bg_transp = false, bg_transp_refract = false, transp_shad = false;
+	bool trace_caustics = false;     // PathIntegrator: caustic_type_ is Path unless the parameter says "none" (integrator_path_tracer.cc:36, :85, :382-387)
 	int shadow_depth = 5;            // integrator_path_tracer.cc:352, integrator_direct_light.cc:201
 };
 
@@ -1335,7 +1336,8 @@ yafaray_integrator_t *yafaray_createIntegrator(yafaray_interface_t *yi, const ch
 			p.get("path_samples", c.path_samples); p.get("bounces", c.bounces);
 			p.get("russian_roulette_min_bounces", c.rr_min_bounces); p.get("no_recursive", c.no_recursive);
 			if(p.get("caustic_type", c_method) && (c_method == "photon" || c_method == "both"))
-			{ fail(yi, "createIntegrator: photon caustics are not supported by the GPU path (use caustic_type=none)"); return nullptr; }
+			{ fail(yi, "createIntegrator: photon caustics are not supported by the GPU path (use caustic_type=path or none)"); return nullptr; }
+			c.trace_caustics = c_method != "none";      // absent or any other word: the constructor's Path stays (:36), preprocess() sets trace_caustics_ (:85)
 		}
 		else
 		{
@@ -1456,6 +1458,7 @@ yafaray_bool_t yafaray_prepareRender(yafaray_interface_t *yi)
 	rp.integrator = ic.type == "pathtracing" ? YAFGPU_INTEGRATOR_PATH : YAFGPU_INTEGRATOR_DIRECT;
 	rp.path_samples = ic.path_samples; rp.bounces = ic.bounces; rp.rr_min_bounces = ic.rr_min_bounces;
 	rp.no_recursive = ic.no_recursive; rp.bg_transp = ic.bg_transp; rp.bg_transp_refract = ic.bg_transp_refract;
+	rp.trace_caustics = (ic.type == "pathtracing" && ic.trace_caustics) ? 1 : 0;
 	rp.width = width; rp.height = height; rp.xstart = xstart; rp.ystart = ystart;
 	rp.aa_minsamples = aa_samples; rp.aa_pixelwidth = filt_sz; rp.filter_type = filter_type; rp.tile_size = tile_size;
 	rp.base_sampling_offset = (uint32_t)base_offset + (uint32_t)node * 100000u;   // imagefilm.h:124

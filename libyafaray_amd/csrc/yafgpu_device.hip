@@ -2490,6 +2490,7 @@ int yafgpu_render_tiles(yafgpu_scene_t *s, const yafgpu_render_params *rp, float
 		if(rp->transp_shad) return fail(-15, "the one-kernel pipeline has no transparent shadows (transpShad); use the wavefront pipeline");
 		if((s->has_specular || s->has_glossy) && rp->raydepth + s->max_add_depth > 0) return fail(-15, "the one-kernel pipeline has no recursiveRaytrace; use the wavefront pipeline for mirror / transparent / glossy-recursive materials");
 		if(s->has_textures) return fail(-15, "the one-kernel pipeline has no shader nodes / textures; use the wavefront pipeline");
+		if(rp->trace_caustics && (s->has_specular || s->has_glossy)) return fail(-15, "the one-kernel pipeline has no path caustics (caustic_type path with specular / glossy lobes); use the wavefront pipeline");
 		if(rp->serial_replay && rp->integrator == YAFGPU_INTEGRATOR_PATH && (rp->bounces - 1 > rp->rr_min_bounces || s->n_lights > 1))
 			return fail(-15, "the one-kernel pipeline cannot replay the reference's serial state (Russian roulette stream, light counter); use the wavefront pipeline or switch the replay off");
 		if(rp->multi_pass || rp->accumulate || rp->resample_mask || rp->aa_clamp_samples != 0.f || rp->pass_offset != 0u)

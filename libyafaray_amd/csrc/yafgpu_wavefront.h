@@ -408,6 +408,10 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h, bool to_clos
 #define HSET(k, v) hot_set<k>(a, slot, h, (v))
 
 #define FREC(L, j) wf_rec(a, kWfRecs + a.frame_recs * (L) + (j), slot)      // recursion frames, see st_recurse
+// path caustics (yafgpu_render_params::trace_caustics): a kernel built with 0 serves renders with caustic_type "none"
+#ifndef YAFGPU_FEAT_CAUSTIC
+#define YAFGPU_FEAT_CAUSTIC 1
+#endif
 // recursiveRaytrace (frames, absorption): a kernel built with 0 serves scenes without specular / filter materials
 #ifndef YAFGPU_FEAT_RECURSE
 #define YAFGPU_FEAT_RECURSE 1
@@ -682,8 +686,9 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 	const uint32_t mb = mat_init_bsdf(pm_rec, dat_n);      // the flags do not depend on the nodes
 	yafgpu_material pm_tmp; (void)pm_tmp;
 	const yafgpu_material *pm_p = &pm_rec;
+	const bool caustic = YAFGPU_FEAT_CAUSTIC && c.stage == kStDepth && rp.trace_caustics && c.incl;      // the segment that ended here: :252
 #if YAFGPU_FEAT_TEXTURE
-	if(c.stage == kStFirst && (mb & kEmit) && pm_rec.n_nodes > 0 && sc.tex.nodes != nullptr)
+	if((c.stage == kStFirst || caustic) && (mb & kEmit) && pm_rec.n_nodes > 0 && sc.tex.nodes != nullptr)
 	{	// its own emission reads the diffuse shader (emit(), material_shiny_diffuse.cc:295-306)
 		const float4 p7 = REC(7);
 		SurfPt hp; hp.p = v3(p7); hp.n = v3(REC(8)); hp.ng = v3(REC(9)); hp.mat = (int)ubits(p7.w);
@@ -706,8 +711,10 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 		HSET(12, f4(path_col, r12.w));
 		c.depth = 1;
 		if(beside)
-		{	// st_extend's work was done by st_beside: throughput *= scol (:251)
-			HSET(11, f4(throughput * c3(REC(27)), r11.w));
+		{	// st_extend's work was done by st_beside: throughput *= scol (:251), include_lights_ = caustic (:253)
+			const float4 r27 = REC(27);
+			HSET(11, f4(throughput * c3(r27), r11.w));
+			c.incl = (int)(ubits(r27.w) & 1u);
 			c.stage = kStDepth;
 			return W_NEXT_VERTEX;
 		}
@@ -742,12 +749,20 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 	}
 	if(alive)
 	{
+		if(caustic && (mb & kEmit))
+		{	// :290 a vertex reached through a caustic lobe adds what it emits, its lights included (include_lights_ is set)
+			const float4 p7 = REC(7);
+			SurfPt hp; hp.p = v3(p7); hp.n = v3(REC(8)); hp.ng = v3(REC(9)); hp.mat = (int)ubits(p7.w);
+			lcol = lcol + mat_emit(pm, hp, v3(REC(10)), true);
+		}
 		path_col = path_col + lcol * throughput;                                                // :292
 		++c.depth;
 	}
 	if(beside)
-	{	// (no roulette test at this vertex, or st_beside would not have gone ahead)  throughput *= scol (:251)
-		HSET(11, f4(throughput * c3(REC(27)), r11.w)); HSET(12, f4(path_col, r12.w));
+	{	// (no roulette test at this vertex, or st_beside would not have gone ahead)  throughput *= scol (:251), include_lights_ = caustic (:253)
+		const float4 r27 = REC(27);
+		HSET(11, f4(throughput * c3(r27), r11.w)); HSET(12, f4(path_col, r12.w));
+		c.incl = (int)(ubits(r27.w) & 1u);
 		c.stage = kStDepth;
 		return W_NEXT_VERTEX;
 	}
@@ -785,6 +800,8 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
 	const float4 r11 = HGET(11);
 	HSET(11, f4(c3(r11) * scol, r11.w));
+	// :252-253 caustic = trace_caustics_ && the lobe sampled is specular, glossy or a filter; state.include_lights_ = caustic
+	c.incl = (ra.rp.trace_caustics && (bs.sampled & (kSpecular | kGlossy | kFilter))) ? 1 : 0;
 	REC(0) = f4(hit.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
 	c.stage = kStDepth;
 	return W_PARK_CLOSEST;
@@ -913,7 +930,8 @@ YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pi
 	if(is_black(scol)) return W_PARK_SHADOW;          // the path sample ends here (:249): nothing was written, st_extend finds it again
 	REC(6).w = w;
 	REC(26) = f4(p_dir, ra.ray_min_dist);
-	REC(27) = f4(scol, 0.f);
+	// (.w: st_extend's include_lights_ for the segment — the vertex being estimated still needs the one it was reached with)
+	REC(27) = f4(scol, fbits((rp.trace_caustics && (bs.sampled & (kSpecular | kGlossy | kFilter))) ? 1u : 0u));
 	return W_PARK_BOTH;
 }
 

@@ -137,7 +137,8 @@ def load_scene(yi, scene, render):
     for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth", "transpShad", "shadowDepth"):
         if k in render:
             integ[k] = render[k]
-    integ["caustic_type"] = "none"
+    # (render["caustic_type"]: "none" unless given; "path" is the reference's own default when the parameter is absent, integrator_path_tracer.cc:36)
+    integ["caustic_type"] = render.get("caustic_type", "none")
     yi.paramsSet(integ)
     yi.createIntegrator("default")
     yi.paramsClearAll()

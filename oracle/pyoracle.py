@@ -207,7 +207,7 @@ class RenderDesc(C.Structure):
         ("aa_indirect_sample_multiplier_factor", C.c_float), ("aa_detect_color_noise", C.c_int32),
         ("aa_dark_detection_type", C.c_int32), ("aa_dark_threshold_factor", C.c_float),
         ("aa_variance_edge_size", C.c_int32), ("aa_variance_pixels", C.c_int32), ("aa_clamp_samples", C.c_float),
-        ("transp_shad", C.c_int32), ("shadow_depth", C.c_int32), ("raydepth", C.c_int32),
+        ("transp_shad", C.c_int32), ("shadow_depth", C.c_int32), ("raydepth", C.c_int32), ("trace_caustics", C.c_int32),
     ]
 
 
@@ -451,6 +451,9 @@ def render_desc(r):
     d.bounces = r.get("bounces", 3)
     d.rr_min_bounces = r.get("russian_roulette_min_bounces", 0)
     d.no_recursive = int(r.get("no_recursive", False))
+    # PathIntegrator::factory: "none" clears trace_caustics_, "both" / "photon" need the photon map (out of scope); anything else,
+    # "path" included, leaves the constructor's Path (integrator_path_tracer.cc:36, :382-387).  These dicts default to "none".
+    d.trace_caustics = int(r.get("caustic_type", "none") != "none")
     d.bg_transp = int(r.get("bg_transp", False))
     d.bg_transp_refract = int(r.get("bg_transp_refract", False))
     d.width = r["width"]

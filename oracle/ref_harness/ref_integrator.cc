@@ -870,6 +870,28 @@ int main()
 		c.srand_seed = 13; c.background[0] = 0.15; c.background[1] = 0.2; c.background[2] = 0.25;
 		cases.push_back(c);
 	}
+	{	// path caustics, the factory's default (no caustic_type parameter: the constructor's Path stays, integrator_path_tracer.cc:36): after a bounce
+		// through a specular, glossy or filter lobe the next vertex shows its lights (include_lights_, :252-253) and adds its emission after the
+		// roulette test (:290); glass, a shinydiffuse with mirror and transparency, an emitting shinydiffuse, a glossy-recursive sheet; roulette from bounce 2
+		Case c; c.name = "pt_caustics_default";
+		c.slot_mat[SLOT_A] = M_GLASS; c.slot_mat[SLOT_B] = M_SD_MIRROR_TRANSP; c.slot_mat[SLOT_C] = M_SD_EMIT; c.slot_mat[SLOT_D] = M_GLOSSY_REC;
+		c.lights = {0, 1};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 2), pi("bounces", 5), pi("russian_roulette_min_bounces", 1), pi("raydepth", 2)};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 3)};
+		c.srand_seed = 17; c.background[0] = 0.1; c.background[1] = 0.1; c.background[2] = 0.12;
+		cases.push_back(c);
+	}
+	{	// ... and spelled out ("path" is no value the factory knows: the default stays), with no_recursive (every lobe path-traced from the camera hit on),
+		// a mirror sheet, coated glossy and rough glass as path vertices, three lights, six bounces without roulette
+		Case c; c.name = "pt_caustics_path_no_recursive";
+		c.slot_mat[SLOT_A] = M_ROUGH_GLASS; c.slot_mat[SLOT_B] = M_COATED; c.slot_mat[SLOT_C] = M_MIRROR; c.slot_mat[SLOT_D] = M_SD_EMIT;
+		c.lights = {0, 1, 2};
+		c.integrator = {ps("type", "pathtracing"), pi("path_samples", 1), pi("bounces", 6), pi("russian_roulette_min_bounces", 6), pi("raydepth", 1), ps("caustic_type", "path"),
+		                pb("no_recursive", true)};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 19; c.background[0] = 0.0; c.background[1] = 0.02; c.background[2] = 0.05;
+		cases.push_back(c);
+	}
 
 	Emit out;
 	out.raw("{\n\"width\": "); out.raw(std::to_string(W)); out.raw(", \"height\": "); out.raw(std::to_string(H)); out.raw(", \"tile_size\": "); out.raw(std::to_string(TILE));

@@ -3579,7 +3579,9 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 					scol = cscale(scol, w);
 					if(cblack(scol)) break;
 					throughput = cmul(throughput, scol);
-					st->include_lights = 0; /* caustic = trace_caustics_ && ... ; trace_caustics_ is false */
+					/* :252-253 a bounce through a specular, glossy or filter lobe makes the next vertex show its lights */
+					const int caustic = rd->trace_caustics && (sm.sampled_flags & (BSDF_SPECULAR | BSDF_GLOSSY | BSDF_FILTER)) != 0;
+					st->include_lights = caustic;
 					p_tmin = st->ray_min_dist;
 					p_tmax = -1.0f;
 					if(!scene_intersect(s, hit->p, p_dir, p_tmin, &p_tmax, hit_2, &st->cn)) break;
@@ -3599,6 +3601,7 @@ static void integrate_d(rstate_t *st, v3 from, v3 dir, float tmin, float tmax, i
 						if(probability <= 0.f || probability < random_value) break;
 						throughput = cscale(throughput, 1.f / probability);
 					}
+					if((mat_bsdfs & BSDF_EMIT) && caustic) lcol = cadd(lcol, mat_emit(p_mat, hit, pwo, st->include_lights));      /* :290 */
 					path_col = cadd(path_col, cmul(lcol, throughput));
 				}
 			}

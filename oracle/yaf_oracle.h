@@ -217,6 +217,8 @@ typedef struct yor_render_desc
 	int32_t transp_shad;               /* tr_shad_: shadow rays are filtered by transparent materials (TriKdTree::intersectTs) */
 	int32_t shadow_depth;              /* s_depth_: more distinct transparent surfaces than this along a shadow ray = shadowed */
 	int32_t raydepth;                  /* r_depth_ of recursiveRaytrace (integrator_montecarlo.cc:791); 0 behaves like "no recursion" */
+	int32_t trace_caustics;            /* PathIntegrator::trace_caustics_: caustic_type "path" — the factory's default when the parameter is absent — or "both"
+	                                    * (integrator_path_tracer.cc:36, :85, :382-387); "none" clears it */
 } yor_render_desc;
 
 typedef struct yor_stats

@@ -30,6 +30,10 @@ def case_scene(doc, cs):
     integ = dict(cs["integrator"])
     rd = {"integrator": integ.pop("type"), "width": doc["width"], "height": doc["height"], "tile_size": doc["tile_size"],
           "AA_pixelwidth": 1.0, "filter_type": "box", "background": cs["background"], "rand_srand": cs["srand"], "rand_skip": 0}
+    # PathIntegrator's caustic_type is Path unless the parameter says "none" (the constructor's default, which the factory leaves
+    # for an absent or unknown value: integrator_path_tracer.cc:36, :382-387); the dict form defaults to "none", so spell it out
+    if rd["integrator"] == "pathtracing":
+        rd["caustic_type"] = integ.get("caustic_type", "path")
     for k in ("caustic_type", "caustics", "do_AO"):
         integ.pop(k, None)
     rd.update(integ)

@@ -882,6 +882,36 @@ def test_rough_glass(raydepth, integrator, extra, pipeline):
     compare_films(film, ofilm, f"rough glass raydepth {raydepth} {integrator} {extra}")
 
 
+@pytest.mark.parametrize("raydepth,extra", [(0, {}), (2, {"russian_roulette_min_bounces": 1}), (1, {"no_recursive": True, "path_samples": 2})])
+def test_path_caustics(raydepth, extra, pipeline):
+    """caustic_type "path" — PathIntegrator's default when the parameter is absent (integrator_path_tracer.cc:36, :85): after a bounce through a
+    specular, glossy or filter lobe the next vertex shows its lights (the emitting panel of the ceiling, a light material) and adds its emission
+    after the roulette test (:252-253, :290); the state is left as the last bounce set it for whatever recursiveRaytrace does next (:863, :973)."""
+    sc = scenes.cornell_soup(260, seed=59, res=(40, 32), sigma=0.08)
+    sc["materials"] = [dict(m) for m in sc["materials"]]
+    sc["materials"].append({"type": "mirror", "color": (0.9, 0.9, 0.9), "reflect": 0.9})
+    sc["materials"].append({"type": "glass", "IOR": 1.5, "filter_color": (0.8, 0.9, 1.0), "transmit_filter": 0.6, "fake_shadows": True})
+    sc["materials"].append({"type": "glossy", "color": (0.9, 0.8, 0.85), "diffuse_color": (0.5, 0.4, 0.6), "diffuse_reflect": 0.5, "glossy_reflect": 0.5,
+                            "exponent": 60.0, "as_diffuse": False})
+    sc["materials"].append({"type": "shinydiffusemat", "color": (0.9, 0.6, 0.3), "diffuse_reflect": 0.6, "specular_reflect": 0.5, "emit": 0.8})
+    sc["materials"].append({"type": "rough_glass", "IOR": 1.4, "alpha": 0.4, "filter_color": (0.9, 0.9, 0.7), "transmit_filter": 0.5})
+    tm = np.array(sc["tri_mat"], np.int32)
+    nm = len(sc["materials"])
+    tm[6:8] = nm - 5          # left wall mirror
+    free = np.arange(10, len(tm)); tm[free[0::4]] = nm - 4; tm[free[1::5]] = nm - 3; tm[free[2::6]] = nm - 2; tm[free[3::7]] = nm - 1
+    sc["tri_mat"] = tm
+    kw = dict(bounces=4, raydepth=raydepth, path_samples=3, integrator="pathtracing", caustic_type="path")
+    kw.update(extra)
+    rd = scenes.render_settings(40, 32, 3, **kw)
+    # (with roulette on the tiles' streams are serial state: both sides start from the same libc rand() state)
+    both = (lambda s_, r_: _render_with_rand_state(s_, r_, same_tree=True)) if "russian_roulette_min_bounces" in extra else render_both
+    film, st, ofilm, ost = both(sc, rd)
+    assert st.rays_closest == ost.rays_closest and st.rays_shadow == ost.rays_shadow
+    compare_films(film, ofilm, f"path caustics raydepth {raydepth} {extra}")
+    film0, _, ofilm0, _ = both(sc, dict(rd, caustic_type="none"))
+    assert not np.allclose(ofilm, ofilm0, rtol=1e-3, atol=1e-4), "the scene does not exercise the caustic terms"
+
+
 @pytest.mark.parametrize("raydepth", [0, 1, 2])
 def test_additional_depth_and_transparent_bias(raydepth, pipeline):
     """Material::additional_depth_ (integrate() carries the largest one met on the way down and recursiveRaytrace goes that much
@@ -1179,6 +1209,8 @@ def _feature_mix(seed, textures=True, serial=False):
         if rs.random() < 0.7:
             sc["lights"] = list(sc["lights"]) + [{"type": "pointlight", "from": tuple(float(x) for x in rs.uniform(-0.6, 0.6, 3)),
                                                  "color": (1.0, 0.9, 0.8), "power": float(rs.uniform(0.5, 3.0))}]
+    if seed % 3 == 1:
+        kw["caustic_type"] = "path"      # the reference's default when the parameter is absent: path caustics (include_lights_ and emission after a specular / glossy / filter bounce)
     if textures and rng.random() < 0.4:
         _texturize(sc, rng)
     rd = scenes.render_settings(w, h, spp, **kw)

@@ -38,6 +38,8 @@ def write(path, scene, render, integrator_extra=None):
     if bg is not None:
         out += ['<background name="world_background">', _param("color", bg), _param("type", "constant"), "</background>"]
     integ = {"type": render.get("integrator", "pathtracing"), "caustic_type": "none"}
+    if render.get("caustic_type", "none") == "path":
+        integ.pop("caustic_type")      # no element at all: the loader's integrator then has the reference's default, path caustics
     for k in ("path_samples", "bounces", "russian_roulette_min_bounces", "no_recursive", "bg_transp", "bg_transp_refract", "raydepth",
               "transpShad", "shadowDepth"):
         if k in render:
@@ -63,7 +65,7 @@ def write(path, scene, render, integrator_extra=None):
     if bg is not None:
         rs["background_name"] = "world_background"
     for k, v in render.items():
-        if k in ("integrator", "background") or k in integ:
+        if k in ("integrator", "background", "caustic_type") or k in integ:
             continue
         rs[k] = v
     out.append("<render>")

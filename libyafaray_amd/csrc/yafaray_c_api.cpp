@@ -1274,7 +1274,10 @@ yafaray_light_t *yafaray_createLight(yafaray_interface_t *yi, const char *name)
 	if(yi->lights.count(name)) { fail(yi, std::string("createLight: \"") + name + "\" already defined"); return nullptr; }
 	if(!yi->params.get("type", type)) { fail(yi, "createLight: type of light not specified"); return nullptr; }
 	auto l = std::make_unique<yafaray_light>();
-	bool enabled;
+	bool enabled, photon_only = false;
+	// light_area.cc:69, light_point.cc:40,60: a photon-only light gives illumSample / illuminate nothing (and still counts among the lights the
+	// one-light estimator picks from): a photon-mapping setting, not taken over
+	if(yi->params.get("photon_only", photon_only) && photon_only) { fail(yi, "createLight: photon_only lights are outside the GPU path's scope (photon mapping)"); return nullptr; }
 	if(type == "arealight") enabled = make_arealight(yi->params, l->l);
 	else if(type == "pointlight") enabled = make_pointlight(yi->params, l->l);
 	else { fail(yi, "createLight: light type \"" + type + "\" is outside the GPU path's scope (arealight, pointlight)"); return nullptr; }

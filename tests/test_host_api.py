@@ -59,7 +59,7 @@ def test_factories_fail_loudly_outside_scope():
         ("material", {"type": "blend_mat"}, "scope"), ("material", {"type": "glass", "dispersion_power": 0.2}, "dispersion"),
         ("material", {"type": "rough_glass", "dispersion_power": 0.2}, "dispersion"), ("material", {"type": "rough_glass", "roughness_shader": "n"}, "roughness_shader"),
         ("material", {"type": "rough_glass", "additionaldepth": 9}, "additionaldepth"), ("material", {"type": "shinydiffusemat", "wireframe_amount": 0.5}, "wireframe"),
-        ("light", {"type": "spotlight"}, "scope"), ("camera", {"type": "orthographic"}, "scope"),
+        ("light", {"type": "spotlight"}, "scope"), ("light", {"type": "pointlight", "photon_only": True}, "photon_only"), ("camera", {"type": "orthographic"}, "scope"),
         ("background", {"type": "sunsky"}, "scope"), ("integrator", {"type": "photonmapping"}, "scope"),
         ("integrator", {"type": "pathtracing", "caustic_type": "photon"}, "photon"),
     ]:

@@ -4,18 +4,25 @@
  * yaf_oracle.c).  It is the *checker*: only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it.  The product (libyafaray_amd) never links or calls it.
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status:
  *   - fast-math, QMC, createCs/sampleCosHemisphere, Bound::cross, perspective camera (pinhole and
- *     depth of field), area/point lights, shinydiffuse/glossy/coated-glossy/glass/mirror/light
- *     materials (eval, pdf, sample, getSpecular, getAlpha, getTransparency), BeerVolumeHandler (glass absorption)
- *     are pinned bit-for-bit against
- *     the reference's own sources compiled here (oracle/_ref, IEEE build) and to ~1e-4
- *     against the reference's -ffast-math release flags (tests/golden/ref_components_*.json).
- *   - kd traversal (intersect / intersectS / intersectTs), Triangle::intersect/getSurface,
- *     PathIntegrator::integrate, recursiveRaytrace, doLightEstimation, TiledIntegrator::render /
- *     renderTile, ImageFilm::addSample / nextPass are restated from the source
- *     but the reference's implementation of them is NOT buildable under this project's
- *     rules (cmake-generated header): for those rows parity is UNPINNED.
+ *     depth of field), area/point lights, shinydiffuse/glossy/coated-glossy/glass/rough-glass/mirror/light
+ *     materials (eval, pdf, sample — rough glass also its two-direction sample —, getSpecular, getAlpha,
+ *     getTransparency), BeerVolumeHandler (glass absorption), image textures, shader nodes and image decoders
+ *     are pinned bit-for-bit against the reference's own sources compiled here (oracle/_ref, IEEE build) and
+ *     to ~1e-4 against the reference's -ffast-math release flags (tests/golden/ref_components_*.json,
+ *     ref_textures_*.json).
+ *   - TiledIntegrator::render / renderPass / renderTile, PathIntegrator::integrate (path caustics included),
+ *     DirectLightIntegrator::integrate, doLightEstimation, estimateAll / OneDirectLight, recursiveRaytrace
+ *     (specular branch, both cases of the glossy branch) and the per-tile roulette stream are pinned bit-for-bit
+ *     against the reference's own integrator sources compiled here (oracle/ref_harness/ref_integrator.cc:
+ *     every sample handed to ImageFilm::addSample, every geometry query and both query counts of fifteen
+ *     cases, tests/golden/ref_integrator_*.json).  The harness provides the bodies of the few Scene:: /
+ *     ImageFilm:: members the integrators call (its header lists them).
+ *   - kd traversal (intersect / intersectS / intersectTs), Triangle::intersect / getSurface and the film's
+ *     filter table are restated from the source, but the reference's implementation of them is NOT buildable
+ *     under this project's rules (cmake-generated header): for those rows parity is UNPINNED except through
+ *     the reference's expected render of test01 (tests/golden/test01_expected.png).
  */
 #ifndef YAF_ORACLE_H
 #define YAF_ORACLE_H

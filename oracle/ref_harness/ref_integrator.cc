@@ -892,6 +892,17 @@ int main()
 		c.srand_seed = 19; c.background[0] = 0.0; c.background[1] = 0.02; c.background[2] = 0.05;
 		cases.push_back(c);
 	}
+	{	// direct lighting through rough glass: DirectLightIntegrator::integrate -> recursiveRaytrace's reflect + transmit glossy case at raydepth 3 (nested:
+		// a trajectory's children split into one trajectory each), all three lights estimated at every hit, transparent shadows through the fake-shadow sheet
+		Case c; c.name = "dl_rough_glass";
+		c.slot_mat[SLOT_A] = M_ROUGH_GLASS; c.slot_mat[SLOT_B] = M_SD_MIRROR_TRANSP; c.slot_mat[SLOT_C] = M_GLOSSY_REC; c.slot_mat[SLOT_D] = M_ROUGH_GLASS_ABS_FAKE;
+		c.lights = {0, 1, 2};
+		c.integrator = {ps("type", "directlighting"), pi("raydepth", 3), pb("caustics", false), pb("do_AO", false), pb("transpShad", true), pi("shadowDepth", 4),
+		                pb("bg_transp_refract", true)};
+		c.render = {pi("AA_passes", 1), pi("AA_minsamples", 2)};
+		c.srand_seed = 23; c.background[0] = 0.3; c.background[1] = 0.2; c.background[2] = 0.1;
+		cases.push_back(c);
+	}
 
 	Emit out;
 	out.raw("{\n\"width\": "); out.raw(std::to_string(W)); out.raw(", \"height\": "); out.raw(std::to_string(H)); out.raw(", \"tile_size\": "); out.raw(std::to_string(TILE));

@@ -16,7 +16,7 @@
  *     DirectLightIntegrator::integrate, doLightEstimation, estimateAll / OneDirectLight, recursiveRaytrace
  *     (specular branch, both cases of the glossy branch) and the per-tile roulette stream are pinned bit-for-bit
  *     against the reference's own integrator sources compiled here (oracle/ref_harness/ref_integrator.cc:
- *     every sample handed to ImageFilm::addSample, every geometry query and both query counts of fifteen
+ *     every sample handed to ImageFilm::addSample, every geometry query and both query counts of sixteen
  *     cases, tests/golden/ref_integrator_*.json).  The harness provides the bodies of the few Scene:: /
  *     ImageFilm:: members the integrators call (its header lists them).
  *   - kd traversal (intersect / intersectS / intersectTs), Triangle::intersect / getSurface and the film's

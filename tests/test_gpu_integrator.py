@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["pt_mis_paths", "pt_three_lights_rr", "pt_recursive", "pt_multipass", "pt_dof", "directlighting",
          "pt_transparent_shadows", "pt_no_recursive", "pt_absorption_aniso", "pt_depth_bias_visibility", "dl_fake_shadows_flat", "pt_degenerate_lobes_clip", "pt_rough_glass",
-         "pt_caustics_default", "pt_caustics_path_no_recursive"]
+         "pt_caustics_default", "pt_caustics_path_no_recursive", "dl_rough_glass"]
 
 
 @pytest.fixture(scope="module")

@@ -25,7 +25,7 @@ from tests.integrator_fixture import case_scene, closest_rays, film_from_samples
 
 CASES = ["pt_mis_paths", "pt_three_lights_rr", "pt_recursive", "pt_multipass", "pt_dof", "directlighting",
          "pt_transparent_shadows", "pt_no_recursive", "pt_absorption_aniso", "pt_depth_bias_visibility", "dl_fake_shadows_flat", "pt_degenerate_lobes_clip", "pt_rough_glass",
-         "pt_caustics_default", "pt_caustics_path_no_recursive"]
+         "pt_caustics_default", "pt_caustics_path_no_recursive", "dl_rough_glass"]
 # one light and roulette off: every sample is a pure function of (pixel, sample index)
 NO_SERIAL_STATE = {"pt_mis_paths", "pt_dof"}
 

@@ -17,8 +17,9 @@ CHILD = textwrap.dedent('''
              "AA_passes", "AA_minsamples", "camera_name", "integrator_name", "bounces", "path_samples", "IOR", "exponent", "transparency",
              "filter_type", "AA_pixelwidth", "raydepth", "absorption", "visibility", "aperture", "bokeh_type", "tile_size", "xstart",
              "element", "name", "texture", "input", "upper_layer", "input1", "input2", "factor", "diffuse_shader", "mirror_shader", "IOR_shader",
-             "texco", "mapping", "mode", "filename", "interpolate", "clipping", "xrepeat", "cropmin_x", "color1", "color2", "value", "bump_shader"]
-    strings = ["shinydiffusemat", "glossy", "glass", "mirror", "light_mat", "coated_glossy", "arealight", "pointlight", "perspective", "pathtracing",
+             "texco", "mapping", "mode", "filename", "interpolate", "clipping", "xrepeat", "cropmin_x", "color1", "color2", "value", "bump_shader",
+             "alpha", "transmit_filter", "fake_shadows", "roughness_shader", "caustic_type", "photon_only", "dispersion_power"]
+    strings = ["shinydiffusemat", "glossy", "glass", "rough_glass", "mirror", "light_mat", "coated_glossy", "arealight", "pointlight", "perspective", "pathtracing", "path", "both",
                "directlighting", "constant", "none", "box", "gauss", "nonsense", "", "cam", "default", "blend_mat", "photonmapping", "sunlight",
                "shader_node", "texture_mapper", "layer", "mix", "value", "image", "t0", "n0", "n1", "uv", "orco", "cube", "sphere", "checker",
                %(root)r + "/tests/golden/test01_tex.png", "bilinear", "mipmap_ewa"]

@@ -492,7 +492,10 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		uint32_t z19 = 0u;
 		if(a.ev_m > 1 && c.level > 0) z19 = ubits(REC(19).z) + (1u << 24);      // the next integrate() call of this camera sample
 		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(z19), alpha);
-		hot_zero_tot(a, slot, h);
+		// (a record pass follows the paths and nothing else: the light estimate's records — 12, 14..18, and 11 without a roulette test to record —
+		// are neither written nor read by it; the final pass sets every one of them up again)
+		const bool rec = a.replay == 1;
+		if(!rec) hot_zero_tot(a, slot, h);
 		c.path_i = 0; c.depth = 0;
 		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
 		{
@@ -501,7 +504,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 			c.dl_on_sp0 = 1;
 			return W_DL_NEXT;
 		}
-		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
+		if(!rec) HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
 		return W_DL_DONE;
 	}
 	if(!got) { ++c.path_i; return W_START_PATH; }                                              // :218 / :259-266
@@ -520,7 +523,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
 	// .w of 8..10: p_ray.dir_ of the segment that ended here — what Material::sample leaves in `wi` when it samples nothing
 	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, dir.x); REC(9) = f4(hit.ng, dir.y); REC(10) = f4(pwo, dir.z);
-	hot_zero_tot(a, slot, h);
+	if(a.replay != 1) hot_zero_tot(a, slot, h);
 	if(YAFGPU_FEAT_RECURSE && (mb & kVolumetric) && c.stage == kStDepth && pm.has_vol_i && dot(hit.n, pwo) < 0.f)
 	{	// integrator_path_tracer.cc:276-279: the segment ran inside an absorbing material (lcol does not depend on it)
 		const float4 r11 = HGET(11);
@@ -531,7 +534,6 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	{	// record pass: note the call (its depth: 0 at the first hit), skip the estimate — it does not steer the path
 		const uint32_t e = wf_event(a, slot, ubits(misc.z), c.path_i);
 		a.ev_flags[e] |= 1u << (c.stage == kStFirst ? 0 : c.depth);
-		HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));
 		return W_DL_DONE;
 	}
 	if(want_dl)
@@ -553,7 +555,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		c.dl_on_sp0 = 0;
 		return W_DL_NEXT;
 	}
-	HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));   // l_end == 0: no light estimate ran
+	if(a.replay != 1) HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));   // l_end == 0: no light estimate ran
 	return W_DL_DONE;
 }
 
@@ -668,9 +670,11 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool beside)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	const Col total = c3(HGET(18));
-	const int l_end = (int)((ubits(HGET(14).w) >> 8) & 0xffu);
-	hot_zero_tot(a, slot, h);                       // taken: nothing reads it again before the next vertex zeroes it
+	// a record pass: no estimate ran, and of the path's records only the throughput matters, and only where a roulette test will want its probability
+	const bool rec = a.replay == 1, rec_thr = !rec || rp.bounces - 1 > rp.rr_min_bounces;
+	const Col total = rec ? mkc(0.f, 0.f, 0.f) : c3(HGET(18));
+	const int l_end = rec ? 0 : (int)((ubits(HGET(14).w) >> 8) & 0xffu);
+	if(!rec) hot_zero_tot(a, slot, h);              // taken: nothing reads it again before the next vertex zeroes it
 	if(c.stage == kStPrimary)
 	{
 		const uint32_t bsdfs0 = ubits(REC(5).w);
@@ -698,7 +702,8 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 	const yafgpu_material &pm = *pm_p;
 	Col lcol = mkc(0.f, 0.f, 0.f);
 	if(l_end > 0) lcol = total * (float)sc.n_lights;
-	float4 r11 = HGET(11), r12 = HGET(12);
+	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	float4 r11 = rec_thr ? HGET(11) : z4, r12 = rec ? z4 : HGET(12);
 	Col throughput = c3(r11), path_col = c3(r12);
 	if(c.stage == kStFirst)
 	{
@@ -708,7 +713,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 			lcol = lcol + mat_emit(pm, dummy, mk(0.f, 0.f, 0.f), false);
 		}
 		path_col = path_col + lcol * throughput;                                                // :228
-		HSET(12, f4(path_col, r12.w));
+		if(!rec) HSET(12, f4(path_col, r12.w));
 		c.depth = 1;
 		if(beside)
 		{	// st_extend's work was done by st_beside: throughput *= scol (:251), include_lights_ = caustic (:253)
@@ -766,7 +771,8 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 		c.stage = kStDepth;
 		return W_NEXT_VERTEX;
 	}
-	HSET(11, f4(throughput, r11.w)); HSET(12, f4(path_col, r12.w));
+	if(rec_thr) HSET(11, f4(throughput, r11.w));
+	if(!rec) HSET(12, f4(path_col, r12.w));
 	if(alive && c.depth < rp.bounces) return W_EXTEND;
 	++c.path_i;
 	return W_START_PATH;
@@ -798,8 +804,11 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
 	REC(6).w = w;
 	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
-	const float4 r11 = HGET(11);
-	HSET(11, f4(c3(r11) * scol, r11.w));
+	if(a.replay != 1 || ra.rp.bounces - 1 > ra.rp.rr_min_bounces)      // (a record pass without a roulette test to record has no use for the throughput)
+	{
+		const float4 r11 = HGET(11);
+		HSET(11, f4(c3(r11) * scol, r11.w));
+	}
 	// :252-253 caustic = trace_caustics_ && the lobe sampled is specular, glossy or a filter; state.include_lights_ = caustic
 	c.incl = (ra.rp.trace_caustics && (bs.sampled & (kSpecular | kGlossy | kFilter))) ? 1 : 0;
 	REC(0) = f4(hit.p, ra.ray_min_dist); REC(1) = f4(p_dir, -1.f);
@@ -813,7 +822,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const DivState dv = wf_div(a, slot, c.level);
 	const int n_paths = max(1, rp.path_samples / dv.division);                                     // :182 n_samples
-	if(c.path_i >= n_paths) { c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
+	if(c.path_i >= n_paths) { if(a.replay != 1) c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
 	c.incl = 0;                                                                                   // :211 state.include_lights_ = false
 	const float4 p = REC(3);
 	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
@@ -835,7 +844,11 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
 	REC(6).w = w;
 	if(bs.sampled == kNone || !YAFGPU_ACC_ZERO_FLAG) REC(10) = f4(wo0, 0.f);      // pwo = wo: only a segment that sampled nothing keeps it (:224, st_after_closest)
-	if(c.path_i == 0)
+	if(a.replay == 1)
+	{	// (record pass: the throughput alone, and only for a roulette test's probability)
+		if(rp.bounces - 1 > rp.rr_min_bounces) HSET(11, f4(scol, 0.f));
+	}
+	else if(c.path_i == 0)
 	{	// the level's first path sample: path colour 0 and the roulette stream of the per-sample mode start here
 		Mwc rr; rr.init(fnv32a(ordinal) + 123u);
 		HSET(11, f4(scol, fbits(rr.x)));

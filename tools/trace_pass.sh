@@ -13,7 +13,9 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "yafgpu" in r["Kernel_Na
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # passes start with wf_generate; the roofline's extra passes come last: take the 3rd timed pass = 4th wf_generate overall (1 warmup + 3 steps)
 gens = [i for i, r in enumerate(rows) if "wf_generate" in r["Kernel_Name"]]
-lo, hi = gens[3], gens[4] if len(gens) > 4 else len(rows)
+import os
+seg = int(os.environ.get("TRACE_SEG", "3"))      # which wf_generate-to-wf_generate stretch (a pass of a chunked or replayed render has several)
+lo, hi = gens[seg], gens[seg + 1] if len(gens) > seg + 1 else len(rows)
 t0 = int(rows[lo]["Start_Timestamp"])
 end_prev = t0
 for r in rows[lo:hi]:

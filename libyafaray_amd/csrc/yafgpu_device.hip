@@ -1717,34 +1717,41 @@ static int wf_grid(const void *kernel, int cus)
 // other scene takes the general kernel of this unit.  YAFGPU_SHADE_VARIANT=general forces the general kernel.
 extern "C" {
 #define YG_DECLARE_SHADE_VARIANT(name) \
-	void yafgpu_shade_##name##_describe(uint32_t *, int *); const void *yafgpu_shade_##name##_kernel(); \
+	void yafgpu_shade_##name##_describe(uint32_t *, int *, int *); const void *yafgpu_shade_##name##_kernel(); \
 	int yafgpu_shade_##name##_launch(const void *, size_t, int, hipStream_t);
 YG_DECLARE_SHADE_VARIANT(diffuse)
 YG_DECLARE_SHADE_VARIANT(glossy)
+YG_DECLARE_SHADE_VARIANT(diffuse_rec)
+YG_DECLARE_SHADE_VARIANT(glossy_rec)
 YG_DECLARE_SHADE_VARIANT(full)
 #undef YG_DECLARE_SHADE_VARIANT
 }
 struct ShadeVariant
 {
 	const char *name;
-	void (*describe)(uint32_t *, int *);
+	void (*describe)(uint32_t *, int *, int *);
 	const void *(*kernel)();
 	int (*launch)(const void *, size_t, int, hipStream_t);
 };
 static const ShadeVariant kShadeVariants[] = {
 	{"diffuse", yafgpu_shade_diffuse_describe, yafgpu_shade_diffuse_kernel, yafgpu_shade_diffuse_launch},
 	{"glossy", yafgpu_shade_glossy_describe, yafgpu_shade_glossy_kernel, yafgpu_shade_glossy_launch},
+	// (the programs of a serial-state replay's record pass: no light estimate, YAFGPU_FEAT_LIGHTS=0)
+	{"diffuse_rec", yafgpu_shade_diffuse_rec_describe, yafgpu_shade_diffuse_rec_kernel, yafgpu_shade_diffuse_rec_launch},
+	{"glossy_rec", yafgpu_shade_glossy_rec_describe, yafgpu_shade_glossy_rec_kernel, yafgpu_shade_glossy_rec_launch},
 	{"full", yafgpu_shade_full_describe, yafgpu_shade_full_kernel, yafgpu_shade_full_launch},      // everything but shader nodes
 };
-static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames)
+static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames, bool record_pass = false)
 {
 	if(const char *e = std::getenv("YAFGPU_SHADE_VARIANT")) if(std::strcmp(e, "general") == 0) return nullptr;
+	if(record_pass) if(const char *e = std::getenv("YAFGPU_RECORD_VARIANT")) if(std::atoi(e) == 0) return nullptr;      // (A/B: the record pass on the pass's own kernel)
 	const bool needs_recurse = frames > 0 || s->has_volumetric;
 	if(s->has_textures || s->has_aniso) return nullptr;        // the variants are built without shader nodes and without the anisotropic lobe
 	for(const ShadeVariant &v : kShadeVariants)
 	{
-		uint32_t mask = 0u; int recurse = 0;
-		v.describe(&mask, &recurse);
+		uint32_t mask = 0u; int recurse = 0, lights = 1;
+		v.describe(&mask, &recurse, &lights);
+		if((lights == 0) != record_pass) continue;
 		if((s->mat_mask & ~mask) == 0u && (recurse || !needs_recurse)) return &v;
 	}
 	return nullptr;
@@ -2068,6 +2075,9 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 	if(std::getenv("YAFGPU_VERBOSE")) std::fprintf(stderr, "[yafgpu] shading kernel: %s (materials 0x%x, frames %d), serial replay: %s\n", shade_variant ? shade_variant->name : "general", s->mat_mask, frames,
 	                                               replay ? (replay_lights ? (need_rr ? "roulette + light counter" : "light counter") : "roulette") : "off");
 	const int g_shade = wf_grid(shade_variant ? shade_variant->kernel() : (const void *)wf_shade, cus);
+	// a record pass runs its own, smaller program where one was built for the scene's materials (else the pass's kernel, which branches on WfArgs::replay)
+	const ShadeVariant *record_variant = replay ? pick_shade_variant(s, frames, true) : nullptr;
+	const int g_shade_rec = record_variant ? wf_grid(record_variant->kernel(), cus) : g_shade;
 	// upper bound of kd-tree queries per path = iterations needed (every path advances one query per iteration)
 	int r_all = 0, r_one = 0;
 	for(int i = 0; i < s->n_lights; ++i)
@@ -2197,7 +2207,8 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 				}
 				int variant_rc = 0;
 				if((rc = timed(2, [&] {
-					if(shade_variant) variant_rc = shade_variant->launch(&a, sizeof a, g_shade, stream);
+					if(record && record_variant) variant_rc = record_variant->launch(&a, sizeof a, g_shade_rec, stream);
+					else if(shade_variant) variant_rc = shade_variant->launch(&a, sizeof a, g_shade, stream);
 					else hipLaunchKernelGGL(wf_shade, dim3(g_shade), dim3(kBlock), 0, stream, a); }))) return rc;
 				if(variant_rc) return fail(-21, "shading kernel variant and main unit disagree on the argument layout");
 				// swap queues: what shade produced is the next iteration's input

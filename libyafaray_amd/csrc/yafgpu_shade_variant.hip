@@ -4,7 +4,9 @@
 // and scratch budget is set by the union of them all (168 VGPRs + 116 B of scratch at 3 waves per SIMD).  Scenes
 // that use a subset run a kernel compiled for that subset: this file is compiled once per variant with
 //
-//   -DYAFGPU_VARIANT_NAME=<name>  -DYAFGPU_MAT_MASK=<bit per YAFGPU_MAT_* handled>  -DYAFGPU_FEAT_RECURSE=<0|1>
+//   -DYAFGPU_VARIANT_NAME=<name>  -DYAFGPU_MAT_MASK=<bit per YAFGPU_MAT_* handled>  -DYAFGPU_FEAT_RECURSE=<0|1>  [-DYAFGPU_FEAT_LIGHTS=0]
+//
+// (FEAT_LIGHTS=0: the program of a serial-state replay's RECORD pass — no light estimate, the vertex of a resume in registers)
 //
 // and includes the main unit with everything but wf_shade and what it calls compiled out.  All of its symbols live in
 // their own namespace (the macro below renames `yafgpu`), so the variants and the main unit link into one library; the
@@ -24,9 +26,9 @@ namespace vns = yafgpu;
 extern "C" {
 
 // material types / features this variant was compiled for
-void YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _describe)(uint32_t *mat_mask, int *recurse)
+void YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _describe)(uint32_t *mat_mask, int *recurse, int *lights)
 {
-	*mat_mask = (uint32_t)(YAFGPU_MAT_MASK); *recurse = YAFGPU_FEAT_RECURSE;
+	*mat_mask = (uint32_t)(YAFGPU_MAT_MASK); *recurse = YAFGPU_FEAT_RECURSE; *lights = YAFGPU_FEAT_LIGHTS;
 }
 const void *YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _kernel)() { return (const void *)vns::wf_shade; }
 // args: the main unit's WfArgs (same definition, so the same layout)

@@ -292,7 +292,16 @@ enum { W_AFTER_CLOSEST, W_AFTER_SHADOW, W_DL_NEXT, W_DL_EVAL, W_DL_DONE, W_RECUR
 #endif
 // tot_zero: the same for record 18, the estimate's sum over the lights closed so far (zero from the start of a vertex's estimate to
 // its first closed light, dead once st_dl_done has taken it): bit 19 (kDlcTotZero).
-struct Hot { float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty, acc_zero, tot_zero; };
+#ifndef YAFGPU_FEAT_LIGHTS
+#define YAFGPU_FEAT_LIGHTS 1      // (see below, at A_REPLAY)
+#endif
+struct Hot
+{
+	float4 r11, r12, r14, r15, r16, r17, r18; uint32_t valid, dirty, acc_zero, tot_zero;
+#if !YAFGPU_FEAT_LIGHTS
+	float4 vt[8]; uint32_t vvalid;      // records 3..10 of this resume's vertex, in registers (a record pass's kernel)
+#endif
+};
 constexpr uint32_t kHotAccBits = 0x70u, kHot14 = 0x08u, kHot18 = 0x80u;
 constexpr uint32_t kDlcAccZero = 1u << 18, kDlcTotZero = 1u << 19;
 template<int K> constexpr bool hot_cached() { return K == 11 || K == 12 || K == 14 || K == 18 || (YAFGPU_HOT_ACC && K >= 15 && K <= 17); }
@@ -406,11 +415,41 @@ YG_DEV void hot_flush(const WfArgs &a, uint32_t slot, const Hot &h, bool to_clos
 }
 #define HGET(k) hot_get<k>(a, slot, h)
 #define HSET(k, v) hot_set<k>(a, slot, h, (v))
+#if !YAFGPU_FEAT_LIGHTS
+// the vertex records of a record pass's kernel: kept in registers for the resume; record 6 also goes to memory (its .w is integrate()'s `w`,
+// which lives across resumes), records 3..5 only when a later path sample will start from the camera hit again, 7..10 never
+template<int K> YG_DEV void vtx_set(const WfArgs &a, uint32_t slot, Hot &h, float4 v)
+{
+	static_assert(K >= 3 && K <= 10, "not a vertex record");
+	h.vt[K - 3] = v; h.vvalid |= 1u << (K - 3);
+	if(K == 6 || (K <= 5 && a.ra.rp.path_samples > 1)) REC(K) = v;
+}
+template<int K> YG_DEV float4 vtx_get(const WfArgs &a, uint32_t slot, Hot &h)
+{
+	static_assert(K >= 3 && K <= 10, "not a vertex record");
+	return (h.vvalid & (1u << (K - 3))) ? h.vt[K - 3] : REC(K);
+}
+#endif
 
 #define FREC(L, j) wf_rec(a, kWfRecs + a.frame_recs * (L) + (j), slot)      // recursion frames, see st_recurse
 // path caustics (yafgpu_render_params::trace_caustics): a kernel built with 0 serves renders with caustic_type "none"
 #ifndef YAFGPU_FEAT_CAUSTIC
 #define YAFGPU_FEAT_CAUSTIC 1
+#endif
+// The light estimate.  A kernel built with 0 is the program of a RECORD pass and nothing else (WfArgs::replay == 1 is a given): it follows the
+// paths, notes the light calls and the roulette probabilities, keeps the hits — no shadow parks, no estimate steps, and the vertex a hit makes
+// goes to the sampler of the same resume in registers instead of through records 7..10 (and 3..5 when no later path sample needs them).
+#ifndef YAFGPU_FEAT_LIGHTS
+#define YAFGPU_FEAT_LIGHTS 1
+#endif
+#if YAFGPU_FEAT_LIGHTS
+#define A_REPLAY (a.replay)
+#define VGET(k) REC(k)
+#define VSET(k, v) (REC(k) = (v))
+#else
+#define A_REPLAY 1
+#define VGET(k) vtx_get<k>(a, slot, h)
+#define VSET(k, v) vtx_set<k>(a, slot, h, (v))
 #endif
 // recursiveRaytrace (frames, absorption): a kernel built with 0 serves scenes without specular / filter materials
 #ifndef YAFGPU_FEAT_RECURSE
@@ -452,7 +491,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const int tri = (int)ubits(ans.x);
 	const bool got = tri >= 0;
-	if(a.replay == 1 && a.hit_cache != nullptr)      // record pass: keep the answer for the final pass (the control word is still the park's)
+	if(A_REPLAY == 1 && a.hit_cache != nullptr)      // record pass: keep the answer for the final pass (the control word is still the park's)
 		a.hit_cache[wf_hit_key(a, slot, pack_ctl(c), a.ev_m > 1 ? ubits(REC(19).z) : 0u)] = ans;
 	if(c.stage == kStPrimary)
 	{
@@ -487,17 +526,17 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 			const float m_alpha = mat_alpha(m, dat0, sp0, wo0);
 			alpha = m_alpha + (1.f - m_alpha) * (rp.bg_transp ? 0.f : 1.f);
 		}
-		REC(3) = f4(sp0.p, fbits((uint32_t)sp0.mat)); REC(4) = f4(sp0.n, 0.f); REC(5) = f4(sp0.ng, fbits(bsdfs0)); REC(6) = f4(wo0, 0.f);
+		VSET(3, f4(sp0.p, fbits((uint32_t)sp0.mat))); VSET(4, f4(sp0.n, 0.f)); VSET(5, f4(sp0.ng, fbits(bsdfs0))); VSET(6, f4(wo0, 0.f));
 		// (throughput, path colour and the roulette stream of this level's path samples: st_start_path, at the first of them)
 		uint32_t z19 = 0u;
 		if(a.ev_m > 1 && c.level > 0) z19 = ubits(REC(19).z) + (1u << 24);      // the next integrate() call of this camera sample
 		REC(19) = make_float4(fbits(0u), fbits((uint32_t)kNone), fbits(z19), alpha);
 		// (a record pass follows the paths and nothing else: the light estimate's records — 12, 14..18, and 11 without a roulette test to record —
 		// are neither written nor read by it; the final pass sets every one of them up again)
-		const bool rec = a.replay == 1;
+		const bool rec = A_REPLAY == 1;
 		if(!rec) hot_zero_tot(a, slot, h);
 		c.path_i = 0; c.depth = 0;
-		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && a.replay != 1)      // (a record pass only follows the paths)
+		if((bsdfs0 & kDiffuse) && sc.n_lights > 0 && A_REPLAY != 1)      // (a record pass only follows the paths)
 		{
 			HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, sc.n_lights, 0, 0))));
 			hot_zero_acc(a, slot, h);
@@ -522,15 +561,15 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 	V3 pwo = -dir;                                                                              // :271
 	if(c.stage == kStFirst && ubits(misc.y) == kNone) pwo = v3(REC(10));                       // :224: keeps the first segment's pwo
 	// .w of 8..10: p_ray.dir_ of the segment that ended here — what Material::sample leaves in `wi` when it samples nothing
-	REC(7) = f4(hit.p, fbits((uint32_t)hit.mat)); REC(8) = f4(hit.n, dir.x); REC(9) = f4(hit.ng, dir.y); REC(10) = f4(pwo, dir.z);
-	if(a.replay != 1) hot_zero_tot(a, slot, h);
+	VSET(7, f4(hit.p, fbits((uint32_t)hit.mat))); VSET(8, f4(hit.n, dir.x)); VSET(9, f4(hit.ng, dir.y)); VSET(10, f4(pwo, dir.z));
+	if(A_REPLAY != 1) hot_zero_tot(a, slot, h);
 	if(YAFGPU_FEAT_RECURSE && (mb & kVolumetric) && c.stage == kStDepth && pm.has_vol_i && dot(hit.n, pwo) < 0.f)
 	{	// integrator_path_tracer.cc:276-279: the segment ran inside an absorbing material (lcol does not depend on it)
 		const float4 r11 = HGET(11);
 		HSET(11, f4(c3(r11) * beer_transmittance(pm.beer_sigma, ans.y), r11.w));
 	}
 	const bool want_dl = sc.n_lights > 0 && (c.stage == kStFirst || (mb & kDiffuse));
-	if(want_dl && a.replay == 1)
+	if(want_dl && A_REPLAY == 1)
 	{	// record pass: note the call (its depth: 0 at the first hit), skip the estimate — it does not steer the path
 		const uint32_t e = wf_event(a, slot, ubits(misc.z), c.path_i);
 		a.ev_flags[e] |= 1u << (c.stage == kStFirst ? 0 : c.depth);
@@ -544,7 +583,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		{
 			// correlative_sample_number_[thread]: the number of calls before this one in the reference's single-thread
 			// order, replayed (lc_base: where this sample starts); without the replay a per-sample ordinal stands in
-			const uint32_t counter = (a.replay == 2 && a.replay_lights) ? a.lc_base[slot] + calls : ordinal * 16u + calls;
+			const uint32_t counter = (A_REPLAY == 2 && a.replay_lights) ? a.lc_base[slot] + calls : ordinal * 16u + calls;
 			Halton h2; h2.init(2u);
 			h2.set_start(rp.base_sampling_offset + counter - 1u);
 			lnum = min((int)(h2.next() * (float)sc.n_lights), sc.n_lights - 1);
@@ -555,7 +594,7 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 		c.dl_on_sp0 = 0;
 		return W_DL_NEXT;
 	}
-	if(a.replay != 1) HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));   // l_end == 0: no light estimate ran
+	if(A_REPLAY != 1) HSET(14, make_float4(0.f, 0.f, 0.f, fbits(pack_dlc(0, 0, 0, 0))));   // l_end == 0: no light estimate ran
 	return W_DL_DONE;
 }
 
@@ -671,13 +710,13 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	// a record pass: no estimate ran, and of the path's records only the throughput matters, and only where a roulette test will want its probability
-	const bool rec = a.replay == 1, rec_thr = !rec || rp.bounces - 1 > rp.rr_min_bounces;
+	const bool rec = A_REPLAY == 1, rec_thr = !rec || rp.bounces - 1 > rp.rr_min_bounces;
 	const Col total = rec ? mkc(0.f, 0.f, 0.f) : c3(HGET(18));
 	const int l_end = rec ? 0 : (int)((ubits(HGET(14).w) >> 8) & 0xffu);
 	if(!rec) hot_zero_tot(a, slot, h);              // taken: nothing reads it again before the next vertex zeroes it
 	if(c.stage == kStPrimary)
 	{
-		const uint32_t bsdfs0 = ubits(REC(5).w);
+		const uint32_t bsdfs0 = ubits(VGET(5).w);
 		if(bsdfs0 & kDiffuse) c.col = c.col + total;                                            // :156
 		const uint32_t path_flags = rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse;
 		if(rp.integrator != YAFGPU_INTEGRATOR_PATH || !(bsdfs0 & path_flags)) return W_RECURSE;
@@ -685,7 +724,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 		if(beside) { c.stage = kStFirst; return W_NEXT_VERTEX; }      // st_start_path's work was done by st_beside
 		return W_START_PATH;
 	}
-	const yafgpu_material &pm_rec = sc.mats[(int)ubits(REC(7).w)];
+	const yafgpu_material &pm_rec = sc.mats[(int)ubits(VGET(7).w)];
 	BsdfDat dat_n;
 	const uint32_t mb = mat_init_bsdf(pm_rec, dat_n);      // the flags do not depend on the nodes
 	yafgpu_material pm_tmp; (void)pm_tmp;
@@ -731,10 +770,10 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 	if(c.depth > rp.rr_min_bounces)
 	{	// Russian roulette :282-288
 		const float probability = smax(throughput.r, smax(throughput.g, throughput.b));
-		if(a.replay != 0)
+		if(A_REPLAY != 0)
 		{
 			const uint32_t e = wf_event(a, slot, a.ev_m > 1 ? ubits(REC(19).z) : 0u, c.path_i);
-			if(a.replay == 1)
+			if(A_REPLAY == 1)
 			{	// record: the test and its probability; the draw is the tile stream's, made by wf_replay_scan in sample order
 				a.ev_p[(size_t)e * (size_t)max(rp.bounces - 1, 1) + (size_t)(c.depth - 1)] = probability;
 				a.ev_flags[e] |= 1u << (16 + c.depth);
@@ -754,7 +793,7 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 	}
 	if(alive)
 	{
-		if(caustic && (mb & kEmit))
+		if(caustic && (mb & kEmit) && !rec)
 		{	// :290 a vertex reached through a caustic lobe adds what it emits, its lights included (include_lights_ is set)
 			const float4 p7 = REC(7);
 			SurfPt hp; hp.p = v3(p7); hp.n = v3(REC(8)); hp.ng = v3(REC(9)); hp.mat = (int)ubits(p7.w);
@@ -782,10 +821,10 @@ YG_DEV int st_dl_done(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, bool besid
 YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
-	const float4 p = REC(7);
-	SurfPt hit; make_sp(v3(p), v3(REC(8)), v3(REC(9)), (int)ubits(p.w), hit);
+	const float4 p = VGET(7);
+	SurfPt hit; make_sp(v3(p), v3(VGET(8)), v3(VGET(9)), (int)ubits(p.w), hit);
 	wf_frame_parked(a, slot, 1, hit);
-	const float4 r10 = REC(10);
+	const float4 r10 = VGET(10);
 	const V3 pwo = v3(r10);
 	yafgpu_material pm_tmp;
 	const yafgpu_material &pm = wf_mat_parked(a, slot, 1, hit, pm_tmp);
@@ -800,11 +839,11 @@ YG_DEV int st_extend(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c)
 	// sample returns Rgb(1) and nothing else, material_shiny_diffuse.cc sample()): the path then carries on straight
 	// through with the previous weight (integrator_path_tracer.cc:243-249).  They live in REC(6).w and in 8..10.w.
 	float w = REC(6).w;
-	V3 p_dir = mk(REC(8).w, REC(9).w, r10.w);
+	V3 p_dir = mk(VGET(8).w, VGET(9).w, r10.w);
 	const Col scol = mat_sample(pm, dat_n, hit, pwo, p_dir, bs, w) * w;
 	REC(6).w = w;
 	if(is_black(scol)) { ++c.path_i; return W_START_PATH; }                                      // :249 `break`
-	if(a.replay != 1 || ra.rp.bounces - 1 > ra.rp.rr_min_bounces)      // (a record pass without a roulette test to record has no use for the throughput)
+	if(A_REPLAY != 1 || ra.rp.bounces - 1 > ra.rp.rr_min_bounces)      // (a record pass without a roulette test to record has no use for the throughput)
 	{
 		const float4 r11 = HGET(11);
 		HSET(11, f4(c3(r11) * scol, r11.w));
@@ -822,12 +861,12 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	const DivState dv = wf_div(a, slot, c.level);
 	const int n_paths = max(1, rp.path_samples / dv.division);                                     // :182 n_samples
-	if(c.path_i >= n_paths) { if(a.replay != 1) c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
+	if(c.path_i >= n_paths) { if(A_REPLAY != 1) c.col = c.col + c3(HGET(12)) / (float)n_paths; return W_RECURSE; } // :297
 	c.incl = 0;                                                                                   // :211 state.include_lights_ = false
-	const float4 p = REC(3);
-	SurfPt sp0; make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp0);
+	const float4 p = VGET(3);
+	SurfPt sp0; make_sp(v3(p), v3(VGET(4)), v3(VGET(5)), (int)ubits(p.w), sp0);
 	wf_frame_parked(a, slot, 0, sp0);
-	const V3 wo0 = v3(REC(6));
+	const V3 wo0 = v3(VGET(6));
 	yafgpu_material m_tmp;
 	const yafgpu_material &m = wf_mat_parked(a, slot, 0, sp0, m_tmp);
 	BsdfDat dat0; mat_init_bsdf(m, dat0);
@@ -838,13 +877,13 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 	if(dv.division > 1) { bs.s_1 = add_mod_1(bs.s_1, dv.dc_1); bs.s_2 = add_mod_1(bs.s_2, dv.dc_2); }   // :201-205
 	bs.pdf = 0.f; bs.sampled = kNone;
 	bs.flags = (rp.no_recursive ? (uint32_t)kAll : (uint32_t)kDiffuse) | kDiffuse | kReflect | kTransmit;
-	const float4 r6 = REC(6);
+	const float4 r6 = VGET(6);
 	float w = r6.w;                                   // integrate()'s `w`: 0 at its start, then whatever the last sample() left
 	V3 p_dir = mk(0.f, 0.f, 0.f);
 	const Col scol = mat_sample(m, dat0, sp0, wo0, p_dir, bs, w) * w;
 	REC(6).w = w;
 	if(bs.sampled == kNone || !YAFGPU_ACC_ZERO_FLAG) REC(10) = f4(wo0, 0.f);      // pwo = wo: only a segment that sampled nothing keeps it (:224, st_after_closest)
-	if(a.replay == 1)
+	if(A_REPLAY == 1)
 	{	// (record pass: the throughput alone, and only for a roulette test's probability)
 		if(rp.bounces - 1 > rp.rr_min_bounces) HSET(11, f4(scol, 0.f));
 	}
@@ -871,7 +910,7 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
-	if(!a.speculate || a.replay == 1 || a.frames != 0 || rp.integrator != YAFGPU_INTEGRATOR_PATH) return W_PARK_SHADOW;      // (a record pass has no shadow parks anyway)
+	if(!a.speculate || A_REPLAY == 1 || a.frames != 0 || rp.integrator != YAFGPU_INTEGRATOR_PATH) return W_PARK_SHADOW;      // (a record pass has no shadow parks anyway)
 	{	// the last pair of the estimate?
 		const uint32_t w14 = ubits(HGET(14).w);
 		const int li = (int)(w14 & 0xffu), l_end = (int)((w14 >> 8) & 0xffu), is = (int)(w14 >> 20);
@@ -919,7 +958,7 @@ YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pi
 	if(c.stage == kStDepth && c.depth > rp.rr_min_bounces)
 	{	// a roulette test stands between the estimate and the next segment (:282-288).  With the serial-state replay its outcome is
 		// already on the table (ev_kill, from the tile's stream); a per-sample stream would have to be drawn from here: no shortcut then
-		if(a.replay != 2) return W_PARK_SHADOW;
+		if(A_REPLAY != 2) return W_PARK_SHADOW;
 		const uint32_t e = wf_event(a, slot, a.ev_m > 1 ? ubits(REC(19).z) : 0u, c.path_i);
 		if((int)a.ev_kill[e] == c.depth) return W_PARK_SHADOW;
 	}
@@ -1186,8 +1225,9 @@ YG_DEV int st_return(const WfArgs &a, uint32_t slot, Ctl &c, float &alpha_out)
 YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, const float4 ans, float result[4], int &out_mask)
 {
 	Ctl c = load_ctl(a, slot);
-	const bool beside = c.pc == kPcAfterBoth;        // the shadow pair of a vertex and the next segment's closest hit came back together
-	int where = (c.pc == kPcAfterShadow || beside) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
+	// (a record pass's kernel: every park is for a closest hit)
+	const bool beside = YAFGPU_FEAT_LIGHTS && c.pc == kPcAfterBoth;        // the shadow pair of a vertex and the next segment's closest hit came back together
+	int where = (YAFGPU_FEAT_LIGHTS && (c.pc == kPcAfterShadow || beside)) ? W_AFTER_SHADOW : W_AFTER_CLOSEST;
 	// The records the light-estimate bookkeeping passes from step to step (throughput, path colour, the estimate
 	// in flight and its accumulators) live in registers for the duration of the advance: a resumed shadow answer
 	// loads them in ONE round of loads instead of one dependent round per step (each step used to re-read what the
@@ -1195,6 +1235,9 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// vertex st_after_closest writes to st_dl_eval in registers costs more in spills than the round trip it saves:
 	// 6.9 -> 7.7 ms on C2.)
 	Hot h; h.valid = 0u; h.dirty = 0u; h.acc_zero = 0u; h.tot_zero = 0u;
+#if !YAFGPU_FEAT_LIGHTS
+	h.vvalid = 0u;
+#endif
 	float alpha = 0.f;
 	uint2 verdict = make_uint2(0u, 0u);
 	if(where == W_AFTER_SHADOW)
@@ -1218,14 +1261,17 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 		if(where == W_NEXT_VERTEX) where = W_AFTER_CLOSEST;
 	}
 	if(where == W_AFTER_CLOSEST) where = st_after_closest(a, slot, h, c, ordinal, ans, beside);
-	if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
-	while(where == W_DL_NEXT || where == W_DL_EVAL)
+	if(YAFGPU_FEAT_LIGHTS)
 	{
-		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
-		else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
+		if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
+		while(where == W_DL_NEXT || where == W_DL_EVAL)
+		{
+			if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
+			else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
+		}
 	}
 	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c, false);
-	if(where == W_PARK_SHADOW) where = st_beside(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
+	if(YAFGPU_FEAT_LIGHTS && where == W_PARK_SHADOW) where = st_beside(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
 	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_RECURSE) where = st_recurse(a, slot, c);

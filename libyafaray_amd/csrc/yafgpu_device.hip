@@ -2181,8 +2181,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 					HIP_OK(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
 				}
 				if(!record && a.replay == 2 && a.hit_cache != nullptr)
-				{	// the record pass answered these queries already
-					if((rc = timed(3, [&] { hipLaunchKernelGGL(wf_cached_closest, dim3((uint32_t)cus * 8u), dim3(kBlock), 0, stream, a); }))) return rc;
+				{	// the record pass answered these queries already: wf_shade reads them from its cache where it would read the traversal's answers
 				}
 				else if((rc = timed(0, [&] {
 					if(stats) hipLaunchKernelGGL((wf_trace<false, true>), dim3(g_trace_c), dim3(kBlock), 0, stream, a);

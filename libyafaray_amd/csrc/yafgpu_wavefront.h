@@ -56,7 +56,7 @@ struct WfArgs
 	int ev_m;
 	// The record pass has already answered every closest-hit query the final pass will ask (the same paths, cut short by the roulette
 	// kills): it keeps the answers — one per (call, path sample, segment), hit_k per camera sample — and the final pass's closest-hit
-	// launches become look-ups (wf_cached_closest).  nullptr: not kept (too many per sample, or a stats pass), the rays are traced again.
+	// launches are dropped: wf_shade looks the answers up (wf_hit_key).  nullptr: not kept (too many per sample, or a stats pass), the rays are traced again.
 	float4 *hit_cache; int hit_k;
 	uint32_t *ev_flags;               // [(path * ev_m + call) * P + path_sample]: bit d = light call at depth d, bit 16 + d = roulette test at depth d
 	float *ev_p;                      // [(path * P + path_sample) * (bounces - 1) + d - 1]: probability of the test at depth d
@@ -482,6 +482,15 @@ YG_DEV uint32_t wf_hit_key(const WfArgs &a, uint32_t slot, uint32_t ctl, uint32_
 	else { ps = (uint32_t)path_i; seg = stage == kStFirst ? 1u : 1u + (uint32_t)depth; }
 	call = min(call, (uint32_t)a.ev_m - 1u); seg = min(seg, per_path - 1u); ps = min(ps, n_ps - 1u);
 	return slot * (uint32_t)a.hit_k + (call * n_ps + ps) * per_path + seg;
+}
+// the control word a segment parked BESIDE a shadow pair (st_beside) would have been parked with by st_start_path / st_extend after the
+// pair: camera hit -> first segment; first hit -> depth 1; depth d -> depth d + 1 (the word in record 13 is still the vertex's)
+YG_DEV uint32_t wf_ctl_of_beside(uint32_t ctl)
+{
+	const uint32_t stage = (ctl >> 2) & 3u, depth = (ctl >> 8) & 0xfu;
+	const uint32_t stage_n = stage == (uint32_t)kStPrimary ? (uint32_t)kStFirst : (uint32_t)kStDepth;
+	const uint32_t depth_n = stage == (uint32_t)kStPrimary ? 0u : (stage == (uint32_t)kStFirst ? 1u : depth + 1u);
+	return (ctl & ~((3u << 2) | (0xfu << 8))) | (stage_n << 2) | (depth_n << 8);
 }
 
 // the closest-hit query of this path was answered: shade the new vertex up to its light estimate
@@ -1899,33 +1908,6 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 
 // Scene::isShadowed with transparent shadows (scene.cc:996-1035) over the shadow queue: one lane per ray, no refill —
 // the feature path for scenes with transparent materials and transpShad, not the benchmark path.
-// The final pass of a serial-state replay whose record pass kept its closest-hit answers (WfArgs::hit_cache): every ray of the
-// closest-hit queue gets its answer by look-up, at its queue position like wf_trace's.
-__global__ __launch_bounds__(kBlock) void wf_cached_closest(const WfArgs a)
-{
-	const uint32_t n = a.cnt_in[0];
-	const uint32_t *q = a.q_closest_in;
-	const size_t c = a.cap;
-	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-	{
-		uint32_t slot = q ? q[i] : i;
-		const bool beside = (slot >> 31) != 0u;
-		slot &= 0x7fffffffu;
-		uint32_t ctl = ubits(a.state[13 * c + slot].w);
-		if(beside)
-		{	// parked beside a shadow pair (st_beside): the control word is still the vertex's — the segment is the one st_start_path /
-			// st_extend would have parked after it: camera hit -> first segment; first hit -> depth 1; depth d -> depth d + 1
-			const uint32_t stage = (ctl >> 2) & 3u, depth = (ctl >> 8) & 0xfu;
-			const uint32_t stage_n = stage == (uint32_t)kStPrimary ? (uint32_t)kStFirst : (uint32_t)kStDepth;
-			const uint32_t depth_n = stage == (uint32_t)kStPrimary ? 0u : (stage == (uint32_t)kStFirst ? 1u : depth + 1u);
-			ctl = (ctl & ~((3u << 2) | (0xfu << 8))) | (stage_n << 2) | (depth_n << 8);
-		}
-		const uint32_t z19 = a.ev_m > 1 ? ubits(a.state[19 * c + slot].z) : 0u;
-		a.state[2 * c + i] = a.hit_cache[wf_hit_key(a, slot, ctl, z19)];
-	}
-	if(a.ra.counters != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && n)
-		atomicAdd((unsigned long long *)&a.ra.counters->rays_closest, (unsigned long long)n);
-}
 
 __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 {
@@ -2034,6 +2016,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const uint32_t nc = a.cnt_in[0], nr = a.cnt_in[4];
 	const uint32_t total = nc + nr;
+	// (the closest-hit queries a final pass answers from the record pass's cache count as the rays they stand for)
+	if(YAFGPU_FEAT_LIGHTS && a.replay == 2 && a.hit_cache != nullptr && a.ra.counters != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && nc)
+		atomicAdd((unsigned long long *)&a.ra.counters->rays_closest, (unsigned long long)nc);
 	const uint32_t per_block = (uint32_t)kBlock * kItems;
 	for(uint32_t base = blockIdx.x * per_block; base < total; base += gridDim.x * per_block)
 	{
@@ -2053,7 +2038,18 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 				slot = (i < nc) ? (a.q_closest_in ? (a.q_closest_in[i] & 0x7fffffffu) : i) : a.q_resume_in[i - nc];      // (bit 31: parked beside a shadow pair — the control word says so too)
 				// the closest-hit answer of queue entry i (the traversal kernel wrote it at the ray's queue position)
 				float4 ans = make_float4(0.f, 0.f, 0.f, 0.f);
-				if(i < nc) ans = a.state[2 * (size_t)a.cap + i];
+				if(i < nc)
+				{
+					if(YAFGPU_FEAT_LIGHTS && a.replay == 2 && a.hit_cache != nullptr)
+					{	// the final pass of a serial-state replay: the record pass kept this query's answer (wf_hit_key; a segment parked beside a shadow
+						// pair is filed under the control word st_start_path / st_extend would have parked it with: wf_ctl_of_beside)
+						uint32_t ctl = ubits(wf_rec(a, 13, slot).w);
+						if(a.q_closest_in && (a.q_closest_in[i] >> 31)) ctl = wf_ctl_of_beside(ctl);
+						const uint32_t z19 = a.ev_m > 1 ? ubits(wf_rec(a, 19, slot).z) : 0u;
+						ans = a.hit_cache[wf_hit_key(a, slot, ctl, z19)];
+					}
+					else ans = a.state[2 * (size_t)a.cap + i];
+				}
 				int px, py, sample; uint32_t pixel_sample, sampling_offs, ordinal;
 				wf_identity<true>(a, slot, px, py, sample, pixel_sample, sampling_offs, ordinal);
 				float res[4];

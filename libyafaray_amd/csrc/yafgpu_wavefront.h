@@ -2234,47 +2234,62 @@ __global__ __launch_bounds__(kWave) void wf_replay_tiles(const ReplayArgs r)
 		const uint32_t e0 = r.seg_begin[seg] * per_px, n_ent = (r.seg_begin[seg + 1u] - r.seg_begin[seg]) * per_px;
 		Mwc rr; rr.init(r.seg_seed[seg]);
 		uint32_t total = 0u;
-		for(uint32_t base = 0u; base < n_ent; base += kWave)
+		// (four groups of 64 entries per turn: their flags are asked for together — the walk itself stays in entry order)
+		constexpr uint32_t kGroups = 4u;
+		for(uint32_t base0 = 0u; base0 < n_ent; base0 += kGroups * kWave)
 		{
-			const uint32_t e = e0 + base + (uint32_t)lane;
-			const bool live = base + (uint32_t)lane < n_ent;
-			const uint32_t flags = live ? r.ev_flags[e] : 0u;
-			const uint32_t tests = flags >> 16;
-			if(__ballot(tests != 0u) == 0ull)
-			{	// no roulette test among these 64: nothing serial to do
-				const uint32_t calls = (uint32_t)__popc(flags & 0xffffu);
-				if(live) { r.ev_kill[e] = 255u; r.ev_calls[e] = (uint8_t)calls; }
-				total += wave_sum(calls);
-				continue;
-			}
-			s_flags[lane] = flags;
-			for(uint32_t d = 1u; d < r.bounces; ++d)
-				if((tests >> d) & 1u) s_p[lane][d] = r.ev_p[(size_t)e * r.n_prob + (d - 1u)];
-			__syncthreads();
-			if(lane == 0)
+			uint32_t fl[kGroups];
+#pragma unroll
+			for(uint32_t g = 0u; g < kGroups; ++g)
 			{
-				const uint32_t cnt = min((uint32_t)kWave, n_ent - base);
-				for(uint32_t j = 0u; j < cnt; ++j)
-				{
-					const uint32_t f = s_flags[j];
-					uint32_t kill = 255u, calls = f & 1u;
-					for(uint32_t d = 1u; d < r.bounces; ++d)
-					{
-						calls += (f >> d) & 1u;
-						if((f >> (16u + d)) & 1u)
-						{
-							const float random_value = (float)rr.next();
-							const float probability = s_p[j][d];
-							if(probability <= 0.f || probability < random_value) { kill = d; break; }
-						}
-					}
-					s_kill[j] = (uint8_t)kill; s_calls[j] = (uint8_t)calls;
-					total += calls;
-				}
+				const uint32_t off = base0 + g * kWave + (uint32_t)lane;
+				fl[g] = off < n_ent ? r.ev_flags[e0 + off] : 0u;
 			}
-			__syncthreads();
-			if(live) { r.ev_kill[e] = s_kill[lane]; r.ev_calls[e] = s_calls[lane]; }
-			__syncthreads();
+#pragma unroll
+			for(uint32_t g = 0u; g < kGroups; ++g)
+			{
+				const uint32_t base = base0 + g * kWave;
+				if(base >= n_ent) break;
+				const uint32_t e = e0 + base + (uint32_t)lane;
+				const bool live = base + (uint32_t)lane < n_ent;
+				const uint32_t flags = fl[g];
+				const uint32_t tests = flags >> 16;
+				if(__ballot(tests != 0u) == 0ull)
+				{	// no roulette test among these 64: nothing serial to do
+					const uint32_t calls = (uint32_t)__popc(flags & 0xffffu);
+					if(live) { r.ev_kill[e] = 255u; r.ev_calls[e] = (uint8_t)calls; }
+					total += wave_sum(calls);
+					continue;
+				}
+				s_flags[lane] = flags;
+				for(uint32_t d = 1u; d < r.bounces; ++d)
+					if((tests >> d) & 1u) s_p[lane][d] = r.ev_p[(size_t)e * r.n_prob + (d - 1u)];
+				__syncthreads();
+				if(lane == 0)
+				{
+					const uint32_t cnt = min((uint32_t)kWave, n_ent - base);
+					for(uint32_t j = 0u; j < cnt; ++j)
+					{
+						const uint32_t f = s_flags[j];
+						uint32_t kill = 255u, calls = f & 1u;
+						for(uint32_t d = 1u; d < r.bounces; ++d)
+						{
+							calls += (f >> d) & 1u;
+							if((f >> (16u + d)) & 1u)
+							{
+								const float random_value = (float)rr.next();
+								const float probability = s_p[j][d];
+								if(probability <= 0.f || probability < random_value) { kill = d; break; }
+							}
+						}
+						s_kill[j] = (uint8_t)kill; s_calls[j] = (uint8_t)calls;
+						total += calls;
+					}
+				}
+				__syncthreads();
+				if(live) { r.ev_kill[e] = s_kill[lane]; r.ev_calls[e] = s_calls[lane]; }
+				__syncthreads();
+			}
 		}
 		if(lane == 0) r.seg_total[seg] = total;
 	}
@@ -2297,17 +2312,32 @@ __global__ __launch_bounds__(kWave) void wf_replay_samples(const ReplayArgs r)
 	{
 		const uint32_t s0 = r.seg_begin[seg] * r.spp, n_slots = (r.seg_begin[seg + 1u] - r.seg_begin[seg]) * r.spp;
 		uint32_t run = r.seg_base_in ? r.seg_base_in[seg] : r.seg_total[seg];
-		for(uint32_t base = 0u; base < n_slots; base += kWave)
+		constexpr uint32_t kGroups = 4u;      // (as in wf_replay_tiles: four groups' loads in flight, the scan in slot order)
+		for(uint32_t base0 = 0u; base0 < n_slots; base0 += kGroups * kWave)
 		{
-			const uint32_t slot = s0 + base + (uint32_t)lane;
-			const bool live = base + (uint32_t)lane < n_slots;
-			uint32_t calls = 0u;
-			if(live) for(uint32_t i = 0u; i < r.n_paths; ++i) calls += r.ev_calls[(size_t)slot * r.n_paths + i];
-			uint32_t incl = calls;
+			uint32_t cl[kGroups];
 #pragma unroll
-			for(int o = 1; o < kWave; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, kWave); if(lane >= o) incl += v; }
-			if(live) r.lc_base[slot] = run + incl - calls;
-			run += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+			for(uint32_t g = 0u; g < kGroups; ++g)
+			{
+				const uint32_t off = base0 + g * kWave + (uint32_t)lane;
+				uint32_t calls = 0u;
+				if(off < n_slots) for(uint32_t i = 0u; i < r.n_paths; ++i) calls += r.ev_calls[(size_t)(s0 + off) * r.n_paths + i];
+				cl[g] = calls;
+			}
+#pragma unroll
+			for(uint32_t g = 0u; g < kGroups; ++g)
+			{
+				const uint32_t base = base0 + g * kWave;
+				if(base >= n_slots) break;
+				const uint32_t slot = s0 + base + (uint32_t)lane;
+				const bool live = base + (uint32_t)lane < n_slots;
+				const uint32_t calls = cl[g];
+				uint32_t incl = calls;
+#pragma unroll
+				for(int o = 1; o < kWave; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, kWave); if(lane >= o) incl += v; }
+				if(live) r.lc_base[slot] = run + incl - calls;
+				run += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+			}
 		}
 	}
 }

@@ -1681,6 +1681,7 @@ static int validate(const yafgpu_scene *s, const yafgpu_render_params *rp)
 	if(rp->filter_type < YAFGPU_FILTER_BOX || rp->filter_type > YAFGPU_FILTER_LANCZOS) return fail(-12, "unknown filter type");
 	if(rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) return fail(-13, "bad shard index/count");
 	if(rp->integrator != YAFGPU_INTEGRATOR_PATH && rp->integrator != YAFGPU_INTEGRATOR_DIRECT) return fail(-14, "unknown integrator");
+	if(rp->path_samples > 8191) return fail(-11, "path_samples > 8191: the device path counts a level's path samples in 13 bits of the control word");
 	// the sample index of a light estimate in flight is packed in 12 bits (pack_dlc); validate() runs for every pass, so a
 	// light-sample multiplier that grows over the passes of an adaptive render is caught when it gets there
 	for(const yafgpu_light &l : s->h_lights)
@@ -1717,10 +1718,12 @@ static int wf_grid(const void *kernel, int cus)
 // other scene takes the general kernel of this unit.  YAFGPU_SHADE_VARIANT=general forces the general kernel.
 extern "C" {
 #define YG_DECLARE_SHADE_VARIANT(name) \
-	void yafgpu_shade_##name##_describe(uint32_t *, int *, int *); const void *yafgpu_shade_##name##_kernel(); \
+	void yafgpu_shade_##name##_describe(uint32_t *, int *, int *, int *); const void *yafgpu_shade_##name##_kernel(); \
 	int yafgpu_shade_##name##_launch(const void *, size_t, int, hipStream_t);
 YG_DECLARE_SHADE_VARIANT(diffuse)
 YG_DECLARE_SHADE_VARIANT(glossy)
+YG_DECLARE_SHADE_VARIANT(diffuse_mp)
+YG_DECLARE_SHADE_VARIANT(glossy_mp)
 YG_DECLARE_SHADE_VARIANT(diffuse_rec)
 YG_DECLARE_SHADE_VARIANT(glossy_rec)
 YG_DECLARE_SHADE_VARIANT(full)
@@ -1729,19 +1732,22 @@ YG_DECLARE_SHADE_VARIANT(full)
 struct ShadeVariant
 {
 	const char *name;
-	void (*describe)(uint32_t *, int *, int *);
+	void (*describe)(uint32_t *, int *, int *, int *);
 	const void *(*kernel)();
 	int (*launch)(const void *, size_t, int, hipStream_t);
 };
 static const ShadeVariant kShadeVariants[] = {
 	{"diffuse", yafgpu_shade_diffuse_describe, yafgpu_shade_diffuse_kernel, yafgpu_shade_diffuse_launch},
 	{"glossy", yafgpu_shade_glossy_describe, yafgpu_shade_glossy_kernel, yafgpu_shade_glossy_launch},
+	// (with a second MIS pair per park, YAFGPU_FEAT_MULTI: for scenes whose light estimates have one to offer)
+	{"diffuse_mp", yafgpu_shade_diffuse_mp_describe, yafgpu_shade_diffuse_mp_kernel, yafgpu_shade_diffuse_mp_launch},
+	{"glossy_mp", yafgpu_shade_glossy_mp_describe, yafgpu_shade_glossy_mp_kernel, yafgpu_shade_glossy_mp_launch},
 	// (the programs of a serial-state replay's record pass: no light estimate, YAFGPU_FEAT_LIGHTS=0)
 	{"diffuse_rec", yafgpu_shade_diffuse_rec_describe, yafgpu_shade_diffuse_rec_kernel, yafgpu_shade_diffuse_rec_launch},
 	{"glossy_rec", yafgpu_shade_glossy_rec_describe, yafgpu_shade_glossy_rec_kernel, yafgpu_shade_glossy_rec_launch},
 	{"full", yafgpu_shade_full_describe, yafgpu_shade_full_kernel, yafgpu_shade_full_launch},      // everything but shader nodes
 };
-static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames, bool record_pass = false)
+static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames, bool record_pass = false, bool want_multi = false)
 {
 	if(const char *e = std::getenv("YAFGPU_SHADE_VARIANT")) if(std::strcmp(e, "general") == 0) return nullptr;
 	if(record_pass) if(const char *e = std::getenv("YAFGPU_RECORD_VARIANT")) if(std::atoi(e) == 0) return nullptr;      // (A/B: the record pass on the pass's own kernel)
@@ -1749,9 +1755,10 @@ static const ShadeVariant *pick_shade_variant(const yafgpu_scene *s, int frames,
 	if(s->has_textures || s->has_aniso) return nullptr;        // the variants are built without shader nodes and without the anisotropic lobe
 	for(const ShadeVariant &v : kShadeVariants)
 	{
-		uint32_t mask = 0u; int recurse = 0, lights = 1;
-		v.describe(&mask, &recurse, &lights);
+		uint32_t mask = 0u; int recurse = 0, lights = 1, multi = 0;
+		v.describe(&mask, &recurse, &lights, &multi);
 		if((lights == 0) != record_pass) continue;
+		if(!record_pass && (multi != 0) != want_multi) continue;
 		if((s->mat_mask & ~mask) == 0u && (recurse || !needs_recurse)) return &v;
 	}
 	return nullptr;
@@ -1967,9 +1974,9 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 		HIP_OK(hipMalloc((void **)&s->wf_state, (size_t)(kWfRecs + frame_recs * frames) * cap * sizeof(float4)));
 		s->wf_frames = frames * frame_recs;      // frame records allocated per path
 		HIP_OK(hipMalloc((void **)&s->wf_results, (size_t)cap * sizeof(float4)));
-		// per buffer set: closest (cap), shadow rays (2*cap), resume (cap)
-		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)8 * cap * sizeof(uint32_t)));
-		HIP_OK(hipMalloc((void **)&s->wf_verdict, ((size_t)2 * cap + 31) / 32 * sizeof(uint32_t) + 64));      // one bit per shadow ray
+		// per buffer set: closest (cap), shadow rays (4*cap: up to two MIS pairs per park), resume (cap)
+		HIP_OK(hipMalloc((void **)&s->wf_queues, (size_t)12 * cap * sizeof(uint32_t)));
+		HIP_OK(hipMalloc((void **)&s->wf_verdict, ((size_t)4 * cap + 31) / 32 * sizeof(uint32_t) + 64));      // one bit per shadow ray
 		HIP_OK(hipMalloc((void **)&s->wf_pix_xy, (size_t)cap * sizeof(uint32_t)));     // pixels of a chunk <= paths of a chunk
 		s->wf_cap = cap;
 	}
@@ -2071,7 +2078,26 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 	const int cus = s->n_cus;
 	const int g_trace_c = stats ? wf_grid((const void *)wf_trace<false, true>, cus) : wf_grid((const void *)wf_trace<false, false>, cus);
 	const int g_trace_s = stats ? wf_grid((const void *)wf_trace<true, true>, cus) : wf_grid((const void *)wf_trace<true, false>, cus);
-	const ShadeVariant *shade_variant = pick_shade_variant(s, frames);
+	// two MIS pairs per park (WfArgs::multi): not with transparent shadows (their filter products are kept per pair), not with recursion frames —
+	// and only where a light estimate can have a second pair at all: the kernels that carry it are a little slower on the first
+	bool want_multi = !(rp.transp_shad != 0 && s->has_transparent) && frames == 0;
+	if(const char *e = std::getenv("YAFGPU_MULTI_PAIR")) if(std::atoi(e) == 0) want_multi = false;
+	if(want_multi)
+	{
+		int pairs = 0;
+		for(int i = 0; i < s->n_lights; ++i)
+		{
+			const yafgpu_light &l = s->h_lights[(size_t)i];
+			pairs += l.type == YAFGPU_LIGHT_POINT ? 1 : (int)std::ceil((float)l.samples * rp.aa_light_sample_multiplier);
+		}
+		want_multi = pairs > 1;
+	}
+	const ShadeVariant *shade_variant = pick_shade_variant(s, frames, false, want_multi);
+	if(!shade_variant && want_multi)
+	{	// no kernel with the second pair for these materials: the one without it rather than the general kernel
+		shade_variant = pick_shade_variant(s, frames, false, false);
+		if(shade_variant) want_multi = false;
+	}
 	if(std::getenv("YAFGPU_VERBOSE")) std::fprintf(stderr, "[yafgpu] shading kernel: %s (materials 0x%x, frames %d), serial replay: %s\n", shade_variant ? shade_variant->name : "general", s->mat_mask, frames,
 	                                               replay ? (replay_lights ? (need_rr ? "roulette + light counter" : "light counter") : "roulette") : "off");
 	const int g_shade = wf_grid(shade_variant ? shade_variant->kernel() : (const void *)wf_shade, cus);
@@ -2142,12 +2168,13 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 		if(masked) HIP_OK(hipMemcpyAsync(s->wf_pix_xy, listed.data() + ch.pixel_begin, (size_t)a.n_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		a.ev_flags = s->rp_flags; a.ev_p = s->rp_p; a.ev_kill = s->rp_kill; a.ev_calls = s->rp_calls; a.lc_base = s->rp_base;
 		a.replay_lights = replay_lights ? 1 : 0; a.ev_m = (int)ev_m;
+		a.multi = want_multi ? 1 : 0;
 		a.speculate = 1;      // the next segment beside a vertex's last shadow pair (WfArgs::speculate); YAFGPU_SPECULATE=0: the sequential phases
 		if(const char *e = std::getenv("YAFGPU_SPECULATE")) a.speculate = std::atoi(e) != 0 ? 1 : 0;
 		a.hit_cache = use_hits ? s->rp_hits : nullptr; a.hit_k = (int)hit_k;
 		const size_t cp = s->wf_cap;
-		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 3 * cp},
-		                        {s->wf_queues + 4 * cp, s->wf_queues + 5 * cp, s->wf_queues + 7 * cp}};   // closest, shadow rays (2*cap), resume
+		uint32_t *qset[2][3] = {{s->wf_queues, s->wf_queues + cp, s->wf_queues + 5 * cp},
+		                        {s->wf_queues + 6 * cp, s->wf_queues + 7 * cp, s->wf_queues + 11 * cp}};   // closest, shadow rays (4*cap), resume
 		uint32_t *cnt[2] = {s->wf_counts, s->wf_counts + 32};
 		a.verdict = s->wf_verdict; a.shadow_filt = transp ? s->wf_filt : nullptr;
 		const uint32_t g_gen = std::min<uint32_t>((a.n_paths + kBlock - 1) / kBlock, (uint32_t)cus * 8u);
@@ -2193,7 +2220,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 				hipStream_t any_stream = fork ? s->side_stream : stream;
 				if(it > 0 && !record)      // (a record pass has no shadow rays)
 				{
-					HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)2 * a.n_paths + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
+					HIP_OK(hipMemsetAsync(s->wf_verdict, 0, ((size_t)4 * a.n_paths + 31) / 32 * sizeof(uint32_t), any_stream));     // occluded rays set their bit
 					if((rc = timed(1, [&] {
 						if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, any_stream, a);
 						else if(stats) hipLaunchKernelGGL((wf_trace<true, true>), dim3(g_trace_s), dim3(kBlock), 0, any_stream, a);
@@ -2325,11 +2352,11 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 				c.a.pixel_begin = px_begin; c.a.n_pixels = px; c.a.n_paths = (uint32_t)np;
 				c.a.pix_prefix = s->d_pix_prefix; c.a.pix_xy = s->wf_pix_xy + (k == 0 ? 0u : px_a); c.a.pix_listed = 0;
 				c.a.ev_m = 1;
-				uint32_t *qb = s->wf_queues + 8 * slot_off;
-				c.qset[0][0] = qb; c.qset[0][1] = qb + np; c.qset[0][2] = qb + 3 * np;
-				c.qset[1][0] = qb + 4 * np; c.qset[1][1] = qb + 5 * np; c.qset[1][2] = qb + 7 * np;
+				uint32_t *qb = s->wf_queues + 12 * slot_off;
+				c.qset[0][0] = qb; c.qset[0][1] = qb + np; c.qset[0][2] = qb + 5 * np;
+				c.qset[1][0] = qb + 6 * np; c.qset[1][1] = qb + 7 * np; c.qset[1][2] = qb + 11 * np;
 				c.cnt[0] = s->wf_counts + 64 * k; c.cnt[1] = s->wf_counts + 64 * k + 32;
-				c.a.verdict = s->wf_verdict + (2 * slot_off + 31) / 32 + (k ? 1 : 0);
+				c.a.verdict = s->wf_verdict + (4 * slot_off + 31) / 32 + (k ? 1 : 0);
 				c.a.shadow_filt = transp ? s->wf_filt + 2 * slot_off : nullptr;
 				c.st = k == 0 ? stream : s->side_stream;
 				c.g_gen = std::min<uint32_t>((uint32_t)((np + kBlock - 1) / kBlock), (uint32_t)cus * 8u);
@@ -2356,7 +2383,7 @@ static int render_wavefront(yafgpu_scene *s, RenderArgs &ra, hipStream_t caller,
 					hipLaunchKernelGGL((wf_trace<false, false>), dim3(g_trace_c), dim3(kBlock), 0, c.st, c.a);
 					if(it > 0)
 					{
-						HIP_OK(hipMemsetAsync(c.a.verdict, 0, ((size_t)2 * c.a.n_paths + 31) / 32 * sizeof(uint32_t), c.st));
+						HIP_OK(hipMemsetAsync(c.a.verdict, 0, ((size_t)4 * c.a.n_paths + 31) / 32 * sizeof(uint32_t), c.st));
 						if(transp) hipLaunchKernelGGL(wf_trace_ts, dim3(cus * 8), dim3(kBlock), 0, c.st, c.a);
 						else hipLaunchKernelGGL((wf_trace<true, false>), dim3(g_trace_s), dim3(kBlock), 0, c.st, c.a);
 					}

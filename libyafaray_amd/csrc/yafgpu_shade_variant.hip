@@ -4,7 +4,7 @@
 // and scratch budget is set by the union of them all (168 VGPRs + 116 B of scratch at 3 waves per SIMD).  Scenes
 // that use a subset run a kernel compiled for that subset: this file is compiled once per variant with
 //
-//   -DYAFGPU_VARIANT_NAME=<name>  -DYAFGPU_MAT_MASK=<bit per YAFGPU_MAT_* handled>  -DYAFGPU_FEAT_RECURSE=<0|1>  [-DYAFGPU_FEAT_LIGHTS=0]
+//   -DYAFGPU_VARIANT_NAME=<name>  -DYAFGPU_MAT_MASK=<bit per YAFGPU_MAT_* handled>  -DYAFGPU_FEAT_RECURSE=<0|1>  [-DYAFGPU_FEAT_LIGHTS=0]  [-DYAFGPU_FEAT_MULTI=0]
 //
 // (FEAT_LIGHTS=0: the program of a serial-state replay's RECORD pass — no light estimate, the vertex of a resume in registers)
 //
@@ -26,9 +26,9 @@ namespace vns = yafgpu;
 extern "C" {
 
 // material types / features this variant was compiled for
-void YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _describe)(uint32_t *mat_mask, int *recurse, int *lights)
+void YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _describe)(uint32_t *mat_mask, int *recurse, int *lights, int *multi)
 {
-	*mat_mask = (uint32_t)(YAFGPU_MAT_MASK); *recurse = YAFGPU_FEAT_RECURSE; *lights = YAFGPU_FEAT_LIGHTS;
+	*mat_mask = (uint32_t)(YAFGPU_MAT_MASK); *recurse = YAFGPU_FEAT_RECURSE; *lights = YAFGPU_FEAT_LIGHTS; *multi = YAFGPU_FEAT_LIGHTS && YAFGPU_FEAT_MULTI;
 }
 const void *YG_CAT(YG_CAT(yafgpu_shade_, YAFGPU_VARIANT_NAME), _kernel)() { return (const void *)vns::wf_shade; }
 // args: the main unit's WfArgs (same definition, so the same layout)

@@ -19,7 +19,7 @@
 
 namespace yafgpu {
 
-constexpr int kWfRecs = 28;   // float4 records of parked state per path (448 B; 22 and 23 are only touched in textured scenes, 24 and 25 only with bump mapping, 26 and 27 by a path that parks its next segment beside a vertex's last shadow pair)
+constexpr int kWfRecs = 32;   // float4 records of parked state per path (512 B; 28..31 hold a SECOND MIS pair parked with the first (WfArgs::multi); 22 and 23 are only touched in textured scenes, 24 and 25 only with bump mapping, 26 and 27 by a path that parks its next segment beside a vertex's last shadow pair)
 
 struct WfArgs
 {
@@ -38,7 +38,7 @@ struct WfArgs
 	// MIS pair).  resume queue: the paths (once each) that wait for shadow answers.
 	const uint32_t *q_closest_in, *q_shadow_in, *q_resume_in;   // nullptr closest queue = identity (first iteration)
 	uint32_t *q_closest_out, *q_shadow_out, *q_resume_out;
-	uint32_t *verdict;                // any-hit answers: BIT 2*slot + which, set for an occluded ray (zeroed before every any-hit launch)
+	uint32_t *verdict;                // any-hit answers: BIT 4*slot + 2*pair + which, set for an occluded ray (zeroed before every any-hit launch)
 	float4 *shadow_filt;              // [2*slot + which] product of the transparencies a shadow ray passed (transparent shadows), or nullptr
 	// Serial-state replay (DESIGN.md "serial state").  The reference keeps two pieces of state that run
 	// through the samples of a render in order: the per-tile MWC stream Russian roulette draws from (integrator_tiled.cc:319,
@@ -69,6 +69,11 @@ struct WfArgs
 	// and one launch tail less per vertex.  Only where nothing in between can change course: no recursion frames, and a roulette test at
 	// this vertex only when the serial-state replay has its outcome on the table.  0: off (comparison runs, YAFGPU_SPECULATE=0).
 	int speculate;
+	// Two MIS pairs per park (DESIGN.md "pairs per park"): a vertex whose light estimate has another pair to go after the one it is about to
+	// park for — another sample of the light, or the next light — evaluates that one too and parks for both (records 28..31, two more verdict
+	// bits, two more bits of the shadow-queue entry): the shadow answers steer nothing, so the second pair is what the resumed path would have
+	// evaluated next, and a light with n samples costs n / 2 state round trips per vertex.  Not with transparent shadows or recursion frames.
+	int multi;
 	uint32_t *cnt_in;                 // [0] closest count, [1] shadow-ray count, [2] closest fetch cursor, [3] shadow fetch cursor, [4] resume count
 	uint32_t *cnt_out;                // same layout, filled by wf_shade for the next iteration
 };
@@ -262,15 +267,15 @@ YG_DEV const yafgpu_material &wf_mat_parked(const WfArgs &a, uint32_t slot, int 
 	return m;
 }
 
-struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl, add; };   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_; add: integrate()'s additional_depth
-YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.add << 12) | ((uint32_t)c.incl << 16) | ((uint32_t)c.path_i << 17); }
+struct Ctl { Col col; int pc, stage, dl_on_sp0, depth, path_i, level, incl, add, mask2; };   // mask2: the second pair parked with the first (WfArgs::multi): which of its rays are out   // level: raylevel of recursiveRaytrace; incl: RenderState::include_lights_; add: integrate()'s additional_depth
+YG_DEV uint32_t pack_ctl(const Ctl &c) { return (uint32_t)c.pc | ((uint32_t)c.stage << 2) | ((uint32_t)c.dl_on_sp0 << 4) | ((uint32_t)c.level << 5) | ((uint32_t)c.depth << 8) | ((uint32_t)c.add << 12) | ((uint32_t)c.incl << 16) | (((uint32_t)c.path_i & 0x1fffu) << 17) | ((uint32_t)c.mask2 << 30); }
 YG_DEV Ctl load_ctl(const WfArgs &a, uint32_t slot)
 {
 	const float4 r = REC(13);
 	const uint32_t w = ubits(r.w);
 	Ctl c; c.col = c3(r);
 	c.pc = (int)(w & 3u); c.stage = (int)((w >> 2) & 3u); c.dl_on_sp0 = (int)((w >> 4) & 1u); c.level = (int)((w >> 5) & 7u);
-	c.depth = (int)((w >> 8) & 0xfu); c.add = (int)((w >> 12) & 0xfu); c.incl = (int)((w >> 16) & 1u); c.path_i = (int)(w >> 17);      // depth < bounces <= 12
+	c.depth = (int)((w >> 8) & 0xfu); c.add = (int)((w >> 12) & 0xfu); c.incl = (int)((w >> 16) & 1u); c.path_i = (int)((w >> 17) & 0x1fffu); c.mask2 = (int)(w >> 30);      // depth < bounces <= 12; path samples < 8192
 	return c;
 }
 YG_DEV uint32_t pack_dlc(int li, int l_end, int mask, int is) { return (uint32_t)li | ((uint32_t)l_end << 8) | ((uint32_t)mask << 16) | ((uint32_t)is << 20); }
@@ -442,6 +447,12 @@ template<int K> YG_DEV float4 vtx_get(const WfArgs &a, uint32_t slot, Hot &h)
 #ifndef YAFGPU_FEAT_LIGHTS
 #define YAFGPU_FEAT_LIGHTS 1
 #endif
+// Two MIS pairs per park (WfArgs::multi).  A kernel built with 0 parks one pair at a time: the second pair's bookkeeping costs the path
+// program 14 more spilled registers (the diffuse variant's launches +10 %), so scenes whose light estimates never have a second pair to
+// offer — one light with one sample, the benchmark scenes — run kernels built without it (yafgpu_device.hip: pick_shade_variant).
+#ifndef YAFGPU_FEAT_MULTI
+#define YAFGPU_FEAT_MULTI 1
+#endif
 #if YAFGPU_FEAT_LIGHTS
 #define A_REPLAY (a.replay)
 #define VGET(k) REC(k)
@@ -475,7 +486,7 @@ YG_DEV float add_mod_1(float x, float y) { const float t = x + y; return t > 1 ?
 // record 19 hold at the park — (call, path sample, segment); a level's own ray (segment 0) belongs to the call about to start
 YG_DEV uint32_t wf_hit_key(const WfArgs &a, uint32_t slot, uint32_t ctl, uint32_t z19)
 {
-	const int stage = (int)((ctl >> 2) & 3u), level = (int)((ctl >> 5) & 7u), depth = (int)((ctl >> 8) & 0xfu), path_i = (int)(ctl >> 17);
+	const int stage = (int)((ctl >> 2) & 3u), level = (int)((ctl >> 5) & 7u), depth = (int)((ctl >> 8) & 0xfu), path_i = (int)((ctl >> 17) & 0x1fffu);
 	const uint32_t n_ps = (uint32_t)max(a.ra.rp.path_samples, 1), per_path = (uint32_t)max(a.ra.rp.bounces, 1) + 1u;
 	uint32_t call = a.ev_m > 1 ? (z19 >> 24) : 0u, seg = 0u, ps = 0u;
 	if(stage == kStPrimary) call = level > 0 ? call + 1u : 0u;      // (the camera ray: record 19 is not set up yet)
@@ -608,12 +619,15 @@ YG_DEV int st_after_closest(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint
 }
 
 // the shadow rays of one MIS pair were answered: add what was unoccluded
-YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict)
+// second: the SECOND pair of the park (WfArgs::multi) — the path stands at its W_DL_EVAL (record 14 names the pair, st_dl_next put it there); what
+// st_dl_eval would have left is in records 29 (first ray's contribution) and 31 (second ray's), which rays went out in mask2
+YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict, bool second = false, int mask2 = 0)
 {
 	const DevScene &sc = a.ra.sc;
 	float4 r14 = HGET(14);
 	const uint32_t w = ubits(r14.w);
-	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = (int)((w >> 16) & 0x3u), is = (int)(w >> 20);
+	const int li = (int)(w & 0xffu), l_end = (int)((w >> 8) & 0xffu), mask = second ? mask2 : (int)((w >> 16) & 0x3u), is = (int)(w >> 20);
+	if(second) { const float4 r29 = REC(29); r14.x = r29.x; r14.y = r29.y; r14.z = r29.z; }
 	const bool dirac = sc.lights[li].type == YAFGPU_LIGHT_POINT;
 	// transparent shadows (integrator_montecarlo.cc:114,182,309): what an unblocked ray picked up on its way scales the
 	// light.  (The reference scales the light colour before forming the contribution, here the parked contribution is
@@ -628,7 +642,8 @@ YG_DEV int st_after_shadow(const WfArgs &a, uint32_t slot, Hot &h, uint2 verdict
 	}
 	if((mask & 2) && verdict.y == 0u)
 	{
-		const Col add = (a.shadow_filt != nullptr) ? c3(REC(21)) * fb : c3(REC(21));
+		const float4 rb = second ? REC(31) : REC(21);
+		const Col add = (a.shadow_filt != nullptr) ? c3(rb) * fb : c3(rb);
 		HSET(16, f4(c3(HGET(16)) + add, 0.f));
 	}
 	r14.w = fbits(pack_dlc(li, l_end, 0, is + 1));
@@ -670,10 +685,12 @@ YG_DEV int st_dl_next(const WfArgs &a, uint32_t slot, Hot &h, int level)
 	return W_DL_DONE;
 }
 
-YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask)
+// second: evaluate the pair named by `w2` as the SECOND pair of the park about to happen (WfArgs::multi): its rays and contributions go to records
+// 28..31, record 14 and the accumulators are left alone; W_PARK_SHADOW with the rays wanted in out_mask, anything else: no second pair
+YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, int &out_mask, bool second = false, uint32_t w2 = 0u)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc;
-	const uint32_t w = ubits(HGET(14).w);
+	const uint32_t w = second ? w2 : ubits(HGET(14).w);
 	const int li = (int)(w & 0xffu), is = (int)(w >> 20), l_end = (int)((w >> 8) & 0xffu);
 	SurfPt sp; V3 wo;
 	if(c.dl_on_sp0) { const float4 p = REC(3); make_sp(v3(p), v3(REC(4)), v3(REC(5)), (int)ubits(p.w), sp); wo = v3(REC(6)); }
@@ -685,6 +702,7 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 	const yafgpu_light &light = sc.lights[li];
 	const bool dirac = light.type == YAFGPU_LIGHT_POINT;
 	const bool cast_shadows = light.cast_shadows && mat.receive_shadows;
+	if(second && !cast_shadows) return W_DL_NEXT;      // (its contributions would go straight into the accumulators: out of order before the first pair's)
 	float s_1 = 0.f, s_2 = 0.f;
 	if(!dirac) dl_samples(ra, light, li, is, wf_div(a, slot, c.level).division, pixel_sample, sampling_offs, s_1, s_2);
 	V3 d; float tmin, tmax; Col contrib;
@@ -693,14 +711,21 @@ YG_DEV int st_dl_eval(const WfArgs &a, uint32_t slot, Hot &h, const Ctl &c, uint
 	float tmin_a = 0.f;
 	if(dl_candidate(ra, light, 0, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
 	{
-		if(cast_shadows) { pending_a = contrib; tmin_a = tmin; REC(1) = f4(d, tmax); mask |= 1; }
+		if(cast_shadows) { pending_a = contrib; tmin_a = tmin; wf_rec(a, second ? 28 : 1, slot) = f4(d, tmax); mask |= 1; }
 		else if(dirac) HSET(17, f4(c3(HGET(17)) + contrib, 0.f));
 		else HSET(15, f4(c3(HGET(15)) + contrib, 0.f));
 	}
 	if(!dirac && dl_candidate(ra, light, 1, s_1, s_2, sp, mat, dat, wo, d, tmin, tmax, contrib))
 	{
-		if(cast_shadows) { REC(20) = f4(d, tmin); REC(21) = f4(contrib, tmax); mask |= 2; }
+		if(cast_shadows) { wf_rec(a, second ? 30 : 20, slot) = f4(d, tmin); wf_rec(a, second ? 31 : 21, slot) = f4(contrib, tmax); mask |= 2; }
 		else HSET(16, f4(c3(HGET(16)) + contrib, 0.f));
+	}
+	if(second)
+	{
+		if(!mask) return W_DL_NEXT;
+		REC(29) = f4(pending_a, tmin_a);      // (the origin is the first pair's, record 0)
+		out_mask = mask;
+		return W_PARK_SHADOW;
 	}
 	if(mask)
 	{
@@ -916,12 +941,13 @@ YG_DEV int st_start_path(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_
 // vertex — and park for both (WfArgs::speculate).  Everything written here is what those steps would write after the answers, except
 // what the pending estimate still reads: the ray goes to record 26 (records 0 / 1 hold the shadow ray), st_extend's colour to
 // record 27 (record 11 must keep the throughput the estimate is booked with), and the control word's stage is advanced on resume.
-YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal)
+// w_last: the (li, l_end, is) word of the last pair of this park — record 14's, or the second pair's (WfArgs::multi)
+YG_DEV int st_beside(const WfArgs &a, uint32_t slot, Hot &h, Ctl &c, uint32_t pixel_sample, uint32_t sampling_offs, uint32_t ordinal, uint32_t w_last)
 {
 	const RenderArgs &ra = a.ra; const DevScene &sc = ra.sc; const yafgpu_render_params &rp = ra.rp;
 	if(!a.speculate || A_REPLAY == 1 || a.frames != 0 || rp.integrator != YAFGPU_INTEGRATOR_PATH) return W_PARK_SHADOW;      // (a record pass has no shadow parks anyway)
 	{	// the last pair of the estimate?
-		const uint32_t w14 = ubits(HGET(14).w);
+		const uint32_t w14 = w_last;
 		const int li = (int)(w14 & 0xffu), l_end = (int)((w14 >> 8) & 0xffu), is = (int)(w14 >> 20);
 		if(li + 1 != l_end) return W_PARK_SHADOW;
 		const yafgpu_light &light = sc.lights[li];
@@ -1247,12 +1273,14 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 #if !YAFGPU_FEAT_LIGHTS
 	h.vvalid = 0u;
 #endif
+	uint32_t w_last = 0u;      // the (li, l_end, is) word of the last pair the path is about to park for (st_beside)
 	float alpha = 0.f;
-	uint2 verdict = make_uint2(0u, 0u);
+	uint2 verdict = make_uint2(0u, 0u), verdict2 = verdict;
 	if(where == W_AFTER_SHADOW)
-	{	// bit 2*slot + which of the verdict bit array (set by the any-hit kernel for an occluded ray)
-		const uint32_t w = a.verdict[slot >> 4], sh = (slot & 15u) << 1;
+	{	// bits 4*slot + 2*pair + which of the verdict bit array (set by the any-hit kernel for an occluded ray)
+		const uint32_t w = a.verdict[slot >> 3], sh = (slot & 7u) << 2;
 		verdict = make_uint2((w >> sh) & 1u, (w >> (sh + 1u)) & 1u);
+		verdict2 = make_uint2((w >> (sh + 2u)) & 1u, (w >> (sh + 3u)) & 1u);
 		hot_preload(a, slot, h, c.stage != kStPrimary);
 	}
 	// The step graph has no backward edge except NEXT <-> EVAL, so the program is written out once in topological
@@ -1262,10 +1290,19 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	// estimate — the small steps, a second time, ahead of everything: the answers, the one light still open, the booking — and then
 	// runs the vertex steps below for the segment's hit.  (A second turn through the big steps instead, as a loop or by calling the
 	// program again, made the optimizer keep the union of their registers alive: 65-90 spilled VGPRs.)
+	// a SECOND pair parked with the first (WfArgs::multi): booked where the path would have evaluated it, at its W_DL_EVAL
+	int pend2 = (YAFGPU_FEAT_LIGHTS && YAFGPU_FEAT_MULTI) ? c.mask2 : 0;
+	c.mask2 = 0;
 	if(beside)
 	{
 		where = st_after_shadow(a, slot, h, verdict);
 		if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);       // closes the light: st_beside only goes ahead at the last pair
+		if(YAFGPU_FEAT_MULTI && where == W_DL_EVAL && pend2)
+		{	// ... which was the second pair of the park
+			where = st_after_shadow(a, slot, h, verdict2, true, pend2);
+			pend2 = 0;
+			if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
+		}
 		if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c, true);
 		if(where == W_NEXT_VERTEX) where = W_AFTER_CLOSEST;
 	}
@@ -1273,14 +1310,43 @@ YG_DEV int wf_advance(const WfArgs &a, uint32_t slot, uint32_t pixel_sample, uin
 	if(YAFGPU_FEAT_LIGHTS)
 	{
 		if(where == W_AFTER_SHADOW) where = st_after_shadow(a, slot, h, verdict);
+		bool second = false;      // the pair being evaluated is the one AFTER the pair the path is about to park for
+		uint32_t w2 = 0u;
 		while(where == W_DL_NEXT || where == W_DL_EVAL)
 		{
 			if(where == W_DL_NEXT) where = st_dl_next(a, slot, h, c.level);
-			else where = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, out_mask);
+			else if(YAFGPU_FEAT_MULTI && pend2) { where = st_after_shadow(a, slot, h, verdict2, true, pend2); pend2 = 0; }
+			else
+			{
+				int m = 0;
+				const int r = st_dl_eval(a, slot, h, c, pixel_sample, sampling_offs, m, second, w2);
+				if(!second)
+				{
+					where = r;
+					if(r == W_PARK_SHADOW)
+					{
+						out_mask = m;
+						w_last = ubits(HGET(14).w);
+						if(YAFGPU_FEAT_MULTI && a.multi)
+						{	// the pair st_dl_next would name after this one: the light's next sample, or the next light's first
+							const int li = (int)(w_last & 0xffu), l_end = (int)((w_last >> 8) & 0xffu), is = (int)(w_last >> 20);
+							const yafgpu_light &light = a.ra.sc.lights[li];
+							const int n = light.type == YAFGPU_LIGHT_POINT ? 1 : dl_area_samples(a.ra, light, wf_div(a, slot, c.level).division);
+							const bool same = is + 1 < n;
+							if(same || li + 1 < l_end) { second = true; w2 = pack_dlc(same ? li : li + 1, l_end, 0, same ? is + 1 : 0); where = W_DL_EVAL; }
+						}
+					}
+				}
+				else
+				{
+					if(r == W_PARK_SHADOW) { c.mask2 = m; out_mask |= m << 2; w_last = w2; }
+					where = W_PARK_SHADOW;
+				}
+			}
 		}
 	}
 	if(where == W_DL_DONE) where = st_dl_done(a, slot, h, c, false);
-	if(YAFGPU_FEAT_LIGHTS && where == W_PARK_SHADOW) where = st_beside(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
+	if(YAFGPU_FEAT_LIGHTS && where == W_PARK_SHADOW) where = st_beside(a, slot, h, c, pixel_sample, sampling_offs, ordinal, w_last);
 	if(where == W_EXTEND) where = st_extend(a, slot, h, c);
 	if(where == W_START_PATH) where = st_start_path(a, slot, h, c, pixel_sample, sampling_offs, ordinal);
 	if(where == W_RECURSE) where = st_recurse(a, slot, c);
@@ -1521,7 +1587,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 	const uint32_t *q = kAny ? a.q_shadow_in : a.q_closest_in;
 	const size_t c = a.cap;
 	bool exhausted = (n == 0u);
-	uint32_t slot = 0u, node = 0u, which = 0u, qi = 0u;      // qi: the ray's position in the queue (where a closest-hit answer goes)
+	uint32_t slot = 0u, node = 0u, which = 0u, pair = 0u, qi = 0u;      // qi: the ray's position in the queue (where a closest-hit answer goes)
 	uint32_t w_next = 0u, w_end = 0u;      // this wave's reserved queue range (wave-uniform)
 	// reservation size: large enough to keep the counter word off the critical path, small enough that a short queue still spreads over all waves
 	const uint32_t batch = min((uint32_t)kTraceBatch, max((uint32_t)kWave, (n / (gridDim.x * (uint32_t)kWavesPerBlock * 2u)) & ~63u));
@@ -1533,7 +1599,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 	// path cost 9x the verdicts' size in HBM writes).  Closest-hit: 16 B at the ray's QUEUE position — waves own contiguous
 	// queue ranges, so the stores of a wave fall into a few lines that complete while still in L2 (by path they were 2.4x).
 	auto answer_any = [&](bool occluded) {
-		const uint32_t bit = 2u * slot + which;
+		const uint32_t bit = 4u * slot + 2u * pair + which;
 		if(occluded) atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u));
 	};
 	// the walk: at a node | at a non-empty leaf, waiting for the pending slot | no node left | no ray
@@ -1578,7 +1644,9 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 				const uint32_t i = first_i + rank;
 				slot = q ? q[i] : i;
 				qi = i;
-				which = slot >> 31; slot &= 0x7fffffffu;      // any-hit: the second ray of a pair; closest-hit: a segment parked beside a shadow pair
+				which = slot >> 31;                            // any-hit: the second ray of a pair; closest-hit: a segment parked beside a shadow pair
+				pair = kAny ? (slot >> 30) & 1u : 0u;          // any-hit: the second pair of a park (records 28..31)
+				slot &= kAny ? 0x3fffffffu : 0x7fffffffu;
 				float4 r0 = a.state[slot], r1 = a.state[c + slot];
 				if(!kAny && which)
 				{	// origin: the vertex in record 0; direction and tmin in record 26 (records 0.w / 1 hold the pair's first shadow ray)
@@ -1586,7 +1654,14 @@ __global__ __launch_bounds__(kBlock, YAFGPU_TRACE_WAVES) void wf_trace(const WfA
 					r1 = make_float4(r26.x, r26.y, r26.z, -1.f);
 					r0.w = r26.w;
 				}
-				if(kAny && which)
+				if(kAny && pair)
+				{	// the second pair of the park: the same origin; 28 direction | tmax and 29.w tmin of its first ray, 30 direction | tmin and 31.w tmax of its second
+					const float4 ra_ = a.state[(which ? 30 : 28) * c + slot];
+					const float rb_ = a.state[(which ? 31 : 29) * c + slot].w;
+					r1 = make_float4(ra_.x, ra_.y, ra_.z, which ? rb_ : ra_.w);
+					r0.w = which ? ra_.w : rb_;
+				}
+				else if(kAny && which)
 				{	// second ray of the pair: same origin, direction/tmin in r20, tmax in r21.w
 					const float4 r20 = a.state[20 * c + slot];
 					r1 = make_float4(r20.x, r20.y, r20.z, a.state[21 * c + slot].w);
@@ -1947,7 +2022,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace_ts(const WfArgs a)
 		const float dist = (r1.w < 0.f) ? INFINITY : r1.w - 2.f * r0.w;
 		Col filt;
 		const bool sh = kd_trace_ts(sc, stk, seen, from, dir, r0.w, dist, a.ra.rp.shadow_depth, filt);     // sray keeps ray.tmin_ (:998-999)
-		if(sh) { const uint32_t bit = 2u * slot + which; atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u)); }
+		if(sh) { const uint32_t bit = 4u * slot + which; atomicOr(&a.verdict[bit >> 5], 1u << (bit & 31u)); }      // (a park has one pair under transparent shadows)
 		a.shadow_filt[2u * slot + which] = f4(filt, 0.f);
 		++count;
 	}
@@ -2013,6 +2088,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 	__shared__ uint32_t s_tot[kWavesPerBlock][3];
 	__shared__ uint32_t s_base[kWavesPerBlock][3];
 	__shared__ uint32_t s_item[kItems][kBlock];
+	__shared__ uint8_t s_more[kItems][kBlock];      // bit0 / bit1: the first / second ray of a SECOND shadow pair (WfArgs::multi)
 	const int lane = (int)(threadIdx.x & (kWave - 1)), wave = (int)(threadIdx.x >> 6);
 	const uint32_t nc = a.cnt_in[0], nr = a.cnt_in[4];
 	const uint32_t total = nc + nr;
@@ -2031,7 +2107,7 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 		{
 			const uint32_t i = base + (uint32_t)k * kBlock + threadIdx.x;
 			const bool live = i < total;
-			int code = 0;
+			int code = 0, more = 0;
 			uint32_t slot = 0u;
 			if(live)
 			{
@@ -2063,11 +2139,13 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 				else if(req == kReqClosest) code = 1;
 				else if(req == kReqShadow) code = 2 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);
 				else if(req == kReqBoth) code = 1 | 16 | ((m & 1) ? 4 : 0) | ((m & 2) ? 8 : 0);      // the closest queue resumes it: no resume entry
+				if(req == kReqShadow || req == kReqBoth) more = (m >> 2) & 3;
 			}
 			s_item[k][threadIdx.x] = slot | ((uint32_t)code << 27);
+			s_more[k][threadIdx.x] = (uint8_t)more;
 			wc += (uint32_t)__popcll(__ballot(code & 1));
 			wr += (uint32_t)__popcll(__ballot(code & 2));
-			ws += (uint32_t)__popcll(__ballot(code & 4)) + (uint32_t)__popcll(__ballot(code & 8));
+			ws += (uint32_t)__popcll(__ballot(code & 4)) + (uint32_t)__popcll(__ballot(code & 8)) + (uint32_t)__popcll(__ballot(more & 1)) + (uint32_t)__popcll(__ballot(more & 2));
 		}
 		if(lane == 0) { s_tot[wave][0] = wc; s_tot[wave][1] = wr; s_tot[wave][2] = ws; }
 		__syncthreads();
@@ -2095,7 +2173,18 @@ __global__ __launch_bounds__(kBlock, YAFGPU_SHADE_WAVES) void wf_shade(const WfA
 			if(code & 4) a.q_shadow_out[os + (uint32_t)__popcll(ba & below)] = slot;
 			const uint32_t na = (uint32_t)__popcll(ba);
 			if(code & 8) a.q_shadow_out[os + na + (uint32_t)__popcll(bb & below)] = slot | 0x80000000u;
-			oc += (uint32_t)__popcll(bc); orr += (uint32_t)__popcll(br); os += na + (uint32_t)__popcll(bb);
+			os += na + (uint32_t)__popcll(bb);
+			// (a second pair's rays: bit 30 of the entry)
+			const int more = (int)s_more[k][threadIdx.x];
+			const unsigned long long b2a = __ballot(more & 1), b2b = __ballot(more & 2);
+			if(b2a | b2b)
+			{
+				if(more & 1) a.q_shadow_out[os + (uint32_t)__popcll(b2a & below)] = slot | 0x40000000u;
+				const uint32_t n2a = (uint32_t)__popcll(b2a);
+				if(more & 2) a.q_shadow_out[os + n2a + (uint32_t)__popcll(b2b & below)] = slot | 0xc0000000u;
+				os += n2a + (uint32_t)__popcll(b2b);
+			}
+			oc += (uint32_t)__popcll(bc); orr += (uint32_t)__popcll(br);
 		}
 		__syncthreads();   // s_tot / s_base are reused by the next round
 	}

@@ -882,6 +882,27 @@ def test_rough_glass(raydepth, integrator, extra, pipeline):
     compare_films(film, ofilm, f"rough glass raydepth {raydepth} {integrator} {extra}")
 
 
+@pytest.mark.parametrize("integrator,samples", [("pathtracing", (5, 2)), ("pathtracing", (1, 1)), ("directlighting", (4, 3))])
+def test_two_shadow_pairs_per_park(integrator, samples, pipeline):
+    """WfArgs::multi: a vertex whose light estimate has another MIS pair to go — the light's next sample, the next light — parks for two pairs
+    at once (odd counts leave a single one at the end; the last pair of an estimate still takes the next segment beside it).  The shadow answers
+    steer nothing, so the film must be the one-pair-per-park program's bit for bit, and the oracle's."""
+    import os
+    sc = scenes.cornell_soup(300, seed=61, res=(48, 40), sigma=0.08, n_lights=2)
+    sc["lights"] = [dict(l, samples=n) for l, n in zip(sc["lights"], samples)] + [{"type": "pointlight", "from": (0.3, -0.2, 0.5), "color": (1.0, 0.9, 0.8), "power": 1.5}]
+    rd = scenes.render_settings(48, 40, 3, bounces=3, raydepth=0, path_samples=2, integrator=integrator)
+    film, st, ofilm, ost = _render_with_rand_state(sc, rd, same_tree=True)
+    assert (st.rays_closest, st.rays_shadow) == (ost.rays_closest, ost.rays_shadow)
+    compare_films(film, ofilm, f"two pairs per park {integrator} {samples}")
+    os.environ["YAFGPU_MULTI_PAIR"] = "0"
+    try:
+        film1, st1, _, _ = _render_with_rand_state(sc, rd, same_tree=True)
+    finally:
+        os.environ.pop("YAFGPU_MULTI_PAIR", None)
+    assert (st1.rays_closest, st1.rays_shadow) == (st.rays_closest, st.rays_shadow)
+    assert np.array_equal(film.view(np.uint32), film1.view(np.uint32)), "one pair per park gives another film"
+
+
 @pytest.mark.parametrize("raydepth,extra", [(0, {}), (2, {"russian_roulette_min_bounces": 1}), (1, {"no_recursive": True, "path_samples": 2})])
 def test_path_caustics(raydepth, extra, pipeline):
     """caustic_type "path" — PathIntegrator's default when the parameter is absent (integrator_path_tracer.cc:36, :85): after a bounce through a
